@@ -1,0 +1,922 @@
+/* ocn_oracle.c -- CPU restatement of the Oceananigans v0.100.5 NonhydrostaticModel RK3 hot path.
+ * TEST INFRASTRUCTURE ONLY (see ocn_oracle.h). Build with -ffp-contract=off: the reference fuses multiply-adds only
+ * where `@muladd` is written; those sites use explicit fma() below, everything else is separate mul/add.
+ * All file:line citations are relative to /root/reference/src unless stated otherwise.
+ */
+#include "ocn_oracle.h"
+#include "../include/ocn_weno_coeffs.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef double _Complex cplx;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * grid
+ * ------------------------------------------------------------------------------------------------------------------ */
+static double *dupvec(const double *src, int n) {
+    double *p = (double *)malloc(sizeof(double) * (size_t)n);
+    memcpy(p, src, sizeof(double) * (size_t)n);
+    return p;
+}
+
+oro_grid *oro_grid_create(const int N[3], const int H[3], const int topo[3], const double L[3],
+                          const double *dxc, const double *dxf, const double *dyc, const double *dyf,
+                          const double *dzc, const double *dzf) {
+    oro_grid *g = (oro_grid *)calloc(1, sizeof(oro_grid));
+    const double *dc[3] = {dxc, dyc, dzc}, *df[3] = {dxf, dyf, dzf};
+    for (int d = 0; d < 3; ++d) {
+        g->N[d] = N[d]; g->H[d] = H[d]; g->topo[d] = topo[d]; g->L[d] = L[d];
+        int len = N[d] + 2 * H[d] + 1;
+        g->dc[d] = dupvec(dc[d], len);
+        g->df[d] = dupvec(df[d], len);
+    }
+    return g;
+}
+
+void oro_grid_destroy(oro_grid *g) {
+    if (!g) return;
+    for (int d = 0; d < 3; ++d) { free(g->dc[d]); free(g->df[d]); }
+    free(g);
+}
+
+/* Grids/grid_utils.jl:66-72: Face fields on Bounded dims have N+1 interior points */
+void oro_parent_size(const oro_grid *g, const int loc[3], int P[3]) {
+    for (int d = 0; d < 3; ++d)
+        P[d] = g->N[d] + 2 * g->H[d] + ((loc[d] == ORO_FACE && g->topo[d] == ORO_BOUNDED) ? 1 : 0);
+}
+
+#define DC(g, d, i) ((g)->dc[d][(i) - 1 + (g)->H[d]])
+#define DF(g, d, i) ((g)->df[d][(i) - 1 + (g)->H[d]])
+
+/* a field view addressed with Julia's 1-based (i, j, k) */
+typedef struct { double *p; long s1, s2; long off; } fld;
+
+static fld mkfld(const oro_grid *g, const double *p, const int loc[3]) {
+    int P[3];
+    oro_parent_size(g, loc, P);
+    fld f;
+    f.p = (double *)p;
+    f.s1 = P[0];
+    f.s2 = (long)P[0] * P[1];
+    f.off = (g->H[0] - 1) + f.s1 * (g->H[1] - 1) + f.s2 * (g->H[2] - 1);
+    return f;
+}
+#define AT(f, i, j, k) ((f).p[(f).off + (long)(i) + (f).s1 * (long)(j) + (f).s2 * (long)(k)])
+
+static const int LOC_U[3] = {ORO_FACE, ORO_CENTER, ORO_CENTER};
+static const int LOC_V[3] = {ORO_CENTER, ORO_FACE, ORO_CENTER};
+static const int LOC_W[3] = {ORO_CENTER, ORO_CENTER, ORO_FACE};
+static const int LOC_C[3] = {ORO_CENTER, ORO_CENTER, ORO_CENTER};
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * halo fills
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* BoundaryConditions/fill_halo_regions_periodic.jl:5-33. Acts on the parent array, over the WHOLE parent extent of
+ * the two other dimensions (fill_halo_kernels.jl:122-135). */
+static void fill_periodic(const oro_grid *g, double *c, const int loc[3], int d) {
+    int P[3];
+    oro_parent_size(g, loc, P);
+    const int H = g->H[d], N = g->N[d];
+    long st[3] = {1, P[0], (long)P[0] * P[1]};
+    int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    for (int b = 0; b < P[d2]; ++b)
+        for (int a = 0; a < P[d1]; ++a) {
+            double *line = c + a * st[d1] + b * st[d2];
+            for (int i = 1; i <= H; ++i) {          /* 1-based parent indices as in the reference */
+                line[(i - 1) * st[d]] = line[(N + i - 1) * st[d]];           /* west  */
+                line[(N + H + i - 1) * st[d]] = line[(H + i - 1) * st[d]];   /* east  */
+            }
+        }
+}
+
+/* fill_halo_regions_flux.jl:9-27 (no-flux mirror, ONE halo cell) and fill_halo_regions_open.jl:2-7 (impenetrable wall
+ * value on Face fields), launched over the interior extent of the other two dims (`:xy` etc., fill_halo_kernels.jl:69-70,
+ * Utils/kernel_launching.jl:211-221). */
+static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, int fill_open_bcs) {
+    fld f = mkfld(g, c, loc);
+    const int N = g->N[d];
+    int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    for (int b = 1; b <= g->N[d2]; ++b)
+        for (int a = 1; a <= g->N[d1]; ++a) {
+            int lo[3], hi[3], ilo[3], ihi[3];
+            lo[d1] = hi[d1] = ilo[d1] = ihi[d1] = a;
+            lo[d2] = hi[d2] = ilo[d2] = ihi[d2] = b;
+            if (loc[d] == ORO_CENTER) {             /* c[0] = c[1]; c[N+1] = c[N] */
+                lo[d] = 0; ilo[d] = 1; hi[d] = N + 1; ihi[d] = N;
+                AT(f, lo[0], lo[1], lo[2]) = AT(f, ilo[0], ilo[1], ilo[2]);
+                AT(f, hi[0], hi[1], hi[2]) = AT(f, ihi[0], ihi[1], ihi[2]);
+            } else if (fill_open_bcs) {             /* c[1] = 0; c[N+1] = 0 (ImpenetrableBoundaryCondition) */
+                lo[d] = 1; hi[d] = N + 1;
+                AT(f, lo[0], lo[1], lo[2]) = 0.0;
+                AT(f, hi[0], hi[1], hi[2]) = 0.0;
+            }
+        }
+}
+
+/* fill_halo_regions.jl:25-36 with the ordering of boundary_condition_ordering.jl:17-46: non-periodic sides first,
+ * then periodic (which also fill corners because they span the whole parent). Stable order x, y, z within a class. */
+void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs) {
+    for (int d = 0; d < 3; ++d)
+        if (g->topo[d] == ORO_BOUNDED) fill_bounded(g, c, loc, d, fill_open_bcs);
+    for (int d = 0; d < 3; ++d)
+        if (g->topo[d] == ORO_PERIODIC) fill_periodic(g, c, loc, d);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * WENO reconstruction
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* Utils/newton_div.jl:8-20 with inv_FT = Float32: exact Float32 reciprocal (CPU `inv_fast` is an IEEE divide), then one
+ * Newton step in Float64 with two fma. */
+double oro_newton_div_f32(double a, double b) {
+    float b_low = (float)b;
+    float inv_b = 1.0f / b_low;
+    double x = a * (double)inv_b;
+    x = fma(fma(x, -b, a), (double)inv_b, x);
+    return x;
+}
+
+/* Advection/weno_interpolants.jl:204-216,261: smoothness_operation for buffer 3 under @muladd
+ * beta = psi1*(C1 psi1 + C2 psi2 + C3 psi3) + psi2*(C4 psi2 + C5 psi3) + psi3*psi3*C6 */
+static inline double beta3(const double p[3], double C1, double C2, double C3, double C4, double C5, double C6) {
+    double in1 = fma(C3, p[2], fma(C2, p[1], C1 * p[0]));
+    double in2 = fma(C5, p[2], C4 * p[1]);
+    return fma(p[2] * p[2], C6, fma(p[1], in2, p[0] * in1));
+}
+/* buffer 2: beta = psi1*(C1 psi1 + C2 psi2) + psi2*psi2*C3 */
+static inline double beta2(const double p[2], double C1, double C2, double C3) {
+    double in1 = fma(C2, p[1], C1 * p[0]);
+    return fma(p[1] * p[1], C3, p[0] * in1);
+}
+
+/* biased_interpolate for WENO{3} (weno_interpolants.jl:504-516): S = psi[i-3 .. i+2] */
+double oro_weno5_biased(const double S[6], int left) {
+    double p0[3], p1[3], p2[3];
+    if (left) {                                     /* :435-437 */
+        p0[0] = S[2]; p0[1] = S[3]; p0[2] = S[4];
+        p1[0] = S[1]; p1[1] = S[2]; p1[2] = S[3];
+        p2[0] = S[0]; p2[1] = S[1]; p2[2] = S[2];
+    } else {
+        p0[0] = S[3]; p0[1] = S[2]; p0[2] = S[1];
+        p1[0] = S[4]; p1[1] = S[3]; p1[2] = S[2];
+        p2[0] = S[5]; p2[1] = S[4]; p2[2] = S[3];
+    }
+    /* beta_loop :280-287 with smoothness_coefficients :172-174 */
+    double b0 = beta3(p0, 10, -31, 11, 25, -19, 4);
+    double b1 = beta3(p1, 4, -13, 5, 13, -13, 4);
+    double b2 = beta3(p2, 4, -19, 11, 25, -31, 10);
+    double tau = fabs(b0 - b2);                     /* :309 */
+    /* zweno_alpha_loop :290-297: C*(1 + newton_div(Float32, tau, beta + eps)^2) */
+    double r0 = oro_newton_div_f32(tau, b0 + OCN_WENO_EPS);
+    double r1 = oro_newton_div_f32(tau, b1 + OCN_WENO_EPS);
+    double r2 = oro_newton_div_f32(tau, b2 + OCN_WENO_EPS);
+    double a0 = OCN_W3C0 * (1.0 + r0 * r0);
+    double a1 = OCN_W3C1 * (1.0 + r1 * r1);
+    double a2 = OCN_W3C2 * (1.0 + r2 * r2);
+    double sinv = 1.0 / ((a0 + a1) + a2);           /* :336 */
+    double w0 = a0 * sinv, w1 = a1 * sinv, w2 = a2 * sinv;
+    /* biased_p :136-137: sum(coeff .* psi) -- plain products and adds */
+    double q0 = (OCN_W3P00 * p0[0] + OCN_W3P01 * p0[1]) + OCN_W3P02 * p0[2];
+    double q1 = (OCN_W3P10 * p1[0] + OCN_W3P11 * p1[1]) + OCN_W3P12 * p1[2];
+    double q2 = (OCN_W3P20 * p2[0] + OCN_W3P21 * p2[1]) + OCN_W3P22 * p2[2];
+    /* weno_reconstruction :500 under @muladd */
+    return fma(w2, q2, fma(w1, q1, w0 * q0));
+}
+
+/* WENO{2} (buffer scheme of WENO{3}, weno_reconstruction.jl:77-93): S = psi[i-2 .. i+1] */
+double oro_weno3_biased(const double S[4], int left) {
+    double p0[2], p1[2];
+    if (left) { p0[0] = S[1]; p0[1] = S[2]; p1[0] = S[0]; p1[1] = S[1]; }   /* :432-433 */
+    else      { p0[0] = S[2]; p0[1] = S[1]; p1[0] = S[3]; p1[1] = S[2]; }
+    double b0 = beta2(p0, 1, -2, 1);
+    double b1 = beta2(p1, 1, -2, 1);
+    double tau = fabs(b0 - b1);                     /* :308 */
+    double r0 = oro_newton_div_f32(tau, b0 + OCN_WENO_EPS);
+    double r1 = oro_newton_div_f32(tau, b1 + OCN_WENO_EPS);
+    double a0 = OCN_W2C0 * (1.0 + r0 * r0);
+    double a1 = OCN_W2C1 * (1.0 + r1 * r1);
+    double sinv = 1.0 / (a0 + a1);
+    double w0 = a0 * sinv, w1 = a1 * sinv;
+    double q0 = OCN_W2P00 * p0[0] + OCN_W2P01 * p0[1];
+    double q1 = OCN_W2P10 * p1[0] + OCN_W2P11 * p1[1];
+    return fma(w1, q1, w0 * q0);
+}
+
+/* Advection/topologically_conditional_interpolation.jl:46-52 (Bounded) -- `i` is the index the _interpolate function is
+ * called with, `center` selects the ᶜ variant (which evaluates the ᶠ stencil at i+1), R the buffer of the scheme. */
+static inline int outside_symmetric_halo(int i, int center, int N, int R) {
+    return center ? ((i >= R) & (i <= N + 1 - R)) : ((i >= R + 1) & (i <= N + 1 - R));
+}
+static inline int outside_biased_halo(int i, int center, int N, int R) {
+    if (center) return (i >= R) & (i <= N + 1 - (R - 1)) & (i >= R - 1) & (i <= N + 1 - R);
+    return (i >= R + 1) & (i <= N + 1 - (R - 1)) & (i >= R) & (i <= N + 1 - R);
+}
+
+/* _symmetric_interpolate for scheme WENO{3}: advecting_velocity_scheme Centered{2} in the interior
+ * (upwind_biased_reconstruction.jl:52-57, centered_reconstruction.jl:45-55), falling back to the buffer schemes'
+ * advecting velocity schemes (Centered{1}) near walls (topologically_conditional_interpolation.jl:93-119).
+ * Q = q[f-2 .. f+1] where f is the face index of the underlying ᶠ stencil. */
+static inline double symmetric_interp(const double Q[4], int bounded, int i, int center, int N) {
+    int order4 = 1;
+    if (bounded) order4 = outside_symmetric_halo(i, center, N, 3);
+    if (order4)  /* calc_reconstruction_stencil(FT, 2, :symmetric): C4*q[-2] + C3*q[-1] + C2*q[0] + C1*q[+1] under @muladd */
+        return fma(OCN_C4_1, Q[3], fma(OCN_C4_2, Q[2], fma(OCN_C4_3, Q[1], OCN_C4_4 * Q[0])));
+    /* WENO{2} and UpwindBiased{1} both carry Centered(order=2): 0.5 q[-1] + 0.5 q[0] */
+    return fma(OCN_C2_1, Q[2], OCN_C2_2 * Q[1]);
+}
+
+/* _biased_interpolate for scheme WENO{3} with cascade WENO{3} -> WENO{2} -> UpwindBiased{1}. S = psi[f-3 .. f+2]. */
+static inline double biased_interp(const double S[6], int left, int bounded, int i, int center, int N) {
+    if (!bounded || outside_biased_halo(i, center, N, 3)) return oro_weno5_biased(S, left);
+    if (outside_biased_halo(i, center, N, 2)) return oro_weno3_biased(S + 1, left);
+    /* UpwindBiased{1}: left -> 1.0*psi[f-1], right -> 1.0*psi[f] (calc_reconstruction_stencil buffer 1) */
+    return left ? 1.0 * S[2] : 1.0 * S[3];
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * advective fluxes (Advection/upwind_biased_advective_fluxes.jl:23-121)
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const oro_grid *g;
+    fld u, v, w;
+} vel;
+
+/* Operators/products_between_fields_and_grid_metrics.jl:5-14 + spacings_and_areas_and_volumes.jl:308-335 */
+static inline double Ax_q_fcc(const vel *V, int i, int j, int k) { return (DC(V->g, 1, j) * DC(V->g, 2, k)) * AT(V->u, i, j, k); }
+static inline double Ay_q_cfc(const vel *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 2, k)) * AT(V->v, i, j, k); }
+static inline double Az_q_ccf(const vel *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 1, j)) * AT(V->w, i, j, k); }
+
+typedef double (*aq_fn)(const vel *, int, int, int);
+
+/* symmetric interpolation of an area-weighted transport along direction d. `center`: ᶜ variant (face index idx+1). */
+static inline double sym_transport(const vel *V, aq_fn q, int d, int center, int i, int j, int k) {
+    const oro_grid *g = V->g;
+    int idx = (d == 0) ? i : (d == 1) ? j : k;
+    int f = idx + (center ? 1 : 0);
+    double Q[4];
+    for (int n = 0; n < 4; ++n) {
+        int m = f - 2 + n;
+        Q[n] = (d == 0) ? q(V, m, j, k) : (d == 1) ? q(V, i, m, k) : q(V, i, j, m);
+    }
+    return symmetric_interp(Q, g->topo[d] == ORO_BOUNDED, idx, center, g->N[d]);
+}
+
+static inline double biased_field(const oro_grid *g, const fld *c, int left, int d, int center, int i, int j, int k) {
+    int idx = (d == 0) ? i : (d == 1) ? j : k;
+    int f = idx + (center ? 1 : 0);
+    double S[6];
+    for (int n = 0; n < 6; ++n) {
+        int m = f - 3 + n;
+        S[n] = (d == 0) ? AT(*c, m, j, k) : (d == 1) ? AT(*c, i, m, k) : AT(*c, i, j, m);
+    }
+    return biased_interp(S, left, g->topo[d] == ORO_BOUNDED, idx, center, g->N[d]);
+}
+
+#define FLUX(name, aq, dsym, csym, dbias, cbias, fieldmember)                                                  \
+    static inline double name(const vel *V, const fld *psi, int i, int j, int k) {                             \
+        double ut = sym_transport(V, aq, dsym, csym, i, j, k);                                                 \
+        double pr = biased_field(V->g, psi, ut > 0, dbias, cbias, i, j, k);                                    \
+        return ut * pr;                                                                                        \
+    }
+/*   name      advecting  sym-dir  ᶜ?  biased-dir ᶜ? */
+FLUX(flux_Uu, Ax_q_fcc, 0, 1, 0, 1, u)  /* :23-29 */
+FLUX(flux_Vu, Ay_q_cfc, 0, 0, 1, 0, u)  /* :31-37 */
+FLUX(flux_Wu, Az_q_ccf, 0, 0, 2, 0, u)  /* :39-45 */
+FLUX(flux_Uv, Ax_q_fcc, 1, 0, 0, 0, v)  /* :47-53 */
+FLUX(flux_Vv, Ay_q_cfc, 1, 1, 1, 1, v)  /* :55-61 */
+FLUX(flux_Wv, Az_q_ccf, 1, 0, 2, 0, v)  /* :63-69 */
+FLUX(flux_Uw, Ax_q_fcc, 2, 0, 0, 0, w)  /* :71-77 */
+FLUX(flux_Vw, Ay_q_cfc, 2, 0, 1, 0, w)  /* :79-85 */
+FLUX(flux_Ww, Az_q_ccf, 2, 1, 2, 1, w)  /* :87-93 */
+
+/* tracer fluxes :99-121: Ax * u[i,j,k] * cR (left-assoc) */
+static inline double flux_cx(const vel *V, const fld *c, int i, int j, int k) {
+    double ut = AT(V->u, i, j, k);
+    double cr = biased_field(V->g, c, ut > 0, 0, 0, i, j, k);
+    return (DC(V->g, 1, j) * DC(V->g, 2, k)) * ut * cr;
+}
+static inline double flux_cy(const vel *V, const fld *c, int i, int j, int k) {
+    double vt = AT(V->v, i, j, k);
+    double cr = biased_field(V->g, c, vt > 0, 1, 0, i, j, k);
+    return (DC(V->g, 0, i) * DC(V->g, 2, k)) * vt * cr;
+}
+static inline double flux_cz(const vel *V, const fld *c, int i, int j, int k) {
+    double wt = AT(V->w, i, j, k);
+    double cr = biased_field(V->g, c, wt > 0, 2, 0, i, j, k);
+    return (DC(V->g, 0, i) * DC(V->g, 1, j)) * wt * cr;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * tendencies
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* Utils/kernel_launching.jl:145-195: exclude_periphery drops the first Face index on Bounded dims */
+static void default_range(const oro_grid *g, const int loc[3], int exclude_periphery, int r[6]) {
+    for (int d = 0; d < 3; ++d) {
+        int o = (exclude_periphery && loc[d] == ORO_FACE && g->topo[d] == ORO_BOUNDED && g->N[d] > 1) ? 1 : 0;
+        r[2 * d] = 1 + o;
+        r[2 * d + 1] = g->N[d];
+    }
+}
+
+static vel mkvel(const oro_grid *g, const double *u, const double *v, const double *w) {
+    vel V;
+    V.g = g;
+    V.u = mkfld(g, u, LOC_U);
+    V.v = mkfld(g, v, LOC_V);
+    V.w = mkfld(g, w, LOC_W);
+    return V;
+}
+
+/* nonhydrostatic_tendency_kernel_functions.jl:70-103 with every optional term `nothing`:
+ * G = -div_𝐯u - 0 + 0 - 0 ... ; the chain of +/- zeros only turns -0.0 into +0.0, reproduced by `+ 0.0`. */
+void oro_compute_Gu(const oro_grid *g, const double *u, const double *v, const double *w, double *Gu, const int *range) {
+    int r[6];
+    if (range) memcpy(r, range, sizeof r); else default_range(g, LOC_U, 1, r);
+    vel V = mkvel(g, u, v, w);
+    fld G = mkfld(g, Gu, LOC_U);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                /* momentum_advection_operators.jl:46-50; V⁻¹ᶠᶜᶜ = 1/(Azᶠᶜᶜ Δzᶠᶜᶜ), Az = Δxᶠ Δyᶜ */
+                double Vinv = 1.0 / ((DF(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
+                double dx = flux_Uu(&V, &V.u, i, j, k) - flux_Uu(&V, &V.u, i - 1, j, k);   /* δxᶠᵃᵃ */
+                double dy = flux_Vu(&V, &V.u, i, j + 1, k) - flux_Vu(&V, &V.u, i, j, k);   /* δyᵃᶜᵃ */
+                double dz = flux_Wu(&V, &V.u, i, j, k + 1) - flux_Wu(&V, &V.u, i, j, k);   /* δzᵃᵃᶜ */
+                double div = Vinv * ((dx + dy) + dz);
+                AT(G, i, j, k) = -div + 0.0;
+            }
+}
+
+void oro_compute_Gv(const oro_grid *g, const double *u, const double *v, const double *w, double *Gv, const int *range) {
+    int r[6];
+    if (range) memcpy(r, range, sizeof r); else default_range(g, LOC_V, 1, r);
+    vel V = mkvel(g, u, v, w);
+    fld G = mkfld(g, Gv, LOC_V);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                double Vinv = 1.0 / ((DC(g, 0, i) * DF(g, 1, j)) * DC(g, 2, k));            /* V⁻¹ᶜᶠᶜ */
+                double dx = flux_Uv(&V, &V.v, i + 1, j, k) - flux_Uv(&V, &V.v, i, j, k);   /* δxᶜᵃᵃ */
+                double dy = flux_Vv(&V, &V.v, i, j, k) - flux_Vv(&V, &V.v, i, j - 1, k);   /* δyᵃᶠᵃ */
+                double dz = flux_Wv(&V, &V.v, i, j, k + 1) - flux_Wv(&V, &V.v, i, j, k);   /* δzᵃᵃᶜ */
+                double div = Vinv * ((dx + dy) + dz);
+                AT(G, i, j, k) = -div + 0.0;
+            }
+}
+
+void oro_compute_Gw(const oro_grid *g, const double *u, const double *v, const double *w, double *Gw, const int *range) {
+    int r[6];
+    if (range) memcpy(r, range, sizeof r); else default_range(g, LOC_W, 1, r);
+    vel V = mkvel(g, u, v, w);
+    fld G = mkfld(g, Gw, LOC_W);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                double Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DF(g, 2, k));            /* V⁻¹ᶜᶜᶠ */
+                double dx = flux_Uw(&V, &V.w, i + 1, j, k) - flux_Uw(&V, &V.w, i, j, k);   /* δxᶜᵃᵃ */
+                double dy = flux_Vw(&V, &V.w, i, j + 1, k) - flux_Vw(&V, &V.w, i, j, k);   /* δyᵃᶜᵃ */
+                double dz = flux_Ww(&V, &V.w, i, j, k) - flux_Ww(&V, &V.w, i, j, k - 1);   /* δzᵃᵃᶠ */
+                double div = Vinv * ((dx + dy) + dz);
+                AT(G, i, j, k) = -div + 0.0;
+            }
+}
+
+/* tracer_advection_operators.jl:29-33; compute_Gc! is launched WITHOUT exclude_periphery (…tendencies.jl:125-127) */
+void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                    const int *range) {
+    int r[6];
+    if (range) memcpy(r, range, sizeof r); else default_range(g, LOC_C, 0, r);
+    vel V = mkvel(g, u, v, w);
+    fld C = mkfld(g, c, LOC_C);
+    fld G = mkfld(g, Gc, LOC_C);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                double Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));            /* V⁻¹ᶜᶜᶜ */
+                double dx = flux_cx(&V, &C, i + 1, j, k) - flux_cx(&V, &C, i, j, k);
+                double dy = flux_cy(&V, &C, i, j + 1, k) - flux_cy(&V, &C, i, j, k);
+                double dz = flux_cz(&V, &C, i, j, k + 1) - flux_cz(&V, &C, i, j, k);
+                double div = Vinv * ((dx + dy) + dz);
+                AT(G, i, j, k) = -div + 0.0;
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * RK3 substep and tendency caching
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* TimeSteppers/runge_kutta_3.jl:212-226, launched :xyz with exclude_periphery=true (:187) */
+void oro_rk3_substep_field(const oro_grid *g, double *U, const int loc[3], double dt, double gamma, double zeta,
+                           int has_zeta, const double *Gn, const double *Gm) {
+    int r[6];
+    default_range(g, loc, 1, r);
+    fld u = mkfld(g, U, loc), gn = mkfld(g, Gn, loc), gm = mkfld(g, Gm, loc);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                if (has_zeta) AT(u, i, j, k) += dt * (gamma * AT(gn, i, j, k) + zeta * AT(gm, i, j, k));
+                else          AT(u, i, j, k) += dt * gamma * AT(gn, i, j, k);
+            }
+}
+
+/* TimeSteppers/store_tendencies.jl:6-22, launched :xyz (no periphery exclusion) */
+void oro_cache_tendencies(const oro_grid *g, double *Gm, const double *Gn, const int loc[3]) {
+    fld a = mkfld(g, Gm, loc), b = mkfld(g, Gn, loc);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) AT(a, i, j, k) = AT(b, i, j, k);
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * pressure source term / correction
+ * ------------------------------------------------------------------------------------------------------------------ */
+/* solve_for_pressure.jl:12-18 / :36-42 + Operators/divergence_operators.jl:16-19 */
+void oro_compute_source_term(const oro_grid *g, const double *u, const double *v, const double *w, cplx *rhs,
+                             int weight_by_dz) {
+    vel V = mkvel(g, u, v, w);
+    const int Nx = g->N[0], Ny = g->N[1], Nz = g->N[2];
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= Nz; ++k)
+        for (int j = 1; j <= Ny; ++j)
+            for (int i = 1; i <= Nx; ++i) {
+                double Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
+                double dx = Ax_q_fcc(&V, i + 1, j, k) - Ax_q_fcc(&V, i, j, k);
+                double dy = Ay_q_cfc(&V, i, j + 1, k) - Ay_q_cfc(&V, i, j, k);
+                double dz = Az_q_ccf(&V, i, j, k + 1) - Az_q_ccf(&V, i, j, k);
+                double div = Vinv * ((dx + dy) + dz);
+                /* `active * δ` with active = true; Fourier-tridiagonal: active * Δzᶜᶜᶜ * δ */
+                double val = weight_by_dz ? (1.0 * DC(g, 2, k)) * div : 1.0 * div;
+                rhs[(i - 1) + (size_t)Nx * ((j - 1) + (size_t)Ny * (k - 1))] = val;
+            }
+}
+
+/* pressure_correction.jl:31-37 with ∂ = δ * Δ⁻¹, Δ⁻¹ = 1/Δ (derivative_operators.jl:20-26, reciprocal_metric_operators.jl) */
+void oro_make_pressure_correction(const oro_grid *g, double *u, double *v, double *w, const double *p) {
+    fld U = mkfld(g, u, LOC_U), Vv = mkfld(g, v, LOC_V), W = mkfld(g, w, LOC_W), P = mkfld(g, p, LOC_C);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) {
+                AT(U, i, j, k) -= (AT(P, i, j, k) - AT(P, i - 1, j, k)) * (1.0 / DF(g, 0, i));
+                AT(Vv, i, j, k) -= (AT(P, i, j, k) - AT(P, i, j - 1, k)) * (1.0 / DF(g, 1, j));
+                AT(W, i, j, k) -= (AT(P, i, j, k) - AT(P, i, j, k - 1)) * (1.0 / DF(g, 2, k));
+            }
+}
+
+/* pressure_correction.jl:48-50: `pNHS ./= Δt⁺` broadcasts over the field's interior... */
+void oro_scale_parent(const oro_grid *g, double *p, const int loc[3], double divisor) {
+    /* Field broadcasting (Fields/broadcasting_abstract_fields.jl) acts on interior(p) for a full field */
+    fld P = mkfld(g, p, loc);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) AT(P, i, j, k) /= divisor;
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * FFT (own implementation: iterative radix-2 + Bluestein for other lengths) and FFTW-convention DCTs
+ * The reference calls FFTW (Solvers/plan_transforms.jl:16-34); bitwise FFT parity is unpinned by the reference.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static void fft_pow2(cplx *x, int n, int sign) {
+    for (int i = 1, j = 0; i < n; ++i) {
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { cplx t = x[i]; x[i] = x[j]; x[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        int half = len >> 1;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < half; ++k) {
+                double ang = sign * 2.0 * M_PI * (double)k / (double)len;
+                cplx wk = cos(ang) + I * sin(ang);
+                cplx a = x[i + k], b = x[i + k + half] * wk;
+                x[i + k] = a + b;
+                x[i + k + half] = a - b;
+            }
+    }
+}
+
+static void fft_any(cplx *x, int n, int sign) {
+    if (n <= 1) return;
+    if ((n & (n - 1)) == 0) { fft_pow2(x, n, sign); return; }
+    /* Bluestein */
+    int m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    cplx *a = (cplx *)calloc((size_t)m, sizeof(cplx)), *b = (cplx *)calloc((size_t)m, sizeof(cplx));
+    cplx *wv = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        long kk = ((long)k * k) % (2L * n);
+        double ang = sign * M_PI * (double)kk / (double)n;
+        wv[k] = cos(ang) + I * sin(ang);
+    }
+    for (int k = 0; k < n; ++k) a[k] = x[k] * wv[k];
+    b[0] = conj(wv[0]);
+    for (int k = 1; k < n; ++k) b[k] = b[m - k] = conj(wv[k]);
+    fft_pow2(a, m, -1);
+    fft_pow2(b, m, -1);
+    for (int k = 0; k < m; ++k) a[k] *= b[k];
+    fft_pow2(a, m, +1);
+    for (int k = 0; k < n; ++k) x[k] = (a[k] / (double)m) * wv[k];
+    free(a); free(b); free(wv);
+}
+
+void oro_fft_line(cplx *x, int n, int stride, int sign) {
+    cplx *tmp = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int i = 0; i < n; ++i) tmp[i] = x[(size_t)i * stride];
+    fft_any(tmp, n, sign);
+    for (int i = 0; i < n; ++i) x[(size_t)i * stride] = tmp[i];
+    free(tmp);
+}
+
+/* FFTW REDFT10: Y_k = 2 sum_j X_j cos(pi (j+1/2) k / n); REDFT01: Y_k = X_0 + 2 sum_{j>=1} X_j cos(pi j (k+1/2) / n).
+ * Applied to real and imaginary parts independently (FFTW r2r on a complex array acts on both components). */
+static void dct_line(cplx *x, int n, int stride, int backward) {
+    cplx *tmp = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        cplx s = 0;
+        if (!backward) {
+            for (int j = 0; j < n; ++j) s += x[(size_t)j * stride] * cos(M_PI * (j + 0.5) * k / n);
+            tmp[k] = 2.0 * s;
+        } else {
+            for (int j = 1; j < n; ++j) s += x[(size_t)j * stride] * cos(M_PI * j * (k + 0.5) / n);
+            tmp[k] = x[0] + 2.0 * s;
+        }
+    }
+    for (int k = 0; k < n; ++k) x[(size_t)k * stride] = tmp[k];
+    free(tmp);
+}
+
+/* transform all lines along dimension d of a dense (n0, n1, n2) column-major complex array */
+static void transform_dim(cplx *A, const int n[3], int d, int kind /*0 fft fwd,1 fft bwd(unnormalised),2 dct fwd,3 dct bwd*/) {
+    size_t st[3] = {1, (size_t)n[0], (size_t)n[0] * n[1]};
+    int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < n[d2]; ++b)
+        for (int a = 0; a < n[d1]; ++a) {
+            cplx *line = A + a * st[d1] + b * st[d2];
+            if (kind == 0) oro_fft_line(line, n[d], (int)st[d], -1);
+            else if (kind == 1) oro_fft_line(line, n[d], (int)st[d], +1);
+            else dct_line(line, n[d], (int)st[d], kind == 3);
+        }
+}
+
+/* Solvers/poisson_eigenvalues.jl:8-23 */
+void oro_poisson_eigenvalues(int N, double L, int topo, double *lam) {
+    for (int i = 1; i <= N; ++i) {
+        double arg = (topo == ORO_PERIODIC) ? ((double)(i - 1) * M_PI) / (double)N
+                                            : ((double)(i - 1) * M_PI) / (double)(2 * N);
+        double s = 2.0 * sin(arg) / (L / (double)N);
+        lam[i - 1] = s * s;
+    }
+}
+
+struct oro_poisson {
+    const oro_grid *g;
+    int kind;
+    int n[3];
+    cplx *storage;      /* solution storage (both kinds) */
+    cplx *source;       /* kind 1: source_term */
+    double *lam[3];
+    double *D, *lower, *t;   /* kind 1: main diagonal (3-D), lower/upper diagonal, scratch */
+};
+
+oro_poisson *oro_poisson_create(const oro_grid *g, int kind) {
+    oro_poisson *s = (oro_poisson *)calloc(1, sizeof(oro_poisson));
+    s->g = g; s->kind = kind;
+    size_t tot = 1;
+    for (int d = 0; d < 3; ++d) { s->n[d] = g->N[d]; tot *= (size_t)g->N[d]; }
+    s->storage = (cplx *)calloc(tot, sizeof(cplx));
+    for (int d = 0; d < 3; ++d) {
+        s->lam[d] = (double *)calloc((size_t)g->N[d], sizeof(double));
+        oro_poisson_eigenvalues(g->N[d], g->L[d], g->topo[d], s->lam[d]);
+    }
+    if (kind == 1) {
+        /* fourier_tridiagonal_poisson_solver.jl:75-134, diagonals :180-210 (HomogeneousZFormulation) */
+        const int Nx = g->N[0], Ny = g->N[1], Nz = g->N[2];
+        s->source = (cplx *)calloc(tot, sizeof(cplx));
+        s->D = (double *)calloc(tot, sizeof(double));
+        s->t = (double *)calloc(tot, sizeof(double));
+        s->lower = (double *)calloc((size_t)(Nz > 1 ? Nz - 1 : 1), sizeof(double));
+        for (int j = 1; j <= Ny; ++j)
+            for (int i = 1; i <= Nx; ++i) {
+                double lxy = s->lam[0][i - 1] + s->lam[1][j - 1];
+#define DD(k) s->D[(i - 1) + (size_t)Nx * ((j - 1) + (size_t)Ny * ((k) - 1))]
+                DD(1) = -1.0 / DF(g, 2, 2) - DC(g, 2, 1) * lxy;
+                DD(Nz) = -1.0 / DF(g, 2, Nz) - DC(g, 2, Nz) * lxy;
+                for (int k = 2; k <= Nz - 1; ++k)
+                    DD(k) = -(1.0 / DF(g, 2, k + 1) + 1.0 / DF(g, 2, k)) - DC(g, 2, k) * lxy;
+#undef DD
+            }
+        for (int q = 1; q <= Nz - 1; ++q) s->lower[q - 1] = 1.0 / DF(g, 2, q + 1);
+    }
+    return s;
+}
+
+void oro_poisson_destroy(oro_poisson *s) {
+    if (!s) return;
+    free(s->storage); free(s->source); free(s->D); free(s->lower); free(s->t);
+    for (int d = 0; d < 3; ++d) free(s->lam[d]);
+    free(s);
+}
+
+cplx *oro_poisson_rhs(oro_poisson *s) { return s->kind == 0 ? s->storage : s->source; }
+
+/* Solvers/batched_tridiagonal_solver.jl:213-245 (z direction): complex f/phi, real a, b (3-D), c; scratch t */
+void oro_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b3d, const double *c,
+                                     const cplx *f, double *t, cplx *phi) {
+#define IX(i, j, k) ((size_t)(i) + (size_t)Nx * ((size_t)(j) + (size_t)Ny * (size_t)(k)))
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int j = 0; j < Ny; ++j)
+        for (int i = 0; i < Nx; ++i) {
+            double beta = b3d[IX(i, j, 0)];
+            phi[IX(i, j, 0)] = f[IX(i, j, 0)] / beta;
+            for (int k = 1; k < Nz; ++k) {
+                double ck1 = c[k - 1], bk = b3d[IX(i, j, k)], ak1 = a[k - 1];
+                t[IX(i, j, k)] = ck1 / beta;
+                beta = bk - ak1 * t[IX(i, j, k)];
+                cplx fk = f[IX(i, j, k)];
+                int dd = fabs(beta) > 10.0 * 2.220446049250313e-16;
+                cplx star = (fk - ak1 * phi[IX(i, j, k - 1)]) / beta;
+                if (dd) phi[IX(i, j, k)] = star;    /* else keep the previous content of phi (:236-237) */
+            }
+            for (int k = Nz - 2; k >= 0; --k) phi[IX(i, j, k)] -= t[IX(i, j, k + 1)] * phi[IX(i, j, k + 1)];
+        }
+#undef IX
+}
+
+static void copy_real_component(const oro_grid *g, double *phi, const cplx *src) {
+    /* fft_based_poisson_solver.jl:129-137 */
+    fld P = mkfld(g, phi, LOC_C);
+    const int Nx = g->N[0], Ny = g->N[1];
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= Ny; ++j)
+            for (int i = 1; i <= Nx; ++i)
+                AT(P, i, j, k) = creal(src[(i - 1) + (size_t)Nx * ((j - 1) + (size_t)Ny * (k - 1))]);
+}
+
+void oro_poisson_solve(oro_poisson *s, double *phi) {
+    const oro_grid *g = s->g;
+    const int *n = s->n;
+    const size_t tot = (size_t)n[0] * n[1] * n[2];
+    if (s->kind == 0) {
+        /* fft_based_poisson_solver.jl:95-125; CPU plans: forward = (bounded dims REDFT10, periodic dims FFT),
+         * backward = (periodic IFFT (normalised), bounded REDFT01 * 1/2N) -- plan_transforms.jl:124-136 */
+        cplx *b = s->storage;
+        for (int d = 0; d < 3; ++d) if (g->topo[d] == ORO_BOUNDED) transform_dim(b, n, d, 2);
+        for (int d = 0; d < 3; ++d) if (g->topo[d] == ORO_PERIODIC) transform_dim(b, n, d, 0);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int k = 0; k < n[2]; ++k)
+            for (int j = 0; j < n[1]; ++j)
+                for (int i = 0; i < n[0]; ++i) {
+                    size_t q = (size_t)i + (size_t)n[0] * ((size_t)j + (size_t)n[1] * k);
+                    double lam = (s->lam[0][i] + s->lam[1][j]) + s->lam[2][k] - 0.0;
+                    b[q] = (-creal(b[q]) / lam) + I * (-cimag(b[q]) / lam);
+                }
+        b[0] = 0;                                                    /* :115 */
+        double norm = 1.0;
+        for (int d = 0; d < 3; ++d) if (g->topo[d] == ORO_PERIODIC) { transform_dim(b, n, d, 1); norm *= (double)n[d]; }
+        if (norm != 1.0) {
+            double inv = 1.0 / norm;
+            for (size_t q = 0; q < tot; ++q) b[q] *= inv;
+        }
+        double bn = 1.0;
+        int anyb = 0;
+        for (int d = 0; d < 3; ++d) if (g->topo[d] == ORO_BOUNDED) { transform_dim(b, n, d, 3); bn *= 1.0 / (2.0 * n[d]); anyb = 1; }
+        if (anyb) for (size_t q = 0; q < tot; ++q) b[q] *= bn;
+        copy_real_component(g, phi, b);
+    } else {
+        /* fourier_tridiagonal_poisson_solver.jl:212-239 (x, y transformed; z tridiagonal) */
+        cplx *src = s->source, *ph = s->storage;
+        for (int d = 0; d < 2; ++d) if (g->topo[d] == ORO_BOUNDED) transform_dim(src, n, d, 2);
+        for (int d = 0; d < 2; ++d) if (g->topo[d] == ORO_PERIODIC) transform_dim(src, n, d, 0);
+        oro_batched_tridiagonal_solve_z(n[0], n[1], n[2], s->lower, s->D, s->lower, src, s->t, ph);
+        double norm = 1.0;
+        for (int d = 0; d < 2; ++d) if (g->topo[d] == ORO_PERIODIC) { transform_dim(ph, n, d, 1); norm *= (double)n[d]; }
+        if (norm != 1.0) {
+            double inv = 1.0 / norm;
+            for (size_t q = 0; q < tot; ++q) ph[q] *= inv;
+        }
+        double bn = 1.0;
+        int anyb = 0;
+        for (int d = 0; d < 2; ++d) if (g->topo[d] == ORO_BOUNDED) { transform_dim(ph, n, d, 3); bn *= 1.0 / (2.0 * n[d]); anyb = 1; }
+        if (anyb) for (size_t q = 0; q < tot; ++q) ph[q] *= bn;
+        /* ϕ .= ϕ .- mean(ϕ) (:233) */
+        cplx sum = 0;
+        for (size_t q = 0; q < tot; ++q) sum += ph[q];
+        cplx mean = sum / (double)tot;
+        for (size_t q = 0; q < tot; ++q) ph[q] -= mean;
+        copy_real_component(g, phi, ph);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * model + time_step!
+ * ------------------------------------------------------------------------------------------------------------------ */
+#define ORO_MAXTR 8
+struct oro_model {
+    const oro_grid *g;
+    int ntr;
+    double *U[3 + ORO_MAXTR];      /* u, v, w, tracers */
+    double *Gn[3 + ORO_MAXTR];
+    double *Gm[3 + ORO_MAXTR];
+    int loc[3 + ORO_MAXTR][3];
+    double *p;
+    oro_poisson *solver;
+    double time, last_dt, last_stage_dt;
+    int iteration, stage;
+};
+
+static size_t parent_len(const oro_grid *g, const int loc[3]) {
+    int P[3];
+    oro_parent_size(g, loc, P);
+    return (size_t)P[0] * P[1] * P[2];
+}
+
+static int grid_z_is_regular(const oro_grid *g) {
+    for (int k = 1 - g->H[2]; k <= g->N[2] + g->H[2]; ++k)
+        if (DC(g, 2, k) != DC(g, 2, 1)) return 0;
+    return 1;
+}
+
+oro_model *oro_model_create(const oro_grid *g, int ntracers) {
+    oro_model *m = (oro_model *)calloc(1, sizeof(oro_model));
+    m->g = g; m->ntr = ntracers;
+    const int *locs[3] = {LOC_U, LOC_V, LOC_W};
+    for (int f = 0; f < 3 + ntracers; ++f) {
+        const int *l = f < 3 ? locs[f] : LOC_C;
+        memcpy(m->loc[f], l, sizeof(int) * 3);
+        size_t len = parent_len(g, l);
+        m->U[f] = (double *)calloc(len, sizeof(double));
+        m->Gn[f] = (double *)calloc(len, sizeof(double));
+        m->Gm[f] = (double *)calloc(len, sizeof(double));
+    }
+    m->p = (double *)calloc(parent_len(g, LOC_C), sizeof(double));
+    /* NonhydrostaticModels.jl:25-40: XYZ-regular -> FFTBased, z-stretched -> FourierTridiagonal */
+    m->solver = oro_poisson_create(g, grid_z_is_regular(g) ? 0 : 1);
+    m->stage = 1;
+    m->last_dt = INFINITY; m->last_stage_dt = INFINITY;
+    return m;
+}
+
+void oro_model_destroy(oro_model *m) {
+    if (!m) return;
+    for (int f = 0; f < 3 + m->ntr; ++f) { free(m->U[f]); free(m->Gn[f]); free(m->Gm[f]); }
+    free(m->p);
+    oro_poisson_destroy(m->solver);
+    free(m);
+}
+
+static int field_index(const oro_model *m, const char *name, char *kind) {
+    /* "u","v","w","cN","p","Gu","Gv","Gw","GcN","Mu","Mv","Mw","McN" */
+    const char *q = name;
+    *kind = 'U';
+    if (q[0] == 'G' || q[0] == 'M') { *kind = q[0]; ++q; }
+    if (!strcmp(q, "u")) return 0;
+    if (!strcmp(q, "v")) return 1;
+    if (!strcmp(q, "w")) return 2;
+    if (q[0] == 'c') { int n = atoi(q + 1); if (n >= 0 && n < m->ntr) return 3 + n; }
+    if (!strcmp(name, "p")) { *kind = 'p'; return 0; }
+    return -1;
+}
+
+double *oro_model_field(oro_model *m, const char *name) {
+    char kind;
+    int f = field_index(m, name, &kind);
+    if (f < 0) return NULL;
+    if (kind == 'p') return m->p;
+    return kind == 'U' ? m->U[f] : kind == 'G' ? m->Gn[f] : m->Gm[f];
+}
+
+void oro_model_field_loc(oro_model *m, const char *name, int loc[3]) {
+    char kind;
+    int f = field_index(m, name, &kind);
+    if (kind == 'p' || f < 0) { memcpy(loc, LOC_C, sizeof(int) * 3); return; }
+    memcpy(loc, m->loc[f], sizeof(int) * 3);
+}
+
+/* update_nonhydrostatic_model_state.jl:20-56 with closure/buoyancy = nothing */
+void oro_model_update_state(oro_model *m, int compute_tendencies) {
+    const oro_grid *g = m->g;
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions(g, m->U[f], m->loc[f], /*fill_open_bcs=*/0);
+    if (compute_tendencies) {
+        oro_compute_Gu(g, m->U[0], m->U[1], m->U[2], m->Gn[0], NULL);
+        oro_compute_Gv(g, m->U[0], m->U[1], m->U[2], m->Gn[1], NULL);
+        oro_compute_Gw(g, m->U[0], m->U[1], m->U[2], m->Gn[2], NULL);
+        for (int t = 0; t < m->ntr; ++t) oro_compute_Gc(g, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->Gn[3 + t], NULL);
+    }
+}
+
+/* pressure_correction.jl:8-20 + solve_for_pressure.jl:91-95 */
+static void compute_pressure_correction(oro_model *m, double dt) {
+    (void)dt;
+    const oro_grid *g = m->g;
+    for (int f = 0; f < 3; ++f) oro_fill_halo_regions(g, m->U[f], m->loc[f], 1);
+    oro_compute_source_term(g, m->U[0], m->U[1], m->U[2], oro_poisson_rhs(m->solver), m->solver->kind == 1);
+    oro_poisson_solve(m->solver, m->p);
+    oro_fill_halo_regions(g, m->p, LOC_C, 1);
+}
+
+/* pressure_correction.jl:40-53 */
+static void make_pressure_correction(oro_model *m, double dt) {
+    oro_make_pressure_correction(m->g, m->U[0], m->U[1], m->U[2], m->p);
+    double dtp = fmax(2.220446049250313e-16, dt);
+    oro_scale_parent(m->g, m->p, LOC_C, dtp);
+}
+
+void oro_model_set_finalize(oro_model *m, int enforce_incompressibility) {
+    /* set_nonhydrostatic_model.jl:33-60: per-field fill_halo_regions! after set!, then update_state!, projection */
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions(m->g, m->U[f], m->loc[f], 1);
+    oro_model_update_state(m, 0);
+    if (enforce_incompressibility) {
+        compute_pressure_correction(m, 1.0);
+        make_pressure_correction(m, 1.0);
+        oro_model_update_state(m, 0);
+    }
+}
+
+static void tick(oro_model *m, double dt, int stage) {      /* TimeSteppers/clock.jl:128-143 */
+    m->time += dt;
+    if (stage) { m->stage += 1; m->last_stage_dt = dt; }
+    else { m->iteration += 1; m->stage = 1; m->last_dt = dt; m->last_stage_dt = dt; }
+}
+
+static void rk3_substep(oro_model *m, double dt, double gamma, double zeta, int has_zeta) {
+    for (int f = 0; f < 3 + m->ntr; ++f)
+        oro_rk3_substep_field(m->g, m->U[f], m->loc[f], dt, gamma, zeta, has_zeta, m->Gn[f], m->Gm[f]);
+}
+
+static void cache_previous_tendencies(oro_model *m) {
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_cache_tendencies(m->g, m->Gm[f], m->Gn[f], m->loc[f]);
+}
+
+/* TimeSteppers/runge_kutta_3.jl:93-170 */
+void oro_model_time_step(oro_model *m, double dt) {
+    if (m->iteration == 0) oro_model_update_state(m, 1);
+    const double g1 = OCN_RK3_G1, g2 = OCN_RK3_G2, g3 = OCN_RK3_G3, z2 = OCN_RK3_Z2, z3 = OCN_RK3_Z3;
+    double dt1 = dt * g1, dt2 = dt * (g2 + z2), dt3 = dt * (g3 + z3);   /* :176-177 */
+    double tn1 = m->time + dt;
+
+    /* compute_flux_bc_tendencies!: no Flux BCs with values in scope (compute_flux_bcs.jl:24-28) */
+    rk3_substep(m, dt, g1, 0.0, 0);
+    tick(m, dt1, 1);
+    compute_pressure_correction(m, dt1);
+    make_pressure_correction(m, dt1);
+    cache_previous_tendencies(m);
+    oro_model_update_state(m, 1);
+
+    rk3_substep(m, dt, g2, z2, 1);
+    tick(m, dt2, 1);
+    compute_pressure_correction(m, dt2);
+    make_pressure_correction(m, dt2);
+    cache_previous_tendencies(m);
+    oro_model_update_state(m, 1);
+
+    rk3_substep(m, dt, g3, z3, 1);
+    double corrected = tn1 - m->time;
+    tick(m, dt3, 0);
+    m->last_stage_dt = corrected;
+    m->last_dt = dt;
+    compute_pressure_correction(m, dt3);
+    make_pressure_correction(m, dt3);
+    oro_model_update_state(m, 1);
+}
+
+double oro_model_time(const oro_model *m) { return m->time; }
+int oro_model_iteration(const oro_model *m) { return m->iteration; }
+
+double oro_model_max_abs_divergence(oro_model *m) {
+    const oro_grid *g = m->g;
+    size_t tot = (size_t)g->N[0] * g->N[1] * g->N[2];
+    cplx *tmp = (cplx *)malloc(sizeof(cplx) * tot);
+    oro_compute_source_term(g, m->U[0], m->U[1], m->U[2], tmp, 0);
+    double mx = 0;
+    for (size_t q = 0; q < tot; ++q) { double a = fabs(creal(tmp[q])); if (a > mx) mx = a; }
+    free(tmp);
+    return mx;
+}
+
+void oro_set_num_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+int oro_get_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,108 @@
+/* ocn_oracle.h -- CPU restatement ("oracle") of the Oceananigans v0.100.5 NonhydrostaticModel RK3 time-step.
+ *
+ * TEST INFRASTRUCTURE ONLY. This is the checker the HIP path is compared against; nothing in the product
+ * (oldoceananigans.jl_amd/, include/) may call into it. Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg load this library.
+ *
+ * PARITY STATUS: "parity unpinned" against the Julia reference for the WENO-5/RK3 floating-point fields -- there is
+ * no Julia in this container or on the GPU box, and the reference's stored regression data are remote DataDeps
+ * (test/data_dependencies.jl:17-38), AB2+Centered only. The restatement is pinned by the reference's data-free
+ * tests instead: exact halo tests, Poisson residual tests, tridiagonal-vs-dense, incompressibility,
+ * Taylor-Green, WENO order-of-accuracy/symmetry, docstring KATs.
+ *
+ * Conventions: all (i, j, k) are Julia 1-based interior indices, halo cells have indices <= 0 or > N, exactly as the
+ * OffsetArrays of the reference (src/Grids/new_data.jl:15-73). Arrays are column-major (x fastest) dense parents.
+ */
+#ifndef OCN_ORACLE_H
+#define OCN_ORACLE_H
+#include <stddef.h>
+#include <complex.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { ORO_PERIODIC = 0, ORO_BOUNDED = 1 };
+enum { ORO_CENTER = 0, ORO_FACE = 1 };
+
+typedef struct {
+    int N[3], H[3], topo[3];
+    double L[3];
+    /* spacings with halos, index idx in 1-H .. N+H(+1): dc[d][idx - 1 + H[d]], df[d][idx - 1 + H[d]].
+     * Lengths: dc N+2H+1 (last entry padding), df N+2H+1. (src/Grids/grid_generation.jl:34-135) */
+    double *dc[3];
+    double *df[3];
+} oro_grid;
+
+typedef struct oro_model oro_model;
+
+/* ---- grid ---- */
+oro_grid *oro_grid_create(const int N[3], const int H[3], const int topo[3], const double L[3],
+                          const double *dxc, const double *dxf, const double *dyc, const double *dyf,
+                          const double *dzc, const double *dzf);
+void oro_grid_destroy(oro_grid *g);
+/* parent extents of a field at location loc (src/Grids/grid_utils.jl:66-72) */
+void oro_parent_size(const oro_grid *g, const int loc[3], int P[3]);
+
+/* ---- halo fills (src/BoundaryConditions/fill_halo_regions*.jl) ---- */
+/* default prognostic/auxiliary BCs (field_boundary_conditions.jl:15-25): Periodic -> periodic copy; Bounded+Center
+ * -> no-flux mirror (one cell); Bounded+Face -> impenetrable (wall value 0), skipped when fill_open_bcs == 0 */
+void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs);
+
+/* ---- tendencies (src/Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:49-163) ---- */
+/* range = {i0, i1, j0, j1, k0, k1} inclusive (KernelParameters); NULL -> :xyz with exclude_periphery as the
+ * reference launches it. */
+void oro_compute_Gu(const oro_grid *g, const double *u, const double *v, const double *w, double *Gu, const int *range);
+void oro_compute_Gv(const oro_grid *g, const double *u, const double *v, const double *w, double *Gv, const int *range);
+void oro_compute_Gw(const oro_grid *g, const double *u, const double *v, const double *w, double *Gw, const int *range);
+void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                    const int *range);
+
+/* single-point WENO kernels exported for KATs */
+double oro_weno5_biased(const double S[6], int left);
+double oro_weno3_biased(const double S[4], int left);
+double oro_newton_div_f32(double a, double b);
+
+/* ---- RK3 (src/TimeSteppers/runge_kutta_3.jl:179-226, store_tendencies.jl:6-22) ---- */
+void oro_rk3_substep_field(const oro_grid *g, double *U, const int loc[3], double dt, double gamma, double zeta,
+                           int has_zeta, const double *Gn, const double *Gm);
+void oro_cache_tendencies(const oro_grid *g, double *Gm, const double *Gn, const int loc[3]);
+
+/* ---- pressure (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl) ---- */
+void oro_compute_source_term(const oro_grid *g, const double *u, const double *v, const double *w,
+                             double _Complex *rhs, int weight_by_dz);
+void oro_make_pressure_correction(const oro_grid *g, double *u, double *v, double *w, const double *p);
+void oro_scale_parent(const oro_grid *g, double *p, const int loc[3], double divisor);
+
+/* ---- solvers (src/Solvers) ---- */
+typedef struct oro_poisson oro_poisson;
+/* kind 0: FFTBasedPoissonSolver (all dims regular); kind 1: FourierTridiagonalPoissonSolver (z tridiagonal) */
+oro_poisson *oro_poisson_create(const oro_grid *g, int kind);
+void oro_poisson_destroy(oro_poisson *s);
+double _Complex *oro_poisson_rhs(oro_poisson *s);     /* storage (kind 0) / source_term (kind 1), size Nx*Ny*Nz */
+void oro_poisson_solve(oro_poisson *s, double *phi);  /* phi: haloed (C,C,C) field, interior overwritten */
+void oro_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b3d, const double *c,
+                                     const double _Complex *f, double *t, double _Complex *phi);
+void oro_poisson_eigenvalues(int N, double L, int topo, double *lam);
+/* unnormalised transforms on a length-n line, exported for tests: FFT (sign -1 fwd, +1 bwd), REDFT10, REDFT01 */
+void oro_fft_line(double _Complex *x, int n, int stride, int sign);
+
+/* ---- model (src/Models/NonhydrostaticModels/nonhydrostatic_model.jl, runge_kutta_3.jl:93-170) ---- */
+oro_model *oro_model_create(const oro_grid *g, int ntracers);
+void oro_model_destroy(oro_model *m);
+double *oro_model_field(oro_model *m, const char *name); /* "u","v","w","c0".., "p", "Gu","Gv","Gw","Gc0".., "Mu".. */
+void oro_model_field_loc(oro_model *m, const char *name, int loc[3]);
+void oro_model_update_state(oro_model *m, int compute_tendencies);
+void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
+void oro_model_time_step(oro_model *m, double dt);
+double oro_model_time(const oro_model *m);
+int oro_model_iteration(const oro_model *m);
+double oro_model_max_abs_divergence(oro_model *m);
+
+void oro_set_num_threads(int n);
+int oro_get_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,285 @@
+"""ctypes front-end of the CPU oracle (oracle/ocn_oracle.c) + a numpy/decimal restatement of grid generation.
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product
+package never imports this module.
+
+Grid generation follows reference src/Grids/grid_generation.jl:34-135 (citations inline). Parity status: see
+ocn_oracle.h ("parity unpinned" vs Julia; pinned by the reference's data-free tests).
+"""
+import ctypes as C
+import os
+import subprocess
+from decimal import Decimal, getcontext
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+PERIODIC, BOUNDED = 0, 1
+CENTER, FACE = 0, 1
+LOC = {"u": (FACE, CENTER, CENTER), "v": (CENTER, FACE, CENTER), "w": (CENTER, CENTER, FACE), "c": (CENTER,) * 3}
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libocn_oracle.so")
+    src = os.path.join(_HERE, "ocn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
+        L.oro_grid_create.restype = vp
+        L.oro_grid_create.argtypes = [ip, ip, ip, dp] + [dp] * 6
+        L.oro_grid_destroy.argtypes = [vp]
+        L.oro_parent_size.argtypes = [vp, ip, ip]
+        L.oro_fill_halo_regions.argtypes = [vp, dp, ip, C.c_int]
+        for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
+            getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
+        L.oro_compute_Gc.argtypes = [vp, dp, dp, dp, dp, dp, ip]
+        L.oro_weno5_biased.restype = C.c_double
+        L.oro_weno5_biased.argtypes = [dp, C.c_int]
+        L.oro_weno3_biased.restype = C.c_double
+        L.oro_weno3_biased.argtypes = [dp, C.c_int]
+        L.oro_newton_div_f32.restype = C.c_double
+        L.oro_newton_div_f32.argtypes = [C.c_double, C.c_double]
+        L.oro_rk3_substep_field.argtypes = [vp, dp, ip, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp]
+        L.oro_cache_tendencies.argtypes = [vp, dp, dp, ip]
+        L.oro_compute_source_term.argtypes = [vp, dp, dp, dp, vp, C.c_int]
+        L.oro_make_pressure_correction.argtypes = [vp, dp, dp, dp, dp]
+        L.oro_scale_parent.argtypes = [vp, dp, ip, C.c_double]
+        L.oro_poisson_create.restype = vp
+        L.oro_poisson_create.argtypes = [vp, C.c_int]
+        L.oro_poisson_destroy.argtypes = [vp]
+        L.oro_poisson_rhs.restype = vp
+        L.oro_poisson_rhs.argtypes = [vp]
+        L.oro_poisson_solve.argtypes = [vp, dp]
+        L.oro_batched_tridiagonal_solve_z.argtypes = [C.c_int] * 3 + [dp, dp, dp, vp, dp, vp]
+        L.oro_poisson_eigenvalues.argtypes = [C.c_int, C.c_double, C.c_int, dp]
+        L.oro_fft_line.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.oro_model_create.restype = vp
+        L.oro_model_create.argtypes = [vp, C.c_int]
+        L.oro_model_destroy.argtypes = [vp]
+        L.oro_model_field.restype = dp
+        L.oro_model_field.argtypes = [vp, C.c_char_p]
+        L.oro_model_field_loc.argtypes = [vp, C.c_char_p, ip]
+        L.oro_model_update_state.argtypes = [vp, C.c_int]
+        L.oro_model_set_finalize.argtypes = [vp, C.c_int]
+        L.oro_model_time_step.argtypes = [vp, C.c_double]
+        L.oro_model_time.restype = C.c_double
+        L.oro_model_time.argtypes = [vp]
+        L.oro_model_iteration.argtypes = [vp]
+        L.oro_model_max_abs_divergence.restype = C.c_double
+        L.oro_model_max_abs_divergence.argtypes = [vp]
+        L.oro_set_num_threads.argtypes = [C.c_int]
+    return _LIB
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["F_CONTIGUOUS"] or a.ndim == 1
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i3(t):
+    return (C.c_int * 3)(*t)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# grid generation (oracle restatement; decimal arithmetic with 80 digits stands in for Julia's 256-bit BigFloat)
+# --------------------------------------------------------------------------------------------------------------------
+def regular_spacing(interval, N):
+    """grid_generation.jl:98-135: Δ = FT(BigFloat(L) / N), L = FT(c₂ - c₁)."""
+    getcontext().prec = 80
+    c1, c2 = Decimal(float(interval[0])), Decimal(float(interval[1]))
+    assert c1 < c2, "must be an increasing interval!"
+    L = c2 - c1
+    return float(L / Decimal(N)), float(L)
+
+
+def stretched_spacings(faces, N, H, bounded):
+    """grid_generation.jl:34-95 for an explicit face vector of length N+1. Returns (L, Δᶜ, Δᶠ) with Δᶜ[idx], Δᶠ[idx]
+    stored for idx = 1-H .. N+H+1 (array position idx-1+H); entries the reference does not define are padded by
+    repeating the nearest defined value."""
+    F_int = np.asarray(faces, dtype=np.float64)
+    assert F_int.shape == (N + 1,) and np.all(np.diff(F_int) > 0)
+    L = F_int[N] - F_int[0]
+    if bounded:   # lower/upper_exterior_Δcoordᶠ(::BoundedTopology) :14,17
+        dm = [F_int[1] - F_int[0]] * H
+        dp = [F_int[-1] - F_int[-2]] * H
+    else:         # :13,16
+        dm = [F_int[N - H + i] - F_int[N - H + i - 1] for i in range(1, H + 1)]     # Fi[end-H+i] - Fi[end-H+i-1]
+        dp = [F_int[i] - F_int[i - 1] for i in range(1, H + 1)]                     # Fi[i+1] - Fi[i]
+    dp = dp[::-1]
+    # F₋ = [c¹ - sum(Δᶠ₋[i:H])], F₊ = reverse([cᴺ⁺¹ + sum(Δᶠ₊[i:H])]) with Julia's left-to-right sum
+    def jsum(v):
+        s = v[0]
+        for x in v[1:]:
+            s = s + x
+        return s
+    Fm = [F_int[0] - jsum(dm[i:H]) for i in range(H)]
+    Fp = [F_int[N] + jsum(dp[i:H]) for i in range(H)][::-1]
+    F = np.concatenate([Fm, F_int, Fp])                       # N + 1 + 2H faces
+    TC = N + 2 * H
+    Cc = np.array([(F[i + 1] + F[i]) / 2 for i in range(TC)])
+    dF = [Cc[i] - Cc[i - 1] for i in range(1, TC)]
+    TF = N + 2 * H + (1 if bounded else 0)
+    F = F[:TF]
+    dC = [F[i + 1] - F[i] for i in range(TF - 1)]
+    dF = [dF[0]] + dF + [dF[-1]]
+    for i in range(len(dF) - 1, 0, -1):
+        dF[i] = dF[i - 1]
+    # reference indices: Δᶜ idx = 1-H .. (TF-1)-H ; Δᶠ idx = -H .. N+H
+    n = N + 2 * H + 1
+    dc = np.empty(n)
+    df = np.empty(n)
+    for pos in range(n):
+        idx = pos + 1 - H
+        pc = idx - (1 - H)
+        dc[pos] = dC[min(pc, len(dC) - 1)]
+        pf = idx - (-H)
+        df[pos] = dF[min(pf, len(dF) - 1)]
+    return float(L), dc, df
+
+
+class Grid:
+    """RectilinearGrid (x, y regular; z regular or stretched-Bounded). reference: Grids/rectilinear_grid.jl:264-291"""
+
+    def __init__(self, size, halo=(3, 3, 3), topology=(PERIODIC, PERIODIC, PERIODIC),
+                 x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0)):
+        self.N = tuple(int(n) for n in size)
+        self.H = tuple(int(h) for h in halo)
+        self.topo = tuple(int(t) for t in topology)
+        self.L = [0.0] * 3
+        self.dc, self.df = [None] * 3, [None] * 3
+        for d, coord in enumerate((x, y, z)):
+            n = self.N[d] + 2 * self.H[d] + 1
+            if isinstance(coord, tuple) and len(coord) == 2 and np.isscalar(coord[0]):
+                delta, L = regular_spacing(coord, self.N[d])
+                self.L[d] = L
+                self.dc[d] = np.full(n, delta)
+                self.df[d] = np.full(n, delta)
+            else:
+                self.L[d], self.dc[d], self.df[d] = stretched_spacings(coord, self.N[d], self.H[d],
+                                                                       self.topo[d] == BOUNDED)
+        self.handle = lib().oro_grid_create(_i3(self.N), _i3(self.H), _i3(self.topo), (C.c_double * 3)(*self.L),
+                                            _dp(self.dc[0]), _dp(self.df[0]), _dp(self.dc[1]), _dp(self.df[1]),
+                                            _dp(self.dc[2]), _dp(self.df[2]))
+
+    def parent_size(self, loc):
+        return tuple(self.N[d] + 2 * self.H[d] + (1 if (loc[d] == FACE and self.topo[d] == BOUNDED) else 0)
+                     for d in range(3))
+
+    def zeros(self, loc):
+        return np.zeros(self.parent_size(loc), dtype=np.float64, order="F")
+
+    def interior(self, a, loc):
+        sl = []
+        for d in range(3):
+            n = self.N[d] + (1 if (loc[d] == FACE and self.topo[d] == BOUNDED) else 0)
+            sl.append(slice(self.H[d], self.H[d] + n))
+        return a[tuple(sl)]
+
+    def interior_cells(self, a):
+        return a[tuple(slice(self.H[d], self.H[d] + self.N[d]) for d in range(3))]
+
+    # ---- kernels ----
+    def fill_halo_regions(self, a, loc, fill_open_bcs=True):
+        lib().oro_fill_halo_regions(self.handle, _dp(a), _i3(loc), int(fill_open_bcs))
+
+    def compute_G(self, which, u, v, w, G, c=None, rng=None):
+        r = (C.c_int * 6)(*rng) if rng is not None else None
+        if which == "c":
+            lib().oro_compute_Gc(self.handle, _dp(u), _dp(v), _dp(w), _dp(c), _dp(G), r)
+        else:
+            getattr(lib(), "oro_compute_G" + which)(self.handle, _dp(u), _dp(v), _dp(w), _dp(G), r)
+
+    def rk3_substep(self, U, loc, dt, gamma, zeta, Gn, Gm):
+        lib().oro_rk3_substep_field(self.handle, _dp(U), _i3(loc), dt, gamma, 0.0 if zeta is None else zeta,
+                                    0 if zeta is None else 1, _dp(Gn), _dp(Gm))
+
+    def source_term(self, u, v, w, weight_by_dz=False):
+        rhs = np.zeros(self.N, dtype=np.complex128, order="F")
+        lib().oro_compute_source_term(self.handle, _dp(u), _dp(v), _dp(w), rhs.ctypes.data, int(weight_by_dz))
+        return rhs
+
+    def pressure_correct(self, u, v, w, p):
+        lib().oro_make_pressure_correction(self.handle, _dp(u), _dp(v), _dp(w), _dp(p))
+
+
+class PoissonSolver:
+    def __init__(self, grid, kind):
+        self.grid, self.kind = grid, kind
+        self.handle = lib().oro_poisson_create(grid.handle, kind)
+        n = grid.N[0] * grid.N[1] * grid.N[2]
+        buf = (C.c_double * (2 * n)).from_address(lib().oro_poisson_rhs(self.handle))
+        self.rhs = np.frombuffer(buf, dtype=np.complex128).reshape(grid.N, order="F")
+
+    def solve(self, phi):
+        lib().oro_poisson_solve(self.handle, _dp(phi))
+
+    def __del__(self):
+        try:
+            lib().oro_poisson_destroy(self.handle)
+        except Exception:
+            pass
+
+
+class Model:
+    """NonhydrostaticModel(grid; advection=WENO(), tracers, timestepper=:RungeKutta3) on the CPU oracle."""
+
+    def __init__(self, grid, ntracers=2):
+        self.grid, self.ntracers = grid, ntracers
+        self.handle = lib().oro_model_create(grid.handle, ntracers)
+
+    def names(self):
+        return ["u", "v", "w"] + ["c%d" % t for t in range(self.ntracers)]
+
+    def field(self, name):
+        """numpy view (parent array with halos, Fortran order) of a model field."""
+        loc = (C.c_int * 3)()
+        lib().oro_model_field_loc(self.handle, name.encode(), loc)
+        shape = self.grid.parent_size(tuple(loc))
+        ptr = lib().oro_model_field(self.handle, name.encode())
+        n = int(np.prod(shape))
+        buf = (C.c_double * n).from_address(C.addressof(ptr.contents))
+        return np.frombuffer(buf, dtype=np.float64).reshape(shape, order="F")
+
+    def loc(self, name):
+        loc = (C.c_int * 3)()
+        lib().oro_model_field_loc(self.handle, name.encode(), loc)
+        return tuple(loc)
+
+    def set(self, enforce_incompressibility=True, **fields):
+        for name, val in fields.items():
+            a = self.field(name)
+            self.grid.interior(a, self.loc(name))[...] = val
+        lib().oro_model_set_finalize(self.handle, int(enforce_incompressibility))
+
+    def update_state(self, compute_tendencies=True):
+        lib().oro_model_update_state(self.handle, int(compute_tendencies))
+
+    def time_step(self, dt):
+        lib().oro_model_time_step(self.handle, float(dt))
+
+    @property
+    def time(self):
+        return lib().oro_model_time(self.handle)
+
+    @property
+    def iteration(self):
+        return lib().oro_model_iteration(self.handle)
+
+    def max_abs_divergence(self):
+        return lib().oro_model_max_abs_divergence(self.handle)
+
+    def __del__(self):
+        try:
+            lib().oro_model_destroy(self.handle)
+        except Exception:
+            pass
