@@ -1,0 +1,153 @@
+/* ocn_mi355x.h -- C ABI of libocn_mi355x.so: the MI355X-native NonhydrostaticModel RK3 time-step hot path.
+ *
+ * This is the drop-in boundary. The reference (Oceananigans v0.100.5) has no FFI: its seam is Julia dispatch on the
+ * architecture type (ext/OceananigansAMDGPUExt.jl:34-113) + `launch!(arch, grid, workspec, kernel!, args...)`
+ * (src/Utils/kernel_launching.jl:340-380). A Julia maintainer binds these entry points with `ccall` from methods
+ * specialised on a new architecture tag; each entry point below names the reference function
+ * (file:line, relative to the reference's src/) whose body it replaces.
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers to dense column-major parent arrays WITH halos, exactly the memory of
+ *    `parent(field.data)` (src/Grids/new_data.jl:36-73): element (i, j, k) (1-based interior index) lives at
+ *    (i-1+Hx) + Px*((j-1+Hy) + Py*(k-1+Hz)), P = N + 2H (+1 for Face fields on Bounded dims, grid_utils.jl:66-72).
+ *  - Pointers are BORROWED for the duration of the call; the library never frees caller memory. Objects created by
+ *    *_create are owned by the library until *_destroy.
+ *  - Every entry point returns int: 0 = ok; negative = invalid argument (mirrors the ArgumentErrors the reference
+ *    throws at construction time); positive = hipError_t / hipfftResult (+1000) / ncclResult_t (+2000).
+ *    ocn_last_error() returns a thread-local message. The library never aborts.
+ *  - All work is enqueued on ONE non-blocking HIP stream per device (the reference runs every kernel on the default
+ *    stream in program order, kernel_launching.jl:335-336). Entry points are asynchronous w.r.t. the host unless
+ *    stated otherwise; ocn_sync() is `sync_device!` (ext/OceananigansAMDGPUExt.jl:112-113).
+ *  - location codes: 0 = Center, 1 = Face. topology codes: 0 = Periodic, 1 = Bounded.
+ */
+#ifndef OCN_MI355X_H
+#define OCN_MI355X_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OCN_PERIODIC 0
+#define OCN_BOUNDED 1
+#define OCN_CENTER 0
+#define OCN_FACE 1
+
+#define OCN_OK 0
+#define OCN_EINVAL (-1)      /* invalid argument (ArgumentError in the reference) */
+#define OCN_ENOTSUP (-2)     /* configuration outside the accelerated hot path */
+#define OCN_ESTATE (-3)      /* call sequence error (e.g. library not initialised) */
+
+typedef struct ocn_grid_s *ocn_grid_t;
+typedef struct ocn_poisson_s *ocn_poisson_t;
+typedef struct ocn_model_s *ocn_model_t;
+
+/* ---------------------------------------------------------------- runtime (src/Architectures.jl:35-123) ---------- */
+int ocn_init(int device_id);                                  /* device!(arch, id) */
+int ocn_sync(void);                                           /* sync_device! */
+const char *ocn_last_error(void);
+const char *ocn_version(void);
+int ocn_malloc(void **ptr, size_t bytes);                     /* zeros(arch, FT, dims...) -- memory is zero-filled */
+int ocn_free(void *ptr);                                      /* unsafe_free! */
+int ocn_memcpy_h2d(void *dst, const void *src, size_t bytes); /* on_architecture(GPU(), a)  (synchronous) */
+int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes); /* on_architecture(CPU(), a)  (synchronous) */
+int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes); /* device_copy_to! (stream ordered) */
+int ocn_memset_zero(void *dst, size_t bytes);
+void *ocn_stream(void);                                       /* the hipStream_t all work is enqueued on */
+
+/* ---------------------------------------------------------------- grid (src/Grids/rectilinear_grid.jl:3-25) ------ */
+/* N, H, topo, L: per dimension. dx, dy: regular spacings. dzc / dzf: HOST arrays of Δzᵃᵃᶜ / Δzᵃᵃᶠ for index
+ * k = 1-Hz .. Nz+Hz+1 (length Nz + 2Hz + 1, position k-1+Hz); pass NULL for a z-regular grid (then dz is used).
+ * Stretched x / y are outside the hot path -> callers must pass regular dx, dy. */
+int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3], const int topo[3], const double L[3],
+                    double dx, double dy, double dz, const double *dzc, const double *dzf);
+int ocn_grid_destroy(ocn_grid_t grid);
+int ocn_grid_parent_size(ocn_grid_t grid, const int loc[3], int P[3]);    /* total_size, grid_utils.jl:138-169 */
+
+/* ---------------------------------------------------------------- halo fills (BoundaryConditions/) -------------- */
+/* fill_halo_regions!(field) with the default boundary conditions of field_boundary_conditions.jl:15-25
+ * (Periodic -> PeriodicBC copies, fill_halo_regions_periodic.jl:5-33; Bounded+Center -> no-flux one-cell mirror,
+ * fill_halo_regions_flux.jl:9-27; Bounded+Face -> impenetrable wall value, fill_halo_regions_open.jl:2-7, skipped when
+ * fill_open_bcs == 0). nfields fields of identical location are filled by ONE launch. */
+int ocn_fill_halo_regions(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int fill_open_bcs);
+
+/* ---------------------------------------------------------------- tendencies ------------------------------------ */
+/* compute_Gu!/Gv!/Gw!/Gc! (Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:138-163) for
+ * advection = WENO(order=5), every other term `nothing`. range = {i0,i1,j0,j1,k0,k1} inclusive 1-based
+ * (KernelParameters, kernel_launching.jl:25-95) or NULL for the reference's default launch (:xyz, exclude_periphery
+ * for velocities). */
+int ocn_compute_Gu(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gu, const int *range);
+int ocn_compute_Gv(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gv, const int *range);
+int ocn_compute_Gw(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gw, const int *range);
+int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                   const int *range);
+/* compute_interior_tendency_contributions! (…tendencies.jl:49-131): all of Gu, Gv, Gw and ntracers Gc in one fused,
+ * flux-sharing pass. */
+int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                           const double *const *tracers, int ntracers,
+                           double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range);
+
+/* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
+/* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage
+ * method `U += Δt γ¹ G¹`. */
+int ocn_rk3_substep(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm,
+                    const int (*locs)[3], int nfields, double dt, double gamma, double zeta, int has_zeta);
+/* _cache_field_tendencies! (TimeSteppers/store_tendencies.jl:6-9) */
+int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const double *const *Gn, const int (*locs)[3], int nfields);
+
+/* ---------------------------------------------------------------- pressure -------------------------------------- */
+/* _compute_source_term! / _fourier_tridiagonal_source_term!(ZDirection) (solve_for_pressure.jl:12-18, 36-42).
+ * rhs: interleaved complex double, dense (Nx, Ny, Nz). */
+int ocn_compute_source_term(ocn_grid_t grid, const double *u, const double *v, const double *w, double *rhs_complex,
+                            int weight_by_dz);
+/* _make_pressure_correction! (pressure_correction.jl:31-37) */
+int ocn_make_pressure_correction(ocn_grid_t grid, double *u, double *v, double *w, const double *p);
+/* `pNHS ./= Δt⁺` (pressure_correction.jl:48-50): interior of a (Center, Center, Center) field */
+int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor);
+
+/* ---------------------------------------------------------------- solvers (src/Solvers) ------------------------- */
+/* kind 0: FFTBasedPoissonSolver (fft_based_poisson_solver.jl:52-74); kind 1: FourierTridiagonalPoissonSolver with
+ * tridiagonal direction z (fourier_tridiagonal_poisson_solver.jl:75-134); kind -1: pick like
+ * NonhydrostaticModels.jl:25-40 (regular z -> 0, stretched z -> 1). */
+int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int kind);
+int ocn_poisson_destroy(ocn_poisson_t solver);
+int ocn_poisson_kind(ocn_poisson_t solver);
+/* device pointer to the complex right-hand-side storage (solver.storage / solver.source_term) */
+int ocn_poisson_rhs(ocn_poisson_t solver, double **rhs_complex);
+/* solve!(ϕ, solver) (fft_based_poisson_solver.jl:95-125 / fourier_tridiagonal_poisson_solver.jl:212-239): consumes the
+ * rhs storage, writes the interior of the haloed (C,C,C) field phi. */
+int ocn_poisson_solve(ocn_poisson_t solver, double *phi);
+/* solve_for_pressure! (solve_for_pressure.jl:91-95) = source term + solve */
+int ocn_solve_for_pressure(ocn_poisson_t solver, const double *u, const double *v, const double *w, double *p);
+/* solve_batched_tridiagonal_system_kernel! (batched_tridiagonal_solver.jl:213-245), z direction: a, c length Nz-1,
+ * b dense (Nx,Ny,Nz) real, f / phi dense complex, t dense real scratch. */
+int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c,
+                                    const double *f_complex, double *t, double *phi_complex);
+
+/* ---------------------------------------------------------------- model fast path ------------------------------- */
+/* NonhydrostaticModel(; grid, advection = WENO(), tracers, timestepper = :RungeKutta3) with coriolis / buoyancy /
+ * closure / forcing = nothing (nonhydrostatic_model.jl:115-244). Fields are allocated (zeroed) by the library. */
+int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers);
+int ocn_model_destroy(ocn_model_t model);
+/* names: "u","v","w","c0".."c7" (tracers), "p" (pNHS), "Gu".."Gc7" (Gⁿ), "Mu".."Mc7" (G⁻). Returns the device
+ * pointer of the parent array and its location. Pointers stay valid for the model's lifetime and are stable at
+ * time-step boundaries. */
+int ocn_model_field(ocn_model_t model, const char *name, double **ptr, int loc[3]);
+/* update_state!(model; compute_tendencies) (update_nonhydrostatic_model_state.jl:20-56) */
+int ocn_model_update_state(ocn_model_t model, int compute_tendencies);
+/* tail of set!(model; ...) after the interiors were written (set_nonhydrostatic_model.jl:44-57) */
+int ocn_model_set_finalize(ocn_model_t model, int enforce_incompressibility);
+/* time_step!(model, Δt) (runge_kutta_3.jl:93-170) */
+int ocn_model_time_step(ocn_model_t model, double dt);
+int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *stage, double *last_dt,
+                    double *last_stage_dt);
+/* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */
+int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
+/* tendency implementation: 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel */
+int ocn_model_set_option(ocn_model_t model, const char *key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

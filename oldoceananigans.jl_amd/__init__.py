@@ -1,0 +1,16 @@
+"""oldoceananigans.jl_amd -- MI355X-native NonhydrostaticModel RK3 time-step (hot path of Oceananigans v0.100.5).
+
+Host-side mirror of the reference's Architecture / Grid / Field / launch! surface over the C ABI of
+libocn_mi355x.so (include/ocn_mi355x.h). Import as `import oldoceananigans_jl_amd as ocn`."""
+from . import _lib
+from ._lib import OcnError, build
+from .advection import WENO
+from .architectures import GPU, architecture, synchronize
+from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
+from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid
+from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
+from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
+                      solve_for_pressure)
+from . import kernels
+
+__all__ = [n for n in dir() if not n.startswith("_")]

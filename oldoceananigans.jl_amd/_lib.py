@@ -1,0 +1,94 @@
+"""ctypes binding of libocn_mi355x.so (C ABI: include/ocn_mi355x.h). The product path FAILS LOUDLY when the HIP
+extension is missing or a call returns a non-zero status -- there is no CPU fallback."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libocn_mi355x.so")
+_lib = None
+
+
+class OcnError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(_HERE, "csrc", f) for f in os.listdir(os.path.join(_HERE, "csrc"))
+            if f.endswith((".hip", ".h", ".sh"))]
+    srcs.append(os.path.join(_HERE, "..", "include", "ocn_mi355x.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "ocn_weno_coeffs.h"))
+    if force or not os.path.exists(SO_PATH) or any(os.path.getmtime(s) > os.path.getmtime(SO_PATH) for s in srcs):
+        subprocess.check_call(["bash", os.path.join(_HERE, "csrc", "build.sh")])
+    return SO_PATH
+
+
+# every symbol include/ocn_mi355x.h declares: name -> (restype, argtypes)
+_vp, _dp, _ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
+_pp = C.POINTER(C.c_void_p)
+SYMBOLS = {
+    "ocn_init": (C.c_int, [C.c_int]),
+    "ocn_sync": (C.c_int, []),
+    "ocn_last_error": (C.c_char_p, []),
+    "ocn_version": (C.c_char_p, []),
+    "ocn_malloc": (C.c_int, [_pp, C.c_size_t]),
+    "ocn_free": (C.c_int, [_vp]),
+    "ocn_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ocn_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ocn_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ocn_memset_zero": (C.c_int, [_vp, C.c_size_t]),
+    "ocn_stream": (_vp, []),
+    "ocn_grid_create": (C.c_int, [_pp, _ip, _ip, _ip, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]),
+    "ocn_grid_destroy": (C.c_int, [_vp]),
+    "ocn_grid_parent_size": (C.c_int, [_vp, _ip, _ip]),
+    "ocn_fill_halo_regions": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int]),
+    "ocn_compute_Gu": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _ip]),
+    "ocn_compute_Gv": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _ip]),
+    "ocn_compute_Gw": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _ip]),
+    "ocn_compute_Gc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _ip]),
+    "ocn_compute_tendencies": (C.c_int, [_vp, _vp, _vp, _vp, _pp, C.c_int, _vp, _vp, _vp, _pp, _ip]),
+    "ocn_rk3_substep": (C.c_int, [_vp, _pp, _pp, _pp, _vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]),
+    "ocn_cache_tendencies": (C.c_int, [_vp, _pp, _pp, _vp, C.c_int]),
+    "ocn_compute_source_term": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int]),
+    "ocn_make_pressure_correction": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ocn_divide_interior": (C.c_int, [_vp, _vp, C.c_double]),
+    "ocn_poisson_create": (C.c_int, [_pp, _vp, C.c_int]),
+    "ocn_poisson_destroy": (C.c_int, [_vp]),
+    "ocn_poisson_kind": (C.c_int, [_vp]),
+    "ocn_poisson_rhs": (C.c_int, [_vp, _pp]),
+    "ocn_poisson_solve": (C.c_int, [_vp, _vp]),
+    "ocn_solve_for_pressure": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "ocn_batched_tridiagonal_solve_z": (C.c_int, [C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ocn_model_create": (C.c_int, [_pp, _vp, C.c_int]),
+    "ocn_model_destroy": (C.c_int, [_vp]),
+    "ocn_model_field": (C.c_int, [_vp, C.c_char_p, _pp, _ip]),
+    "ocn_model_update_state": (C.c_int, [_vp, C.c_int]),
+    "ocn_model_set_finalize": (C.c_int, [_vp, C.c_int]),
+    "ocn_model_time_step": (C.c_int, [_vp, C.c_double]),
+    "ocn_model_clock": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
+    "ocn_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
+    "ocn_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise OcnError(f"HIP extension {SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback in the product path)")
+        _lib = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(_lib, name)        # AttributeError if the library does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise OcnError(f"libocn_mi355x status {status}: {lib().ocn_last_error().decode()}")
+
+
+def i3(t):
+    return (C.c_int * 3)(*[int(x) for x in t])

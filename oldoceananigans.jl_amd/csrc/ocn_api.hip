@@ -1,0 +1,866 @@
+// ocn_api.hip -- C ABI (include/ocn_mi355x.h) of the MI355X-native NonhydrostaticModel hot path.
+// Host orchestration mirrors the reference functions cited next to each entry point; all device work is enqueued on
+// one non-blocking HIP stream.
+#include "../../include/ocn_mi355x.h"
+#include "ocn_kernels.h"
+#include "ocn_tendency_fused.h"
+#include <hipfft/hipfft.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------------------------------------------------
+// runtime state / error handling
+// ---------------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_));     \
+    } while (0)
+#define FFT_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipfftResult r_ = (expr);                                                                \
+        if (r_ != HIPFFT_SUCCESS) return fail(1000 + (int)r_, "%s: hipfftResult %d", #expr, (int)r_); \
+    } while (0)
+#define NEED_INIT()                                                                              \
+    do {                                                                                         \
+        if (!g_stream) return fail(OCN_ESTATE, "ocn_init() has not been called");                \
+    } while (0)
+#define KERNEL_CHECK()                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = hipGetLastError();                                                       \
+        if (e_ != hipSuccess) return fail((int)e_, "kernel launch: %s", hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *ocn_last_error(void) { return g_err; }
+extern "C" const char *ocn_version(void) { return "ocn_mi355x 0.1 (gfx950; reference Oceananigans v0.100.5)"; }
+
+extern "C" int ocn_init(int device_id) {
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) return fail(OCN_ESTATE, "no HIP device visible");
+    if (device_id < 0 || device_id >= count) return fail(OCN_EINVAL, "device_id %d out of range [0, %d)", device_id, count);
+    HIP_TRY(hipSetDevice(device_id));
+    if (g_stream && g_device == device_id) return OCN_OK;
+    if (g_stream) { hipStreamDestroy(g_stream); g_stream = nullptr; }
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = device_id;
+    return OCN_OK;
+}
+
+extern "C" int ocn_sync(void) { NEED_INIT(); HIP_TRY(hipStreamSynchronize(g_stream)); return OCN_OK; }
+extern "C" void *ocn_stream(void) { return (void *)g_stream; }
+
+extern "C" int ocn_malloc(void **ptr, size_t bytes) {
+    NEED_INIT();
+    if (!ptr) return fail(OCN_EINVAL, "ptr is NULL");
+    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8));
+    HIP_TRY(hipMemsetAsync(*ptr, 0, bytes ? bytes : 8, g_stream));
+    return OCN_OK;
+}
+extern "C" int ocn_free(void *ptr) { if (ptr) HIP_TRY(hipFree(ptr)); return OCN_OK; }
+extern "C" int ocn_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    NEED_INIT();
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return OCN_OK;
+}
+extern "C" int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    NEED_INIT();
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return OCN_OK;
+}
+extern "C" int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes) {
+    NEED_INIT();
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+    return OCN_OK;
+}
+extern "C" int ocn_memset_zero(void *dst, size_t bytes) {
+    NEED_INIT();
+    HIP_TRY(hipMemsetAsync(dst, 0, bytes, g_stream));
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// grid
+// ---------------------------------------------------------------------------------------------------------------------
+struct ocn_grid_s {
+    DGrid d;
+    double L[3];
+    bool z_regular;
+    double *tables;   // one device allocation holding dzc, dzf, ax, ay, vinv_c, vinv_f, rdzf
+    std::vector<double> h_dzc, h_dzf;
+};
+
+static void parent_size(const DGrid &g, const int loc[3], int P[3]) {
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
+    for (int d = 0; d < 3; ++d) P[d] = N[d] + 2 * H[d] + ((loc[d] == OCN_FACE && T[d] == OCN_BOUNDED) ? 1 : 0);
+}
+
+static FView make_view(const DGrid &g, const double *p, const int loc[3]) {
+    int P[3];
+    parent_size(g, loc, P);
+    FView v;
+    v.p = const_cast<double *>(p);
+    v.s1 = P[0];
+    v.s2 = (long)P[0] * P[1];
+    v.off = (g.Hx - 1) + (long)v.s1 * (g.Hy - 1) + v.s2 * (g.Hz - 1);
+    return v;
+}
+
+static const int LOC_U[3] = {OCN_FACE, OCN_CENTER, OCN_CENTER};
+static const int LOC_V[3] = {OCN_CENTER, OCN_FACE, OCN_CENTER};
+static const int LOC_W[3] = {OCN_CENTER, OCN_CENTER, OCN_FACE};
+static const int LOC_C[3] = {OCN_CENTER, OCN_CENTER, OCN_CENTER};
+
+extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3], const int topo[3], const double L[3],
+                               double dx, double dy, double dz, const double *dzc, const double *dzf) {
+    NEED_INIT();
+    if (!grid || !N || !H || !topo || !L) return fail(OCN_EINVAL, "NULL argument");
+    for (int d = 0; d < 3; ++d) {
+        if (N[d] < 1) return fail(OCN_EINVAL, "size must be positive (dimension %d)", d);
+        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED)
+            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic and Bounded are accelerated", topo[d], d);
+        // WENO(order=5) needs a halo of 3 (nonhydrostatic_model.jl:184, inflate_grid_halo_size) and N >= 3 so that
+        // adapt_advection_order (Advection/adapt_advection_order.jl:90-96) keeps the scheme
+        if (H[d] < 3) return fail(OCN_EINVAL, "halo %d < 3 in dimension %d: WENO(order=5) requires halo >= 3", H[d], d);
+        if (N[d] < H[d]) return fail(OCN_EINVAL, "size %d < halo %d in dimension %d", N[d], H[d], d);
+        if (!(L[d] > 0)) return fail(OCN_EINVAL, "extent must be positive");
+    }
+    if (!(dx > 0) || !(dy > 0)) return fail(OCN_EINVAL, "dx, dy must be positive");
+    if ((dzc == nullptr) != (dzf == nullptr)) return fail(OCN_EINVAL, "pass both dzc and dzf or neither");
+    if (!dzc && !(dz > 0)) return fail(OCN_EINVAL, "dz must be positive for a z-regular grid");
+    if (dzc && topo[2] != OCN_BOUNDED)
+        return fail(OCN_ENOTSUP, "stretched z requires Bounded z topology (FourierTridiagonalPoissonSolver, "
+                                 "fourier_tridiagonal_poisson_solver.jl:88-92)");
+    ocn_grid_s *g = new ocn_grid_s();
+    DGrid &D = g->d;
+    D.Nx = N[0]; D.Ny = N[1]; D.Nz = N[2];
+    D.Hx = H[0]; D.Hy = H[1]; D.Hz = H[2];
+    D.tx = topo[0]; D.ty = topo[1]; D.tz = topo[2];
+    D.dx = dx; D.dy = dy; D.az = dx * dy;
+    D.rdx = 1.0 / dx; D.rdy = 1.0 / dy;
+    for (int d = 0; d < 3; ++d) g->L[d] = L[d];
+    const int n = N[2] + 2 * H[2] + 1;
+    g->h_dzc.resize(n); g->h_dzf.resize(n);
+    g->z_regular = true;
+    for (int q = 0; q < n; ++q) {
+        g->h_dzc[q] = dzc ? dzc[q] : dz;
+        g->h_dzf[q] = dzf ? dzf[q] : dz;
+        if (!(g->h_dzc[q] > 0) || !(g->h_dzf[q] > 0)) { delete g; return fail(OCN_EINVAL, "z spacings must be positive"); }
+    }
+    for (int k = 1; k <= N[2]; ++k)
+        if (g->h_dzc[k - 1 + H[2]] != g->h_dzc[H[2]] || g->h_dzf[k - 1 + H[2]] != g->h_dzc[H[2]]) g->z_regular = false;
+    std::vector<double> tab(7 * (size_t)n);
+    for (int q = 0; q < n; ++q) {
+        const double zc = g->h_dzc[q], zf = g->h_dzf[q];
+        tab[0 * n + q] = zc;
+        tab[1 * n + q] = zf;
+        tab[2 * n + q] = dy * zc;                       // Axᶠᶜᶜ = Δy Δz   (spacings_and_areas_and_volumes.jl:308-335)
+        tab[3 * n + q] = dx * zc;                       // Ayᶜᶠᶜ = Δx Δz
+        tab[4 * n + q] = 1.0 / ((dx * dy) * zc);        // V⁻¹ = 1 / (Az Δz)  (:369-378, reciprocal_metric_operators.jl)
+        tab[5 * n + q] = 1.0 / ((dx * dy) * zf);
+        tab[6 * n + q] = 1.0 / zf;
+    }
+    hipError_t e = hipMalloc((void **)&g->tables, tab.size() * sizeof(double));
+    if (e != hipSuccess) { delete g; return fail((int)e, "hipMalloc(grid tables): %s", hipGetErrorString(e)); }
+    e = hipMemcpy(g->tables, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(g->tables); delete g; return fail((int)e, "hipMemcpy(grid tables): %s", hipGetErrorString(e)); }
+    D.dzc = g->tables; D.dzf = g->tables + n; D.ax = g->tables + 2 * n; D.ay = g->tables + 3 * n;
+    D.vinv_c = g->tables + 4 * n; D.vinv_f = g->tables + 5 * n; D.rdzf = g->tables + 6 * n;
+    *grid = g;
+    return OCN_OK;
+}
+
+extern "C" int ocn_grid_destroy(ocn_grid_t grid) {
+    if (!grid) return OCN_OK;
+    hipFree(grid->tables);
+    delete grid;
+    return OCN_OK;
+}
+
+extern "C" int ocn_grid_parent_size(ocn_grid_t grid, const int loc[3], int P[3]) {
+    if (!grid || !loc || !P) return fail(OCN_EINVAL, "NULL argument");
+    parent_size(grid->d, loc, P);
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// launch helpers (Utils/kernel_launching.jl: `launch!`, `interior_work_layout`)
+// ---------------------------------------------------------------------------------------------------------------------
+static inline dim3 grid3(int nx, int ny, int nz, dim3 block) {
+    return dim3((nx + block.x - 1) / block.x, (ny + block.y - 1) / block.y, nz);
+}
+static const dim3 BLK(64, 4, 1);
+
+// kernel_launching.jl:145-195: exclude_periphery drops the first Face index on Bounded dims
+static Range6 default_range(const DGrid &g, const int loc[3], bool exclude_periphery) {
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
+    int lo[3];
+    for (int d = 0; d < 3; ++d)
+        lo[d] = 1 + ((exclude_periphery && loc[d] == OCN_FACE && T[d] == OCN_BOUNDED && N[d] > 1) ? 1 : 0);
+    return Range6{lo[0], N[0], lo[1], N[1], lo[2], N[2]};
+}
+
+static int check_range(const DGrid &g, const int *range, Range6 *out, const int loc[3], bool exclude_periphery) {
+    if (!range) { *out = default_range(g, loc, exclude_periphery); return OCN_OK; }
+    Range6 r{range[0], range[1], range[2], range[3], range[4], range[5]};
+    // stencils reach 3 cells: the tendency of cell i needs psi[i-3 .. i+3]
+    if (r.i0 < 1 || r.j0 < 1 || r.k0 < 1 || r.i1 > g.Nx || r.j1 > g.Ny || r.k1 > g.Nz)
+        return fail(OCN_EINVAL, "kernel range (%d:%d, %d:%d, %d:%d) exceeds the interior", r.i0, r.i1, r.j0, r.j1, r.k0, r.k1);
+    *out = r;
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// halo fills
+// ---------------------------------------------------------------------------------------------------------------------
+static int fill_halo_group(const DGrid &g, double *const *fields, int n, const int loc[3], bool fill_open) {
+    if (n <= 0) return OCN_OK;
+    FieldList fl;
+    fl.n = n;
+    for (int f = 0; f < n; ++f) fl.p[f] = fields[f];
+    int P[3];
+    parent_size(g, loc, P);
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
+    FView view = make_view(g, nullptr, loc);
+    // order: boundary_condition_ordering.jl:17-46 -- non-periodic first, then periodic; insertion sort with an
+    // always-true `lt` reverses same-class entries => z, y, x inside each class.
+    for (int d = 2; d >= 0; --d) {
+        if (T[d] != OCN_BOUNDED) continue;
+        const bool face = loc[d] == OCN_FACE;
+        if (face && !fill_open) continue;
+        const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
+        const long total = (long)Na * Nb;
+        const int nb = (int)((total + 255) / 256);
+        if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[0], face, fill_open);
+        if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[1], face, fill_open);
+        if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[2], face, fill_open);
+    }
+    for (int d = 2; d >= 0; --d) {
+        if (T[d] != OCN_PERIODIC) continue;
+        const int Pa = d == 0 ? P[1] : P[0], Pb = d == 2 ? P[1] : P[2];
+        const long total = (long)2 * H[d] * Pa * Pb;
+        const int nb = (int)((total + 255) / 256);
+        if (d == 0) hipLaunchKernelGGL(fill_periodic_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], N[0], H[0]);
+        if (d == 1) hipLaunchKernelGGL(fill_periodic_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], N[1], H[1]);
+        if (d == 2) hipLaunchKernelGGL(fill_periodic_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], N[2], H[2]);
+    }
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// groups fields by identical location (identical parent shape) -> one set of launches per group
+static int fill_halo_regions(const DGrid &g, double *const *fields, const int (*locs)[3], int nfields, bool fill_open) {
+    if (nfields > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
+    bool done[OCN_MAX_FIELDS] = {false};
+    for (int f = 0; f < nfields; ++f) {
+        if (done[f]) continue;
+        double *grp[OCN_MAX_FIELDS];
+        int n = 0;
+        int P0[3], P1[3];
+        parent_size(g, locs[f], P0);
+        for (int h = f; h < nfields; ++h) {
+            if (done[h]) continue;
+            parent_size(g, locs[h], P1);
+            bool same = P0[0] == P1[0] && P0[1] == P1[1] && P0[2] == P1[2];
+            for (int d = 0; d < 3 && same; ++d) {
+                const int T[3] = {g.tx, g.ty, g.tz};
+                if (T[d] == OCN_BOUNDED && locs[h][d] != locs[f][d]) same = false;
+            }
+            if (same) { grp[n++] = fields[h]; done[h] = true; }
+        }
+        int rc = fill_halo_group(g, grp, n, locs[f], fill_open);
+        if (rc) return rc;
+    }
+    return OCN_OK;
+}
+
+extern "C" int ocn_fill_halo_regions(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int fill_open_bcs) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || nfields < 0) return fail(OCN_EINVAL, "invalid argument");
+    return fill_halo_regions(grid->d, fields, locs, nfields, fill_open_bcs != 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// tendencies
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F>
+static int launch_tendency(const DGrid &g, const double *u, const double *v, const double *w, const double *c, double *G,
+                           const int *range) {
+    const int *loc = F == F_U ? LOC_U : (F == F_V ? LOC_V : (F == F_W ? LOC_W : LOC_C));
+    Range6 r;
+    int rc = check_range(g, range, &r, loc, F != F_C);
+    if (rc) return rc;
+    const int nx = r.i1 - r.i0 + 1, ny = r.j1 - r.j0 + 1, nz = r.k1 - r.k0 + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;   // "Don't launch kernels with no size" (kernel_launching.jl:370)
+    FView fu = make_view(g, u, LOC_U), fv = make_view(g, v, LOC_V), fw = make_view(g, w, LOC_W);
+    FView fc = make_view(g, c ? c : u, LOC_C), fG = make_view(g, G, loc);
+    hipLaunchKernelGGL(tendency_kernel<F>, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, fu, fv, fw, fc, fG, r);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_Gu(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gu, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !Gu) return fail(OCN_EINVAL, "NULL argument");
+    return launch_tendency<F_U>(grid->d, u, v, w, nullptr, Gu, range);
+}
+extern "C" int ocn_compute_Gv(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gv, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !Gv) return fail(OCN_EINVAL, "NULL argument");
+    return launch_tendency<F_V>(grid->d, u, v, w, nullptr, Gv, range);
+}
+extern "C" int ocn_compute_Gw(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gw, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !Gw) return fail(OCN_EINVAL, "NULL argument");
+    return launch_tendency<F_W>(grid->d, u, v, w, nullptr, Gw, range);
+}
+extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
+                              const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !c || !Gc) return fail(OCN_EINVAL, "NULL argument");
+    return launch_tendency<F_C>(grid->d, u, v, w, c, Gc, range);
+}
+
+static int compute_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr,
+                              int ntr, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range, int impl) {
+    if (impl == 1 && fused_tendency_supported(g, range)) return launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc);
+    int rc;
+    if ((rc = launch_tendency<F_U>(g, u, v, w, nullptr, Gu, range))) return rc;
+    if ((rc = launch_tendency<F_V>(g, u, v, w, nullptr, Gv, range))) return rc;
+    if ((rc = launch_tendency<F_W>(g, u, v, w, nullptr, Gw, range))) return rc;
+    for (int t = 0; t < ntr; ++t)
+        if ((rc = launch_tendency<F_C>(g, u, v, w, tr[t], Gc[t], range))) return rc;
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                                      const double *const *tracers, int ntracers, double *Gu, double *Gv, double *Gw,
+                                      double *const *Gc, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
+        (ntracers > 0 && (!tracers || !Gc)))
+        return fail(OCN_EINVAL, "invalid argument");
+    int rc = compute_tendencies(grid->d, u, v, w, tracers, ntracers, Gu, Gv, Gw, Gc, range, 1);
+    if (rc) return rc;
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RK3 substep, tendency caching
+// ---------------------------------------------------------------------------------------------------------------------
+static int fill_substep_args(const DGrid &g, SubstepArgs &a, double *const *U, const double *const *Gn, const double *const *Gm,
+                             const int (*locs)[3], int n, bool exclude_periphery, int *maxnx, int *maxny, int *maxnz) {
+    if (n < 0 || n > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "nfields out of range");
+    a.n = n;
+    *maxnx = *maxny = *maxnz = 0;
+    for (int f = 0; f < n; ++f) {
+        a.U[f] = U[f]; a.Gn[f] = Gn[f]; a.Gm[f] = Gm ? Gm[f] : nullptr;
+        a.view[f] = make_view(g, nullptr, locs[f]);
+        a.r[f] = default_range(g, locs[f], exclude_periphery);
+        *maxnx = std::max(*maxnx, a.r[f].i1 - a.r[f].i0 + 1);
+        *maxny = std::max(*maxny, a.r[f].j1 - a.r[f].j0 + 1);
+        *maxnz = std::max(*maxnz, a.r[f].k1 - a.r[f].k0 + 1);
+    }
+    return OCN_OK;
+}
+
+static int rk3_substep(const DGrid &g, double *const *U, const double *const *Gn, const double *const *Gm, const int (*locs)[3],
+                       int n, double dt, double gamma, double zeta, bool has_zeta) {
+    SubstepArgs a;
+    int nx, ny, nz;
+    int rc = fill_substep_args(g, a, U, Gn, Gm, locs, n, true, &nx, &ny, &nz);
+    if (rc || n == 0 || nx <= 0 || ny <= 0 || nz <= 0) return rc;
+    hipLaunchKernelGGL(rk3_substep_kernel, grid3(nx, ny, nz * n, BLK), BLK, 0, g_stream, a, dt, gamma, zeta, has_zeta);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_rk3_substep(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm,
+                               const int (*locs)[3], int nfields, double dt, double gamma, double zeta, int has_zeta) {
+    NEED_INIT();
+    if (!grid || !U || !Gn || !locs || (has_zeta && !Gm)) return fail(OCN_EINVAL, "NULL argument");
+    return rk3_substep(grid->d, U, Gn, Gm, locs, nfields, dt, gamma, zeta, has_zeta != 0);
+}
+
+extern "C" int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const double *const *Gn, const int (*locs)[3], int nfields) {
+    NEED_INIT();
+    if (!grid || !Gm || !Gn || !locs) return fail(OCN_EINVAL, "NULL argument");
+    SubstepArgs a;
+    int nx, ny, nz;
+    int rc = fill_substep_args(grid->d, a, Gm, Gn, nullptr, locs, nfields, false, &nx, &ny, &nz);
+    if (rc || nfields == 0) return rc;
+    hipLaunchKernelGGL(cache_tendencies_kernel, grid3(nx, ny, nz * nfields, BLK), BLK, 0, g_stream, a);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pressure source term / correction
+// ---------------------------------------------------------------------------------------------------------------------
+static int source_term(const DGrid &g, const double *u, const double *v, const double *w, double2 *rhs, bool weight) {
+    hipLaunchKernelGGL(source_term_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_source_term(ocn_grid_t grid, const double *u, const double *v, const double *w, double *rhs_complex,
+                                       int weight_by_dz) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
+    return source_term(grid->d, u, v, w, (double2 *)rhs_complex, weight_by_dz != 0);
+}
+
+static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p) {
+    hipLaunchKernelGGL(pressure_correction_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C));
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_make_pressure_correction(ocn_grid_t grid, double *u, double *v, double *w, const double *p) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !p) return fail(OCN_EINVAL, "NULL argument");
+    return pressure_correction(grid->d, u, v, w, p);
+}
+
+static int divide_interior(const DGrid &g, double *p, double divisor) {
+    hipLaunchKernelGGL(divide_interior_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, p, LOC_C), divisor);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
+    NEED_INIT();
+    if (!grid || !p) return fail(OCN_EINVAL, "NULL argument");
+    return divide_interior(grid->d, p, divisor);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Poisson solvers
+// ---------------------------------------------------------------------------------------------------------------------
+struct ocn_poisson_s {
+    ocn_grid_t grid;
+    int kind;
+    size_t n;                   // Nx*Ny*Nz
+    double2 *storage = nullptr; // kind 0: rhs + solution; kind 1: solution
+    double2 *source = nullptr;  // kind 1: rhs
+    double *lam[3] = {nullptr, nullptr, nullptr};
+    double *D = nullptr, *lower = nullptr, *t = nullptr;
+    double2 *partial = nullptr, *mean = nullptr;
+    hipfftHandle plan = 0;
+    bool has_plan = false;
+};
+
+// Solvers/poisson_eigenvalues.jl:8-23
+static void poisson_eigenvalues(int N, double L, int topo, std::vector<double> &lam) {
+    lam.resize(N);
+    for (int i = 1; i <= N; ++i) {
+        double arg = topo == OCN_PERIODIC ? ((double)(i - 1) * M_PI) / (double)N : ((double)(i - 1) * M_PI) / (double)(2 * N);
+        double s = 2.0 * sin(arg) / (L / (double)N);
+        lam[i - 1] = s * s;
+    }
+}
+
+extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
+    if (!s) return OCN_OK;
+    if (s->has_plan) hipfftDestroy(s->plan);
+    hipFree(s->storage); hipFree(s->source); hipFree(s->D); hipFree(s->lower); hipFree(s->t);
+    hipFree(s->partial); hipFree(s->mean);
+    for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
+    delete s;
+    return OCN_OK;
+}
+
+extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int kind) {
+    NEED_INIT();
+    if (!solver || !grid) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = grid->d;
+    if (g.tx != OCN_PERIODIC || g.ty != OCN_PERIODIC)
+        return fail(OCN_ENOTSUP, "Bounded x / y need the DCT transforms (discrete_transforms.jl:108-169): not accelerated yet");
+    if (kind == -1) kind = (g.tz == OCN_BOUNDED) ? 1 : 0;   // see DESIGN.md: z-Bounded always takes the tridiagonal path
+    if (kind == 0 && g.tz != OCN_PERIODIC)
+        return fail(OCN_ENOTSUP, "FFTBasedPoissonSolver with Bounded z needs a DCT: use kind 1 (Fourier-tridiagonal)");
+    if (kind == 0 && !grid->z_regular) return fail(OCN_EINVAL, "FFTBasedPoissonSolver requires a regular grid");
+    if (kind == 1 && g.tz != OCN_BOUNDED)
+        return fail(OCN_EINVAL, "`FourierTridiagonalPoissonSolver` can only be used when the stretched direction's topology is `Bounded`.");
+    if (kind != 0 && kind != 1) return fail(OCN_EINVAL, "unknown solver kind %d", kind);
+    ocn_poisson_s *s = new ocn_poisson_s();
+    s->grid = grid; s->kind = kind;
+    s->n = (size_t)g.Nx * g.Ny * g.Nz;
+    int rc = OCN_OK;
+#define TRY_OR_FREE(expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) { rc = fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); goto bad; }   \
+    } while (0)
+    {
+        TRY_OR_FREE(hipMalloc((void **)&s->storage, s->n * sizeof(double2)));
+        TRY_OR_FREE(hipMemset(s->storage, 0, s->n * sizeof(double2)));
+        const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
+        std::vector<double> lam[3];
+        for (int d = 0; d < 3; ++d) {
+            poisson_eigenvalues(N[d], grid->L[d], T[d], lam[d]);
+            TRY_OR_FREE(hipMalloc((void **)&s->lam[d], N[d] * sizeof(double)));
+            TRY_OR_FREE(hipMemcpy(s->lam[d], lam[d].data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (kind == 0) {
+            hipfftResult r = hipfftPlan3d(&s->plan, g.Nz, g.Ny, g.Nx, HIPFFT_Z2Z);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlan3d failed (%d)", (int)r); goto bad; }
+            s->has_plan = true;
+        } else {
+            // fourier_tridiagonal_poisson_solver.jl:75-134; diagonals :180-210 (HomogeneousZFormulation), host-built
+            TRY_OR_FREE(hipMalloc((void **)&s->source, s->n * sizeof(double2)));
+            TRY_OR_FREE(hipMemset(s->source, 0, s->n * sizeof(double2)));
+            TRY_OR_FREE(hipMalloc((void **)&s->D, s->n * sizeof(double)));
+            TRY_OR_FREE(hipMalloc((void **)&s->t, s->n * sizeof(double)));
+            TRY_OR_FREE(hipMemset(s->t, 0, s->n * sizeof(double)));
+            TRY_OR_FREE(hipMalloc((void **)&s->lower, std::max(1, g.Nz - 1) * sizeof(double)));
+            TRY_OR_FREE(hipMalloc((void **)&s->partial, 1024 * sizeof(double2)));
+            TRY_OR_FREE(hipMalloc((void **)&s->mean, sizeof(double2)));
+            const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, Hz = g.Hz;
+            auto dzf = [&](int k) { return grid->h_dzf[k - 1 + Hz]; };
+            auto dzc = [&](int k) { return grid->h_dzc[k - 1 + Hz]; };
+            std::vector<double> D(s->n), lower(std::max(1, Nz - 1));
+            for (int j = 0; j < Ny; ++j)
+                for (int i = 0; i < Nx; ++i) {
+                    double lxy = lam[0][i] + lam[1][j];
+                    auto at = [&](int k) -> double & { return D[(size_t)i + (size_t)Nx * (j + (size_t)Ny * (k - 1))]; };
+                    at(1) = -1.0 / dzf(2) - dzc(1) * lxy;
+                    at(Nz) = -1.0 / dzf(Nz) - dzc(Nz) * lxy;
+                    for (int k = 2; k <= Nz - 1; ++k) at(k) = -(1.0 / dzf(k + 1) + 1.0 / dzf(k)) - dzc(k) * lxy;
+                }
+            for (int q = 1; q <= Nz - 1; ++q) lower[q - 1] = 1.0 / dzf(q + 1);
+            TRY_OR_FREE(hipMemcpy(s->D, D.data(), s->n * sizeof(double), hipMemcpyHostToDevice));
+            TRY_OR_FREE(hipMemcpy(s->lower, lower.data(), lower.size() * sizeof(double), hipMemcpyHostToDevice));
+            int nfft[2] = {g.Ny, g.Nx};
+            hipfftResult r = hipfftPlanMany(&s->plan, 2, nfft, nullptr, 1, g.Nx * g.Ny, nullptr, 1, g.Nx * g.Ny, HIPFFT_Z2Z, g.Nz);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany failed (%d)", (int)r); goto bad; }
+            s->has_plan = true;
+        }
+        hipfftResult r = hipfftSetStream(s->plan, g_stream);
+        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r); goto bad; }
+    }
+    *solver = s;
+    return OCN_OK;
+bad:
+    ocn_poisson_destroy(s);
+    return rc;
+#undef TRY_OR_FREE
+}
+
+extern "C" int ocn_poisson_kind(ocn_poisson_t s) { return s ? s->kind : OCN_EINVAL; }
+
+extern "C" int ocn_poisson_rhs(ocn_poisson_t s, double **rhs_complex) {
+    if (!s || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
+    *rhs_complex = (double *)(s->kind == 0 ? s->storage : s->source);
+    return OCN_OK;
+}
+
+static int poisson_solve(ocn_poisson_s *s, double *phi) {
+    const DGrid &g = s->grid->d;
+    FView vphi = make_view(g, phi, LOC_C);
+    if (s->kind == 0) {
+        // fft_based_poisson_solver.jl:95-125
+        FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(spectral_divide_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->storage, s->lam[0],
+                           s->lam[1], s->lam[2], g.Nx, g.Ny, g.Nz);
+        FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_BACKWARD));
+        const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
+        hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vphi, s->storage, scale, true,
+                           (const double2 *)nullptr);
+    } else {
+        // fourier_tridiagonal_poisson_solver.jl:212-239
+        FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->source, (hipfftDoubleComplex *)s->source, HIPFFT_FORWARD));
+        hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, g_stream, g.Nx, g.Ny, g.Nz, s->lower,
+                           s->D, s->lower, s->source, s->t, s->storage);
+        FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_BACKWARD));
+        const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
+        const int nb = 1024;
+        hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, g_stream, s->storage, (long)s->n, s->partial);
+        hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, g_stream, s->partial, nb, 1.0 / (double)s->n, scale, s->mean);
+        hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vphi, s->storage, scale, true,
+                           (const double2 *)s->mean);
+        // the reference keeps the (normalised, mean-free) solution in `storage` between solves; the guarded update of the
+        // singular column re-reads it (batched_tridiagonal_solver.jl:234-237). The read value only shifts the solution
+        // by a constant that the mean removal deletes, so `storage` keeps the unnormalised field here.
+    }
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *phi) {
+    NEED_INIT();
+    if (!s || !phi) return fail(OCN_EINVAL, "NULL argument");
+    return poisson_solve(s, phi);
+}
+
+extern "C" int ocn_solve_for_pressure(ocn_poisson_t s, const double *u, const double *v, const double *w, double *p) {
+    NEED_INIT();
+    if (!s || !u || !v || !w || !p) return fail(OCN_EINVAL, "NULL argument");
+    int rc = source_term(s->grid->d, u, v, w, s->kind == 0 ? s->storage : s->source, s->kind == 1);
+    if (rc) return rc;
+    return poisson_solve(s, p);
+}
+
+extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c,
+                                               const double *f_complex, double *t, double *phi_complex) {
+    NEED_INIT();
+    if (Nx < 1 || Ny < 1 || Nz < 1 || !a || !b || !c || !f_complex || !t || !phi_complex) return fail(OCN_EINVAL, "invalid argument");
+    hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, g_stream, Nx, Ny, Nz, a, b, c,
+                       (const double2 *)f_complex, t, (double2 *)phi_complex);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------------------------------------------------
+struct ocn_model_s {
+    ocn_grid_t grid;
+    int ntr, nf;
+    double *U[OCN_MAX_FIELDS], *Gn[OCN_MAX_FIELDS], *Gm[OCN_MAX_FIELDS];
+    int loc[OCN_MAX_FIELDS][3];
+    double *p;
+    ocn_poisson_t solver;
+    double *blockmax;
+    // Clock (TimeSteppers/clock.jl:39-45)
+    double time = 0, last_dt = INFINITY, last_stage_dt = INFINITY;
+    int64_t iteration = 0;
+    int stage = 1;
+    int tendency_impl = 1;
+    int swap_tendencies = 1;
+};
+
+extern "C" int ocn_model_destroy(ocn_model_t m) {
+    if (!m) return OCN_OK;
+    for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
+    hipFree(m->p); hipFree(m->blockmax);
+    ocn_poisson_destroy(m->solver);
+    delete m;
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
+    NEED_INIT();
+    if (!model || !grid) return fail(OCN_EINVAL, "NULL argument");
+    if (ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3) return fail(OCN_EINVAL, "ntracers must be in 0..%d", OCN_MAX_FIELDS - 3);
+    ocn_model_s *m = new ocn_model_s();
+    m->grid = grid; m->ntr = ntracers; m->nf = 3 + ntracers;
+    for (int f = 0; f < OCN_MAX_FIELDS; ++f) m->U[f] = m->Gn[f] = m->Gm[f] = nullptr;
+    m->p = nullptr; m->solver = nullptr; m->blockmax = nullptr;
+    const int *locs[3] = {LOC_U, LOC_V, LOC_W};
+    int rc = OCN_OK;
+    auto alloc = [&](double **p, const int loc[3]) -> int {
+        int P[3];
+        parent_size(grid->d, loc, P);
+        size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
+        hipError_t e = hipMalloc((void **)p, bytes);
+        if (e != hipSuccess) return fail((int)e, "hipMalloc(field): %s", hipGetErrorString(e));
+        e = hipMemsetAsync(*p, 0, bytes, g_stream);
+        if (e != hipSuccess) return fail((int)e, "hipMemset(field): %s", hipGetErrorString(e));
+        return OCN_OK;
+    };
+    for (int f = 0; f < m->nf && !rc; ++f) {
+        const int *l = f < 3 ? locs[f] : LOC_C;
+        memcpy(m->loc[f], l, sizeof(int) * 3);
+        if (!rc) rc = alloc(&m->U[f], l);
+        if (!rc) rc = alloc(&m->Gn[f], l);
+        if (!rc) rc = alloc(&m->Gm[f], l);
+    }
+    if (!rc) rc = alloc(&m->p, LOC_C);
+    if (!rc) {
+        hipError_t e = hipMalloc((void **)&m->blockmax, 1024 * sizeof(double));
+        if (e != hipSuccess) rc = fail((int)e, "hipMalloc: %s", hipGetErrorString(e));
+    }
+    if (!rc) rc = ocn_poisson_create(&m->solver, grid, -1);
+    if (rc) { ocn_model_destroy(m); return rc; }
+    *model = m;
+    return OCN_OK;
+}
+
+static int field_lookup(ocn_model_s *m, const char *name, double ***slot, int **loc) {
+    const char *q = name;
+    char kind = 'U';
+    if (!strcmp(name, "p")) { *slot = &m->p; *loc = const_cast<int *>(LOC_C); return OCN_OK; }
+    if (q[0] == 'G' || q[0] == 'M') { kind = q[0]; ++q; }
+    int f = -1;
+    if (!strcmp(q, "u")) f = 0;
+    else if (!strcmp(q, "v")) f = 1;
+    else if (!strcmp(q, "w")) f = 2;
+    else if (q[0] == 'c' && q[1] >= '0' && q[1] <= '9' && !q[2] && (q[1] - '0') < m->ntr) f = 3 + (q[1] - '0');
+    if (f < 0) return fail(OCN_EINVAL, "name %s not found in model.velocities or model.tracers.", name);
+    *slot = kind == 'U' ? &m->U[f] : (kind == 'G' ? &m->Gn[f] : &m->Gm[f]);
+    *loc = m->loc[f];
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_field(ocn_model_t m, const char *name, double **ptr, int loc[3]) {
+    if (!m || !name || !ptr) return fail(OCN_EINVAL, "NULL argument");
+    double **slot;
+    int *l;
+    int rc = field_lookup(m, name, &slot, &l);
+    if (rc) return rc;
+    *ptr = *slot;
+    if (loc) memcpy(loc, l, sizeof(int) * 3);
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
+    if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
+    if (!strcmp(key, "tendency_impl")) { m->tendency_impl = value; return OCN_OK; }
+    if (!strcmp(key, "swap_tendencies")) { m->swap_tendencies = value; return OCN_OK; }
+    return fail(OCN_EINVAL, "unknown option %s", key);
+}
+
+// update_state! (update_nonhydrostatic_model_state.jl:20-56), closure / buoyancy / forcing = nothing
+static int update_state(ocn_model_s *m, bool compute_tend) {
+    const DGrid &g = m->grid->d;
+    int rc = fill_halo_regions(g, m->U, m->loc, m->nf, /*fill_open_bcs=*/false);
+    if (rc) return rc;
+    if (compute_tend)
+        rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
+                                m->tendency_impl);
+    return rc;
+}
+
+// compute_pressure_correction! (pressure_correction.jl:8-20)
+static int compute_pressure_correction(ocn_model_s *m) {
+    const DGrid &g = m->grid->d;
+    int rc = fill_halo_regions(g, m->U, m->loc, 3, true);
+    if (rc) return rc;
+    ocn_poisson_s *s = m->solver;
+    if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], s->kind == 0 ? s->storage : s->source, s->kind == 1))) return rc;
+    if ((rc = poisson_solve(s, m->p))) return rc;
+    double *pp[1] = {m->p};
+    const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
+    return fill_halo_regions(g, pp, pl, 1, true);
+}
+
+// make_pressure_correction! (pressure_correction.jl:40-53)
+static int make_pressure_correction(ocn_model_s *m, double dt) {
+    const DGrid &g = m->grid->d;
+    int rc = pressure_correction(g, m->U[0], m->U[1], m->U[2], m->p);
+    if (rc) return rc;
+    double dtp = std::fmax(2.220446049250313e-16, dt);
+    return divide_interior(g, m->p, dtp);
+}
+
+extern "C" int ocn_model_update_state(ocn_model_t m, int compute_tendencies_flag) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    return update_state(m, compute_tendencies_flag != 0);
+}
+
+extern "C" int ocn_model_set_finalize(ocn_model_t m, int enforce_incompressibility) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = m->grid->d;
+    int rc = fill_halo_regions(g, m->U, m->loc, m->nf, true);     // set!(ϕ, value); fill_halo_regions!(ϕ) per field
+    if (rc) return rc;
+    if ((rc = update_state(m, false))) return rc;
+    if (enforce_incompressibility) {
+        if ((rc = compute_pressure_correction(m))) return rc;
+        if ((rc = make_pressure_correction(m, 1.0))) return rc;
+        if ((rc = update_state(m, false))) return rc;
+    }
+    return OCN_OK;
+}
+
+static void tick(ocn_model_s *m, double dt, bool stage) {       // clock.jl:128-143
+    m->time += dt;
+    if (stage) { m->stage += 1; m->last_stage_dt = dt; }
+    else { m->iteration += 1; m->stage = 1; m->last_dt = dt; m->last_stage_dt = dt; }
+}
+
+// cache_previous_tendencies! (store_tendencies.jl:12-22). G⁻ <- Gⁿ followed by a full recomputation of Gⁿ is a
+// pointer swap on this architecture: cells the tendency kernels never write (halos, excluded periphery) are zero in
+// both buffers for the model's lifetime.
+static int cache_previous_tendencies(ocn_model_s *m) {
+    if (m->swap_tendencies) {
+        for (int f = 0; f < m->nf; ++f) std::swap(m->Gn[f], m->Gm[f]);
+        return OCN_OK;
+    }
+    SubstepArgs a;
+    int nx, ny, nz;
+    int rc = fill_substep_args(m->grid->d, a, m->Gm, m->Gn, nullptr, m->loc, m->nf, false, &nx, &ny, &nz);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cache_tendencies_kernel, grid3(nx, ny, nz * m->nf, BLK), BLK, 0, g_stream, a);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// time_step!(model::AbstractModel{<:RungeKutta3TimeStepper}, Δt) (TimeSteppers/runge_kutta_3.jl:93-170)
+extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = m->grid->d;
+    int rc;
+    if (m->iteration == 0 && (rc = update_state(m, true))) return rc;
+    const double g1 = OCN_RK3_G1, g2 = OCN_RK3_G2, g3 = OCN_RK3_G3, z2 = OCN_RK3_Z2, z3 = OCN_RK3_Z3;
+    const double dt1 = dt * g1, dt2 = dt * (g2 + z2), dt3 = dt * (g3 + z3);
+    const double tn1 = m->time + dt;
+    const double gam[3] = {g1, g2, g3}, zet[3] = {0.0, z2, z3}, sdt[3] = {dt1, dt2, dt3};
+    for (int stage = 0; stage < 3; ++stage) {
+        // compute_flux_bc_tendencies!: no value-carrying Flux BCs in scope (compute_flux_bcs.jl:24-28)
+        if ((rc = rk3_substep(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, gam[stage], zet[stage], stage > 0))) return rc;
+        if (stage < 2) tick(m, sdt[stage], true);
+        else {
+            double corrected = tn1 - m->time;
+            tick(m, dt3, false);
+            m->last_stage_dt = corrected;
+            m->last_dt = dt;
+        }
+        if ((rc = compute_pressure_correction(m))) return rc;
+        if ((rc = make_pressure_correction(m, sdt[stage]))) return rc;
+        if (stage < 2 && (rc = cache_previous_tendencies(m))) return rc;
+        if ((rc = update_state(m, true))) return rc;
+    }
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_clock(ocn_model_t m, double *time, int64_t *iteration, int *stage, double *last_dt, double *last_stage_dt) {
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    if (time) *time = m->time;
+    if (iteration) *iteration = m->iteration;
+    if (stage) *stage = m->stage;
+    if (last_dt) *last_dt = m->last_dt;
+    if (last_stage_dt) *last_stage_dt = m->last_stage_dt;
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_max_abs_divergence(ocn_model_t m, double *value) {
+    NEED_INIT();
+    if (!m || !value) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = m->grid->d;
+    const int nb = 1024;
+    hipLaunchKernelGGL(max_abs_div_kernel, dim3(nb), dim3(256), 0, g_stream, g, make_view(g, m->U[0], LOC_U),
+                       make_view(g, m->U[1], LOC_V), make_view(g, m->U[2], LOC_W), m->blockmax);
+    KERNEL_CHECK();
+    std::vector<double> h(nb);
+    HIP_TRY(hipMemcpyAsync(h.data(), m->blockmax, nb * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    double mx = 0;
+    for (double x : h) mx = std::max(mx, x);
+    *value = mx;
+    return OCN_OK;
+}

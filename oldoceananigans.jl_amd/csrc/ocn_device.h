@@ -1,0 +1,135 @@
+// ocn_device.h -- device-side building blocks of the MI355X (gfx950) NonhydrostaticModel hot path.
+//
+// Arithmetic contract (DESIGN.md "numerics"): this translation unit is compiled with -ffp-contract=off; a fused
+// multiply-add is emitted only where the reference writes `@muladd` (src/Advection/weno_interpolants.jl:261,500,
+// centered_reconstruction.jl:47-53) or `fma` (src/Utils/newton_div.jl:18) -- through __builtin_fma. Everything else is
+// separate IEEE mul/add, so results are bit-comparable with the CPU oracle.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/ocn_weno_coeffs.h"
+
+#define OCN_MAX_FIELDS 11   // u, v, w + 8 tracers
+
+// Device view of a RectilinearGrid (reference: src/Grids/rectilinear_grid.jl:3-25) with the metric products of
+// src/Operators/spacings_and_areas_and_volumes.jl precomputed per k (x, y regular): all tables are indexed [k-1+Hz],
+// k = 1-Hz .. Nz+Hz+1.
+struct DGrid {
+    int Nx, Ny, Nz, Hx, Hy, Hz;
+    int tx, ty, tz;            // 0 periodic, 1 bounded
+    double dx, dy;             // Δxᶜ = Δxᶠ, Δyᶜ = Δyᶠ
+    double az;                 // Azᶜᶜᶠ = Δx Δy
+    double rdx, rdy;           // 1/Δxᶠ, 1/Δyᶠ
+    const double *dzc, *dzf;   // Δzᵃᵃᶜ, Δzᵃᵃᶠ
+    const double *ax;          // Axᶠᶜᶜ = Δy Δzᶜ
+    const double *ay;          // Ayᶜᶠᶜ = Δx Δzᶜ
+    const double *vinv_c;      // 1 / ((Δx Δy) Δzᶜ)   = V⁻¹ᶜᶜᶜ = V⁻¹ᶠᶜᶜ = V⁻¹ᶜᶠᶜ
+    const double *vinv_f;      // 1 / ((Δx Δy) Δzᶠ)   = V⁻¹ᶜᶜᶠ
+    const double *rdzf;        // 1 / Δzᶠ
+};
+
+// A haloed field addressed with the reference's 1-based (i, j, k): p[off + i + s1*j + s2*k]
+struct FView {
+    double *p;
+    int s1;
+    long s2;
+    long off;
+    __device__ __forceinline__ double &at(int i, int j, int k) const { return p[off + i + (long)s1 * j + s2 * k]; }
+    __device__ __forceinline__ long lin(int i, int j, int k) const { return off + i + (long)s1 * j + s2 * k; }
+    template <int D> __device__ __forceinline__ long stride() const { return D == 0 ? 1L : (D == 1 ? (long)s1 : s2); }
+};
+
+struct Range6 { int i0, i1, j0, j1, k0, k1; };
+
+// ---------------------------------------------------------------------------------------------------------------------
+// WENO(order = 5) reconstruction -- src/Advection/weno_interpolants.jl
+// ---------------------------------------------------------------------------------------------------------------------
+// newton_div(Float32, a, b): src/Utils/newton_div.jl:8-20. The Float32 reciprocal must be the correctly rounded IEEE
+// quotient (the CPU reference evaluates `inv_fast` as a true divide); compiled with
+// -fhip-fp32-correctly-rounded-divide-sqrt so `1.0f / x` is exact, not v_rcp_f32.
+__device__ __forceinline__ double newton_div_f32(double a, double b) {
+    float b_low = (float)b;
+    float inv_b = 1.0f / b_low;
+    double inv_d = (double)inv_b;
+    double x = a * inv_d;
+    return __builtin_fma(__builtin_fma(x, -b, a), inv_d, x);
+}
+
+// smoothness_operation (buffer 3) under @muladd, weno_interpolants.jl:204-216,261
+__device__ __forceinline__ double beta3(double p0, double p1, double p2, double C1, double C2, double C3, double C4,
+                                        double C5, double C6) {
+    double in1 = __builtin_fma(C3, p2, __builtin_fma(C2, p1, C1 * p0));
+    double in2 = __builtin_fma(C5, p2, C4 * p1);
+    return __builtin_fma(p2 * p2, C6, __builtin_fma(p1, in2, p0 * in1));
+}
+__device__ __forceinline__ double beta2(double p0, double p1, double C1, double C2, double C3) {
+    double in1 = __builtin_fma(C2, p1, C1 * p0);
+    return __builtin_fma(p1 * p1, C3, p0 * in1);
+}
+
+// biased_interpolate for WENO{3} (weno_interpolants.jl:504-516); s0..s5 = psi[f-3 .. f+2]
+__device__ __forceinline__ double weno5_biased(double s0, double s1, double s2, double s3, double s4, double s5, bool left) {
+    // S₀₃, S₁₃, S₂₃ (:435-437): the right-biased stencils are the mirrored left-biased ones
+    double a0 = left ? s2 : s3, a1 = left ? s3 : s2, a2 = left ? s4 : s1;   // stencil 0
+    double b0 = left ? s1 : s4, b1 = a0,             b2 = a1;               // stencil 1 = (s1,s2,s3) | (s4,s3,s2)
+    double c0 = left ? s0 : s5, c1 = b0,             c2 = a0;               // stencil 2 = (s0,s1,s2) | (s5,s4,s3)
+    double be0 = beta3(a0, a1, a2, 10, -31, 11, 25, -19, 4);
+    double be1 = beta3(b0, b1, b2, 4, -13, 5, 13, -13, 4);
+    double be2 = beta3(c0, c1, c2, 4, -19, 11, 25, -31, 10);
+    double tau = fabs(be0 - be2);
+    double r0 = newton_div_f32(tau, be0 + OCN_WENO_EPS);
+    double r1 = newton_div_f32(tau, be1 + OCN_WENO_EPS);
+    double r2 = newton_div_f32(tau, be2 + OCN_WENO_EPS);
+    double al0 = OCN_W3C0 * (1.0 + r0 * r0);
+    double al1 = OCN_W3C1 * (1.0 + r1 * r1);
+    double al2 = OCN_W3C2 * (1.0 + r2 * r2);
+    double sinv = 1.0 / ((al0 + al1) + al2);
+    double w0 = al0 * sinv, w1 = al1 * sinv, w2 = al2 * sinv;
+    double q0 = (OCN_W3P00 * a0 + OCN_W3P01 * a1) + OCN_W3P02 * a2;
+    double q1 = (OCN_W3P10 * b0 + OCN_W3P11 * b1) + OCN_W3P12 * b2;
+    double q2 = (OCN_W3P20 * c0 + OCN_W3P21 * c1) + OCN_W3P22 * c2;
+    return __builtin_fma(w2, q2, __builtin_fma(w1, q1, w0 * q0));
+}
+
+// WENO{2} (buffer scheme); s0..s3 = psi[f-2 .. f+1]
+__device__ __forceinline__ double weno3_biased(double s0, double s1, double s2, double s3, bool left) {
+    double a0 = left ? s1 : s2, a1 = left ? s2 : s1;
+    double b0 = left ? s0 : s3, b1 = a0;
+    double be0 = beta2(a0, a1, 1, -2, 1);
+    double be1 = beta2(b0, b1, 1, -2, 1);
+    double tau = fabs(be0 - be1);
+    double r0 = newton_div_f32(tau, be0 + OCN_WENO_EPS);
+    double r1 = newton_div_f32(tau, be1 + OCN_WENO_EPS);
+    double al0 = OCN_W2C0 * (1.0 + r0 * r0);
+    double al1 = OCN_W2C1 * (1.0 + r1 * r1);
+    double sinv = 1.0 / (al0 + al1);
+    double w0 = al0 * sinv, w1 = al1 * sinv;
+    double q0 = OCN_W2P00 * a0 + OCN_W2P01 * a1;
+    double q1 = OCN_W2P10 * b0 + OCN_W2P11 * b1;
+    return __builtin_fma(w1, q1, w0 * q0);
+}
+
+// topologically_conditional_interpolation.jl:46-52 (Bounded). `i` = index the _interpolate function is called with.
+__device__ __forceinline__ bool outside_symmetric_halo(int i, bool center, int N, int R) {
+    return center ? ((i >= R) & (i <= N + 1 - R)) : ((i >= R + 1) & (i <= N + 1 - R));
+}
+__device__ __forceinline__ bool outside_biased_halo(int i, bool center, int N, int R) {
+    return center ? ((i >= R) & (i <= N + 1 - (R - 1)) & (i >= R - 1) & (i <= N + 1 - R))
+                  : ((i >= R + 1) & (i <= N + 1 - (R - 1)) & (i >= R) & (i <= N + 1 - R));
+}
+
+// _symmetric_interpolate (scheme WENO{3} -> Centered{2}; near walls -> Centered{1}); q0..q3 = q[f-2 .. f+1]
+__device__ __forceinline__ double symmetric_interp(double q0, double q1, double q2, double q3, bool bounded, int i,
+                                                   bool center, int N) {
+    bool order4 = !bounded || outside_symmetric_halo(i, center, N, 3);
+    double hi = __builtin_fma(OCN_C4_1, q3, __builtin_fma(OCN_C4_2, q2, __builtin_fma(OCN_C4_3, q1, OCN_C4_4 * q0)));
+    if (order4) return hi;
+    return __builtin_fma(OCN_C2_1, q2, OCN_C2_2 * q1);
+}
+
+// _biased_interpolate (WENO{3} -> WENO{2} -> UpwindBiased{1}); s0..s5 = psi[f-3 .. f+2]
+__device__ __forceinline__ double biased_interp(double s0, double s1, double s2, double s3, double s4, double s5,
+                                                bool left, bool bounded, int i, bool center, int N) {
+    if (!bounded || outside_biased_halo(i, center, N, 3)) return weno5_biased(s0, s1, s2, s3, s4, s5, left);
+    if (outside_biased_halo(i, center, N, 2)) return weno3_biased(s1, s2, s3, s4, left);
+    return left ? 1.0 * s2 : 1.0 * s3;
+}

@@ -1,0 +1,344 @@
+// ocn_kernels.h -- HIP kernels of the hot path (reference kernel inventory: SURVEY.md 2.1). gfx950 / wave64.
+#pragma once
+#include "ocn_device.h"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// advective fluxes (src/Advection/upwind_biased_advective_fluxes.jl:23-121), evaluated straight from global memory.
+// This is the "as launched by the reference" formulation (each face flux evaluated by both adjacent cells); the fused
+// flux-sharing kernel lives in ocn_tendency_fused.h.
+// ---------------------------------------------------------------------------------------------------------------------
+enum { AQ_U = 0, AQ_V = 1, AQ_W = 2 };
+
+// area-weighted transports  Ax_qᶠᶜᶜ(u), Ay_qᶜᶠᶜ(v), Az_qᶜᶜᶠ(w)  (Operators/products_between_fields_and_grid_metrics.jl:5-14)
+template <int AQ> __device__ __forceinline__ double area_q(const DGrid &g, const FView &f, int i, int j, int k) {
+    double a = AQ == AQ_U ? g.ax[k - 1 + g.Hz] : (AQ == AQ_V ? g.ay[k - 1 + g.Hz] : g.az);
+    return a * f.at(i, j, k);
+}
+
+// symmetric interpolation of a transport along D; CEN: ᶜ variant (stencil of face idx+1)
+template <int AQ, int D, bool CEN>
+__device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, int i, int j, int k) {
+    const int idx = D == 0 ? i : (D == 1 ? j : k);
+    const int o = CEN ? 1 : 0;
+    double q[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        int m = o - 2 + n;
+        q[n] = D == 0 ? area_q<AQ>(g, f, i + m, j, k) : (D == 1 ? area_q<AQ>(g, f, i, j + m, k) : area_q<AQ>(g, f, i, j, k + m));
+    }
+    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) != 0;
+    const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
+    return symmetric_interp(q[0], q[1], q[2], q[3], bounded, idx, CEN, N);
+}
+
+template <int D, bool CEN>
+__device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, bool left, int i, int j, int k) {
+    const int idx = D == 0 ? i : (D == 1 ? j : k);
+    const int o = CEN ? 1 : 0;
+    const long st = c.stride<D>();
+    const double *p = c.p + c.lin(i, j, k) + (o - 3) * st;
+    double s0 = p[0], s1 = p[st], s2 = p[2 * st], s3 = p[3 * st], s4 = p[4 * st], s5 = p[5 * st];
+    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) != 0;
+    const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
+    return biased_interp(s0, s1, s2, s3, s4, s5, left, bounded, idx, CEN, N);
+}
+
+// advective_momentum_flux_{U,V,W}{u,v,w}: transport AQ interpolated along DS (CS), advected field reconstructed along
+// DB (CB).
+template <int AQ, int DS, bool CS, int DB, bool CB>
+__device__ __forceinline__ double mom_flux(const DGrid &g, const FView &adv, const FView &psi, int i, int j, int k) {
+    double ut = sym_transport<AQ, DS, CS>(g, adv, i, j, k);
+    double pr = biased_field<DB, CB>(g, psi, ut > 0, i, j, k);
+    return ut * pr;
+}
+
+// advective_tracer_flux_{x,y,z} (:99-121): A * U[i,j,k] * cR
+template <int D> __device__ __forceinline__ double tracer_flux(const DGrid &g, const FView &vel, const FView &c, int i, int j, int k) {
+    double ut = vel.at(i, j, k);
+    double cr = biased_field<D, false>(g, c, ut > 0, i, j, k);
+    double a = D == 0 ? g.ax[k - 1 + g.Hz] : (D == 1 ? g.ay[k - 1 + g.Hz] : g.az);
+    return a * ut * cr;
+}
+
+enum { F_U = 0, F_V = 1, F_W = 2, F_C = 3 };
+
+// compute_Gu!/Gv!/Gw!/Gc! (Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:138-163) with
+// div_𝐯u/v/w (Advection/momentum_advection_operators.jl:46-83) and div_Uc (tracer_advection_operators.jl:29-33).
+template <int F>
+__global__ void __launch_bounds__(256) tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, Range6 r) {
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    double dx, dy, dz, vinv;
+    if (F == F_U) {
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        dx = mom_flux<AQ_U, 0, true, 0, true>(g, u, u, i, j, k) - mom_flux<AQ_U, 0, true, 0, true>(g, u, u, i - 1, j, k);
+        dy = mom_flux<AQ_V, 0, false, 1, false>(g, v, u, i, j + 1, k) - mom_flux<AQ_V, 0, false, 1, false>(g, v, u, i, j, k);
+        dz = mom_flux<AQ_W, 0, false, 2, false>(g, w, u, i, j, k + 1) - mom_flux<AQ_W, 0, false, 2, false>(g, w, u, i, j, k);
+    } else if (F == F_V) {
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        dx = mom_flux<AQ_U, 1, false, 0, false>(g, u, v, i + 1, j, k) - mom_flux<AQ_U, 1, false, 0, false>(g, u, v, i, j, k);
+        dy = mom_flux<AQ_V, 1, true, 1, true>(g, v, v, i, j, k) - mom_flux<AQ_V, 1, true, 1, true>(g, v, v, i, j - 1, k);
+        dz = mom_flux<AQ_W, 1, false, 2, false>(g, w, v, i, j, k + 1) - mom_flux<AQ_W, 1, false, 2, false>(g, w, v, i, j, k);
+    } else if (F == F_W) {
+        vinv = g.vinv_f[k - 1 + g.Hz];
+        dx = mom_flux<AQ_U, 2, false, 0, false>(g, u, w, i + 1, j, k) - mom_flux<AQ_U, 2, false, 0, false>(g, u, w, i, j, k);
+        dy = mom_flux<AQ_V, 2, false, 1, false>(g, v, w, i, j + 1, k) - mom_flux<AQ_V, 2, false, 1, false>(g, v, w, i, j, k);
+        dz = mom_flux<AQ_W, 2, true, 2, true>(g, w, w, i, j, k) - mom_flux<AQ_W, 2, true, 2, true>(g, w, w, i, j, k - 1);
+    } else {
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        dx = tracer_flux<0>(g, u, c, i + 1, j, k) - tracer_flux<0>(g, u, c, i, j, k);
+        dy = tracer_flux<1>(g, v, c, i, j + 1, k) - tracer_flux<1>(g, v, c, i, j, k);
+        dz = tracer_flux<2>(g, w, c, i, j, k + 1) - tracer_flux<2>(g, w, c, i, j, k);
+    }
+    double div = vinv * ((dx + dy) + dz);
+    G.at(i, j, k) = -div + 0.0;   // `-div - 0 + 0 ...` of the tendency functions: only maps -0.0 to +0.0
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// halo fills (src/BoundaryConditions). One launch handles up to OCN_MAX_FIELDS fields of identical parent shape.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FieldList {
+    double *p[OCN_MAX_FIELDS];
+    int n;
+};
+
+// _fill_periodic_*_halo! (fill_halo_regions_periodic.jl:5-33) along dimension D of parent arrays of shape (P0,P1,P2):
+// parent[i] = parent[N+i], parent[N+H+i] = parent[H+i] for i = 1..H, over the whole extent of the two other dims.
+template <int D>
+__global__ void __launch_bounds__(256) fill_periodic_kernel(FieldList fl, int P0, int P1, int P2, int N, int H) {
+    // thread -> (h, a, b): h in [0, 2H) fastest when D == 0 so that accesses stay contiguous in x
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Pa = D == 0 ? P1 : P0;            // first remaining dim
+    const int Pb = D == 2 ? P1 : P2;            // second remaining dim
+    long total = (long)2 * H * Pa * Pb;
+    if (t >= total) return;
+    int h, a, b;
+    if (D == 0) { h = t % (2 * H); long r = t / (2 * H); a = r % Pa; b = r / Pa; }
+    else        { a = t % Pa; long r = t / Pa; if (D == 1) { h = r % (2 * H); b = r / (2 * H); } else { b = r % Pb; h = r / Pb; } }
+    int dst = h < H ? h : N + h;                // 0-based parent index: west i-1 (i=1..H) | east N+H+i-1
+    int src = h < H ? N + h : h;                //                       N+i-1            | H+i-1  (h-H+H)
+    long s0 = 1, s1 = P0, s2 = (long)P0 * P1;
+    long od, os;
+    if (D == 0) { od = dst * s0 + a * s1 + b * s2; os = src * s0 + a * s1 + b * s2; }
+    else if (D == 1) { od = a * s0 + dst * s1 + b * s2; os = a * s0 + src * s1 + b * s2; }
+    else { od = a * s0 + b * s1 + dst * s2; os = a * s0 + b * s1 + src * s2; }
+    for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
+}
+
+// Bounded directions: _fill_flux_*_halo! (fill_halo_regions_flux.jl:9-27) one-cell mirror for Center fields,
+// open/impenetrable wall value (fill_halo_regions_open.jl:2-7) for Face fields. Launched over the INTERIOR extent
+// (grid N) of the two other dims.
+template <int D>
+__global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, FView view, int Na, int Nb, int N, bool face,
+                                                           bool fill_open) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)Na * Nb) return;
+    int a = 1 + t % Na, b = 1 + t / Na;
+    long lo, ilo, hi, ihi;
+    if (D == 0) { lo = view.lin(face ? 1 : 0, a, b); ilo = view.lin(1, a, b); hi = view.lin(N + 1, a, b); ihi = view.lin(N, a, b); }
+    else if (D == 1) { lo = view.lin(a, face ? 1 : 0, b); ilo = view.lin(a, 1, b); hi = view.lin(a, N + 1, b); ihi = view.lin(a, N, b); }
+    else { lo = view.lin(a, b, face ? 1 : 0); ilo = view.lin(a, b, 1); hi = view.lin(a, b, N + 1); ihi = view.lin(a, b, N); }
+    for (int f = 0; f < fl.n; ++f) {
+        double *p = fl.p[f];
+        if (!face) { p[lo] = p[ilo]; p[hi] = p[ihi]; }
+        else if (fill_open) { p[lo] = 0.0; p[hi] = 0.0; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RK3 substep / tendency caching (src/TimeSteppers/runge_kutta_3.jl:212-226, store_tendencies.jl:6-9)
+// ---------------------------------------------------------------------------------------------------------------------
+struct SubstepArgs {
+    double *U[OCN_MAX_FIELDS];
+    const double *Gn[OCN_MAX_FIELDS];
+    const double *Gm[OCN_MAX_FIELDS];
+    FView view[OCN_MAX_FIELDS];     // .p unused
+    Range6 r[OCN_MAX_FIELDS];
+    int n;
+};
+
+__global__ void __launch_bounds__(256) rk3_substep_kernel(SubstepArgs a, double dt, double gamma, double zeta, bool has_zeta) {
+    const int f = blockIdx.z % a.n;
+    const Range6 r = a.r[f];
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z / a.n;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const long q = a.view[f].lin(i, j, k);
+    double Uv = a.U[f][q];
+    if (has_zeta) Uv += dt * (gamma * a.Gn[f][q] + zeta * a.Gm[f][q]);
+    else          Uv += dt * gamma * a.Gn[f][q];
+    a.U[f][q] = Uv;
+}
+
+__global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
+    const int f = blockIdx.z % a.n;
+    const Range6 r = a.r[f];
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z / a.n;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const long q = a.view[f].lin(i, j, k);
+    a.U[f][q] = a.Gn[f][q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pressure: source term, correction, scaling (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, double2 *rhs, bool weight_by_dz) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const int kk = k - 1 + g.Hz;
+    const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
+    double dx = ax * u.at(i + 1, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
+    double dy = ay * v.at(i, j + 1, k) - ay * v.at(i, j, k);
+    double dz = az * w.at(i, j, k + 1) - az * w.at(i, j, k);
+    double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
+    double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
+    rhs[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))] = make_double2(val, 0.0);
+}
+
+__global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const double pc = p.at(i, j, k);
+    u.at(i, j, k) -= (pc - p.at(i - 1, j, k)) * g.rdx;            // ∂xᶠᶜᶜ = δx * Δx⁻¹
+    v.at(i, j, k) -= (pc - p.at(i, j - 1, k)) * g.rdy;
+    w.at(i, j, k) -= (pc - p.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz];
+}
+
+__global__ void __launch_bounds__(256) divide_interior_kernel(DGrid g, FView p, double divisor) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    p.at(i, j, k) /= divisor;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Poisson solvers (src/Solvers)
+// ---------------------------------------------------------------------------------------------------------------------
+// `@. ϕc = -b / (λx + λy + λz - m)` with m = 0 and `ϕc[1,1,1] = 0` (fft_based_poisson_solver.jl:110,115)
+__global__ void __launch_bounds__(256) spectral_divide_kernel(double2 *b, const double *lx, const double *ly, const double *lz,
+                                                              int Nx, int Ny, int Nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= Nx || j >= Ny || k >= Nz) return;
+    const long q = (long)i + (long)Nx * (j + (long)Ny * k);
+    double lam = (lx[i] + ly[j]) + lz[k] - 0.0;
+    double2 val = b[q];
+    val.x = -val.x / lam;
+    val.y = -val.y / lam;
+    if (q == 0) { val.x = 0.0; val.y = 0.0; }
+    b[q] = val;
+}
+
+// copy_real_component! (fft_based_poisson_solver.jl:129-137) fused with the ifft normalisation (AbstractFFTs ScaledPlan:
+// multiply by 1/prod(N)) and, for the Fourier-tridiagonal solver, the mean removal
+// `ϕ .= ϕ .- mean(ϕ)` (fourier_tridiagonal_poisson_solver.jl:233): real(ϕ*scale - mean).
+__global__ void __launch_bounds__(256) copy_real_kernel(DGrid g, FView phi, const double2 *src, double scale, bool apply_scale,
+                                                        const double2 *mean) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    double val = src[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))].x;
+    if (apply_scale) val *= scale;
+    if (mean) val -= mean->x;
+    phi.at(i, j, k) = val;
+}
+
+// solve_batched_tridiagonal_system_kernel! z direction (batched_tridiagonal_solver.jl:213-245): one thread per (i, j)
+// column, coalesced across i. Complex f / phi, real a, b (3-D), c, scratch t (3-D real).
+__global__ void __launch_bounds__(256) tridiagonal_z_kernel(int Nx, int Ny, int Nz, const double *a, const double *b,
+                                                            const double *c, const double2 *f, double *t, double2 *phi) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (i >= Nx || j >= Ny) return;
+    const long st = (long)Nx * Ny;
+    long q = (long)i + (long)Nx * j;
+    double beta = b[q];
+    double2 f1 = f[q];
+    double2 prev = make_double2(f1.x / beta, f1.y / beta);
+    phi[q] = prev;
+    for (int k = 1; k < Nz; ++k) {
+        q += st;
+        double ck1 = c[k - 1], ak1 = a[k - 1], bk = b[q];
+        double tk = ck1 / beta;
+        t[q] = tk;
+        beta = bk - ak1 * tk;
+        double2 fk = f[q];
+        bool dd = fabs(beta) > 10.0 * 2.220446049250313e-16;
+        double2 star = make_double2((fk.x - ak1 * prev.x) / beta, (fk.y - ak1 * prev.y) / beta);
+        double2 old = phi[q];
+        prev = dd ? star : old;
+        phi[q] = prev;
+    }
+    for (int k = Nz - 2; k >= 0; --k) {
+        double tk1 = t[q];          // t[k+1]
+        q -= st;
+        double2 cur = phi[q];
+        cur.x -= tk1 * prev.x;
+        cur.y -= tk1 * prev.y;
+        phi[q] = cur;
+        prev = cur;
+    }
+}
+
+// deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
+__global__ void __launch_bounds__(256) sum_partial_kernel(const double2 *x, long n, double2 *partial) {
+    __shared__ double sx[256], sy[256];
+    double ax = 0, ay = 0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        ax += x[q].x; ay += x[q].y;
+    }
+    sx[threadIdx.x] = ax; sy[threadIdx.x] = ay;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sx[threadIdx.x] += sx[threadIdx.x + s]; sy[threadIdx.x] += sy[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = make_double2(sx[0], sy[0]);
+}
+__global__ void __launch_bounds__(256) sum_final_kernel(const double2 *partial, int nb, double inv_count, double scale, double2 *mean) {
+    __shared__ double sx[256], sy[256];
+    double ax = 0, ay = 0;
+    for (int q = threadIdx.x; q < nb; q += 256) { ax += partial[q].x; ay += partial[q].y; }
+    sx[threadIdx.x] = ax; sy[threadIdx.x] = ay;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sx[threadIdx.x] += sx[threadIdx.x + s]; sy[threadIdx.x] += sy[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *mean = make_double2(sx[0] * scale * inv_count, sy[0] * scale * inv_count);
+}
+
+// max |∇·u| (test helper)
+__global__ void __launch_bounds__(256) max_abs_div_kernel(DGrid g, FView u, FView v, FView w, double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    long total = (long)g.Nx * g.Ny * g.Nz;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        int i = 1 + q % g.Nx, j = 1 + (q / g.Nx) % g.Ny, k = 1 + q / ((long)g.Nx * g.Ny);
+        const int kk = k - 1 + g.Hz;
+        double dx = g.ax[kk] * u.at(i + 1, j, k) - g.ax[kk] * u.at(i, j, k);
+        double dy = g.ay[kk] * v.at(i, j + 1, k) - g.ay[kk] * v.at(i, j, k);
+        double dz = g.az * w.at(i, j, k + 1) - g.az * w.at(i, j, k);
+        double d = fabs(g.vinv_c[kk] * ((dx + dy) + dz));
+        m = d > m ? d : m;
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}

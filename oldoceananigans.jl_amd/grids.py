@@ -1,0 +1,177 @@
+"""RectilinearGrid (reference: src/Grids/rectilinear_grid.jl:3-25,264-291; coordinate generation
+src/Grids/grid_generation.jl:34-135). Host-side metadata only; the device view lives behind `ocn_grid_t`."""
+import ctypes as C
+from fractions import Fraction
+
+import numpy as np
+
+from . import _lib
+
+
+class Periodic:
+    code = 0
+
+
+class Bounded:
+    code = 1
+
+
+class Flat:
+    code = 2
+
+
+class Center:
+    code = 0
+
+
+class Face:
+    code = 1
+
+
+def _topo_code(t):
+    t = t if isinstance(t, type) else type(t)
+    if t is Flat:
+        raise NotImplementedError("Flat topologies are outside the accelerated hot path")
+    return t.code
+
+
+def _regular_coordinate(interval, N, name):
+    """generate_coordinate(FT, topo, N, H, node_interval::Tuple) (grid_generation.jl:98-135): Δ = FT(BigFloat(L)/N)."""
+    c1, c2 = Fraction(float(interval[0])), Fraction(float(interval[1]))
+    if c2 < c1:
+        raise ValueError(f"{name} must be an increasing interval!")
+    L = c2 - c1
+    return float(L / N), float(L), float(c1)
+
+
+def _stretched_coordinate(faces, N, H, bounded, name):
+    """generate_coordinate for an explicit face vector / function (grid_generation.jl:34-95).
+    Returns L, faces-with-halo, Δᶜ and Δᶠ as arrays indexed by position k-1+H for k = 1-H .. N+H+1 (entries the
+    reference leaves undefined repeat the last defined value)."""
+    if callable(faces):
+        faces = [faces(k) for k in range(1, N + 2)]
+    Fi = np.asarray(faces, dtype=np.float64)
+    if Fi.shape != (N + 1,):
+        raise ValueError(f"length({name}) must be N+1 = {N + 1}")
+    if not np.all(np.diff(Fi) >= 0) or not np.all(np.diff(Fi) > 0):
+        raise ValueError(f"The elements of {name} must be increasing!")
+    L = Fi[N] - Fi[0]
+    if bounded:
+        dm = [Fi[1] - Fi[0] for _ in range(H)]
+        dp = [Fi[N] - Fi[N - 1] for _ in range(H)]
+    else:
+        dm = [Fi[N - H + i] - Fi[N - H + i - 1] for i in range(1, H + 1)]
+        dp = [Fi[i] - Fi[i - 1] for i in range(1, H + 1)]
+    dp = dp[::-1]
+
+    def lsum(v):
+        s = v[0]
+        for x in v[1:]:
+            s = s + x
+        return s
+
+    Fm = [Fi[0] - lsum(dm[i:]) for i in range(H)]
+    Fp = [Fi[N] + lsum(dp[i:]) for i in range(H)][::-1]
+    F = np.concatenate([Fm, Fi, Fp])
+    TC = N + 2 * H
+    Cn = np.array([(F[i + 1] + F[i]) / 2 for i in range(TC)])
+    dF = [Cn[i] - Cn[i - 1] for i in range(1, TC)]
+    TF = N + 2 * H + (1 if bounded else 0)
+    F = F[:TF]
+    dC = [F[i + 1] - F[i] for i in range(TF - 1)]
+    dF = [dF[0]] + dF + [dF[-1]]
+    for i in range(len(dF) - 1, 0, -1):
+        dF[i] = dF[i - 1]
+    n = N + 2 * H + 1
+    dzc = np.array([dC[min(p, len(dC) - 1)] for p in range(n)])                 # ref index starts at 1-H
+    dzf = np.array([dF[min(p + 1, len(dF) - 1)] for p in range(n)])             # ref index starts at -H
+    return float(L), F, Cn, dzc, dzf
+
+
+class RectilinearGrid:
+    """RectilinearGrid(arch; size, x, y, z | extent, topology, halo) -- x and y must be regular (2-tuples); z may be a
+    2-tuple or an array/function of Nz+1 faces (Bounded only)."""
+
+    def __init__(self, architecture, size, x=None, y=None, z=None, extent=None,
+                 topology=(Periodic, Periodic, Periodic), halo=(3, 3, 3)):
+        self.architecture = architecture
+        self.Nx, self.Ny, self.Nz = (int(n) for n in size)
+        self.Hx, self.Hy, self.Hz = (int(h) for h in halo)
+        self.topology = tuple(t if isinstance(t, type) else type(t) for t in topology)
+        if extent is not None:
+            if any(c is not None for c in (x, y, z)):
+                raise ValueError("Cannot specify both extent and x, y, z keyword arguments!")
+            # default_horizontal_extent / default_vertical_extent (Grids/input_validation.jl:161-162)
+            x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
+        if x is None or y is None or z is None:
+            raise ValueError("Must supply extent or x, y, z keyword when topology is not Flat")
+        for name, c in (("x", x), ("y", y)):
+            if not (isinstance(c, tuple) and len(c) == 2):
+                raise NotImplementedError(f"stretched {name} is outside the accelerated hot path (only z may be stretched)")
+        self.Δxᶜᵃᵃ, self.Lx, self.x0 = _regular_coordinate(x, self.Nx, "x")
+        self.Δyᵃᶜᵃ, self.Ly, self.y0 = _regular_coordinate(y, self.Ny, "y")
+        self.Δxᶠᵃᵃ, self.Δyᵃᶠᵃ = self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ
+        n = self.Nz + 2 * self.Hz + 1
+        if isinstance(z, tuple) and len(z) == 2 and np.isscalar(z[0]):
+            dz, self.Lz, self.z0 = _regular_coordinate(z, self.Nz, "z")
+            self.z_regular = True
+            self.Δzᵃᵃᶜ = np.full(n, dz)
+            self.Δzᵃᵃᶠ = np.full(n, dz)
+            self._dz = dz
+        else:
+            if self.topology[2] is not Bounded:
+                raise NotImplementedError("a stretched z coordinate requires a Bounded z topology")
+            self.Lz, self.zᵃᵃᶠ, self.zᵃᵃᶜ, self.Δzᵃᵃᶜ, self.Δzᵃᵃᶠ = _stretched_coordinate(
+                z, self.Nz, self.Hz, True, "z")
+            self.z_regular = False
+            self._dz = 0.0
+        h = C.c_void_p()
+        dp = C.POINTER(C.c_double)
+        zc = None if self.z_regular else self.Δzᵃᵃᶜ.ctypes.data_as(dp)
+        zf = None if self.z_regular else self.Δzᵃᵃᶠ.ctypes.data_as(dp)
+        _lib.check(_lib.lib().ocn_grid_create(
+            C.byref(h), _lib.i3(self.size), _lib.i3(self.halo_size), _lib.i3([_topo_code(t) for t in self.topology]),
+            (C.c_double * 3)(self.Lx, self.Ly, self.Lz), self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ, self._dz, zc, zf))
+        self.handle = h
+
+    @property
+    def size(self):
+        return (self.Nx, self.Ny, self.Nz)
+
+    @property
+    def halo_size(self):
+        return (self.Hx, self.Hy, self.Hz)
+
+    def total_size(self, loc):
+        """total_size(loc, topo, N, H) (grid_utils.jl:138-169)"""
+        return tuple(n + 2 * h + (1 if (l is Face and t is Bounded) else 0)
+                     for n, h, l, t in zip(self.size, self.halo_size, loc, self.topology))
+
+    def interior_size(self, loc):
+        return tuple(n + (1 if (l is Face and t is Bounded) else 0) for n, l, t in zip(self.size, loc, self.topology))
+
+    def nodes(self, loc):
+        """interior node coordinates (xnodes, ynodes, znodes) as broadcastable arrays"""
+        out = []
+        for d, (n, l, t) in enumerate(zip(self.size, loc, self.topology)):
+            delta = (self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ, self._dz)[d]
+            origin = (self.x0, self.y0, getattr(self, "z0", 0.0))[d]
+            m = n + (1 if (l is Face and t is Bounded) else 0)
+            if d == 2 and not self.z_regular:
+                arr = self.zᵃᵃᶠ[self.Hz:self.Hz + m] if l is Face else self.zᵃᵃᶜ[self.Hz:self.Hz + m]
+            else:
+                arr = origin + delta * (np.arange(m) + (0.0 if l is Face else 0.5))
+            shape = [1, 1, 1]
+            shape[d] = m
+            out.append(np.asarray(arr, dtype=np.float64).reshape(shape))
+        return out
+
+    def __del__(self):
+        try:
+            _lib.lib().ocn_grid_destroy(self.handle)
+        except Exception:
+            pass
+
+    def __repr__(self):
+        names = "×".join(str(n) for n in self.size)
+        return f"{names} RectilinearGrid{{Float64, {', '.join(t.__name__ for t in self.topology)}}} on {self.architecture} with {self.halo_size} halo"

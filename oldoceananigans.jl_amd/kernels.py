@@ -1,0 +1,53 @@
+"""Raw kernel entry points on borrowed Fields: what `launch!(arch, grid, workspec, kernel!, args...)` runs for each
+hot-path kernel of the reference."""
+import ctypes as C
+
+from . import _lib
+from .fields import _loc_array, _ptr_array
+
+
+def _range(r):
+    return None if r is None else (C.c_int * 6)(*[int(x) for x in r])
+
+
+def compute_Gu(grid, u, v, w, Gu, kernel_parameters=None):
+    _lib.check(_lib.lib().ocn_compute_Gu(grid.handle, u.data, v.data, w.data, Gu.data, _range(kernel_parameters)))
+
+
+def compute_Gv(grid, u, v, w, Gv, kernel_parameters=None):
+    _lib.check(_lib.lib().ocn_compute_Gv(grid.handle, u.data, v.data, w.data, Gv.data, _range(kernel_parameters)))
+
+
+def compute_Gw(grid, u, v, w, Gw, kernel_parameters=None):
+    _lib.check(_lib.lib().ocn_compute_Gw(grid.handle, u.data, v.data, w.data, Gw.data, _range(kernel_parameters)))
+
+
+def compute_Gc(grid, u, v, w, c, Gc, kernel_parameters=None):
+    _lib.check(_lib.lib().ocn_compute_Gc(grid.handle, u.data, v.data, w.data, c.data, Gc.data, _range(kernel_parameters)))
+
+
+def compute_tendencies(grid, u, v, w, tracers, Gu, Gv, Gw, Gc, kernel_parameters=None):
+    """compute_interior_tendency_contributions! as one fused flux-sharing pass"""
+    tr = _ptr_array(tracers) if tracers else None
+    gc = _ptr_array(Gc) if Gc else None
+    _lib.check(_lib.lib().ocn_compute_tendencies(grid.handle, u.data, v.data, w.data, tr, len(tracers), Gu.data, Gv.data,
+                                                 Gw.data, gc, _range(kernel_parameters)))
+
+
+def rk3_substep(grid, fields, Gn, Gm, Δt, γ, ζ):
+    """rk3_substep_field! over a tuple of fields (ζ = None -> first stage)"""
+    _lib.check(_lib.lib().ocn_rk3_substep(grid.handle, _ptr_array(fields), _ptr_array(Gn), _ptr_array(Gm),
+                                          _loc_array(fields), len(fields), float(Δt), float(γ),
+                                          0.0 if ζ is None else float(ζ), 0 if ζ is None else 1))
+
+
+def cache_tendencies(grid, Gm, Gn):
+    _lib.check(_lib.lib().ocn_cache_tendencies(grid.handle, _ptr_array(Gm), _ptr_array(Gn), _loc_array(Gn), len(Gn)))
+
+
+def make_pressure_correction(grid, u, v, w, p):
+    _lib.check(_lib.lib().ocn_make_pressure_correction(grid.handle, u.data, v.data, w.data, p.data))
+
+
+def divide_interior(grid, p, divisor):
+    _lib.check(_lib.lib().ocn_divide_interior(grid.handle, p.data, float(divisor)))

@@ -1,0 +1,118 @@
+"""NonhydrostaticModel + RK3 time stepping (reference: src/Models/NonhydrostaticModels/nonhydrostatic_model.jl:115-244,
+src/TimeSteppers/runge_kutta_3.jl:93-170). The whole time-step runs inside libocn_mi355x.so (`ocn_model_time_step`);
+this module is the host-side mirror of the reference's API."""
+import ctypes as C
+from collections import namedtuple
+
+from . import _lib
+from .advection import WENO
+from .fields import Field
+from .grids import Center, Face
+
+
+class Clock:
+    """TimeSteppers/clock.jl:39-45 (read-only view of the library's clock)"""
+
+    def __init__(self, model):
+        self._model = model
+
+    def _get(self):
+        t, it, st, ldt, lsdt = C.c_double(), C.c_int64(), C.c_int(), C.c_double(), C.c_double()
+        _lib.check(_lib.lib().ocn_model_clock(self._model.handle, C.byref(t), C.byref(it), C.byref(st), C.byref(ldt),
+                                              C.byref(lsdt)))
+        return t.value, it.value, st.value, ldt.value, lsdt.value
+
+    time = property(lambda self: self._get()[0])
+    iteration = property(lambda self: self._get()[1])
+    stage = property(lambda self: self._get()[2])
+    last_Δt = property(lambda self: self._get()[3])
+    last_stage_Δt = property(lambda self: self._get()[4])
+
+
+class NonhydrostaticModel:
+    """NonhydrostaticModel(; grid, advection=WENO(), tracers=(:T, :S), timestepper=:RungeKutta3) with
+    coriolis / buoyancy / closure / forcing = nothing -- the configuration BASELINE.json benchmarks."""
+
+    def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", buoyancy=None, coriolis=None,
+                 closure=None, forcing=None):
+        if advection is None:
+            advection = WENO()
+        if not isinstance(advection, WENO):
+            raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
+        if timestepper not in ("RungeKutta3", ":RungeKutta3"):
+            raise NotImplementedError("only timestepper = :RungeKutta3 is on the accelerated hot path")
+        for name, val in (("buoyancy", buoyancy), ("coriolis", coriolis), ("closure", closure), ("forcing", forcing)):
+            if val is not None:
+                raise NotImplementedError(f"{name} != nothing is outside the accelerated hot path (SURVEY.md 8f)")
+        self.grid, self.advection = grid, advection
+        self.tracer_names = tuple(str(t) for t in (tracers if isinstance(tracers, (tuple, list)) else (tracers,)))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ocn_model_create(C.byref(h), grid.handle, len(self.tracer_names)))
+        self.handle = h
+        self.clock = Clock(self)
+        V = namedtuple("Velocities", "u v w")
+        self.velocities = V(self._field("u"), self._field("v"), self._field("w"))
+        T = namedtuple("Tracers", self.tracer_names) if self.tracer_names else tuple
+        self.tracers = T(*[self._field("c%d" % n) for n in range(len(self.tracer_names))])
+        P = namedtuple("Pressures", "pNHS")
+        self.pressures = P(self._field("p"))
+
+    @property
+    def architecture(self):
+        return self.grid.architecture
+
+    def _field(self, cname):
+        p, loc = C.c_void_p(), (C.c_int * 3)()
+        _lib.check(_lib.lib().ocn_model_field(self.handle, cname.encode(), C.byref(p), loc))
+        return Field(tuple(Face if l else Center for l in loc), self.grid, data=p, owner=self)
+
+    def tendency(self, name, previous=False):
+        """timestepper.Gⁿ[name] / G⁻[name]; pointers are stable at time-step boundaries."""
+        return self._field(("M" if previous else "G") + self._cname(name))
+
+    def _cname(self, name):
+        if name in ("u", "v", "w"):
+            return name
+        if name in self.tracer_names:
+            return "c%d" % self.tracer_names.index(name)
+        raise ValueError(f"name {name} not found in model.velocities or model.tracers.")
+
+    def fields(self):
+        d = dict(zip("uvw", self.velocities))
+        d.update(dict(zip(self.tracer_names, self.tracers)))
+        return d
+
+    def set_option(self, key, value):
+        _lib.check(_lib.lib().ocn_model_set_option(self.handle, key.encode(), int(value)))
+
+    def __del__(self):
+        try:
+            _lib.lib().ocn_model_destroy(self.handle)
+        except Exception:
+            pass
+
+
+def set_model(model, enforce_incompressibility=True, **kwargs):
+    """set!(model; enforce_incompressibility=true, kwargs...) (set_nonhydrostatic_model.jl:33-60)"""
+    flds = model.fields()
+    for name, value in kwargs.items():
+        if name not in flds:
+            raise ValueError(f"name {name} not found in model.velocities or model.tracers.")
+        flds[name].set(value)
+    _lib.check(_lib.lib().ocn_model_set_finalize(model.handle, int(enforce_incompressibility)))
+
+
+def update_state(model, compute_tendencies=True):
+    """update_state!(model; compute_tendencies) (update_nonhydrostatic_model_state.jl:20-56)"""
+    _lib.check(_lib.lib().ocn_model_update_state(model.handle, int(compute_tendencies)))
+
+
+def time_step(model, Δt):
+    """time_step!(model, Δt) (runge_kutta_3.jl:93-170)"""
+    _lib.check(_lib.lib().ocn_model_time_step(model.handle, float(Δt)))
+
+
+def max_abs_divergence(model):
+    v = C.c_double()
+    _lib.check(_lib.lib().ocn_model_max_abs_divergence(model.handle, C.byref(v)))
+    return v.value

@@ -119,11 +119,13 @@ static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, 
 }
 
 /* fill_halo_regions.jl:25-36 with the ordering of boundary_condition_ordering.jl:17-46: non-periodic sides first,
- * then periodic (which also fill corners because they span the whole parent). Stable order x, y, z within a class. */
+ * then periodic (which also fill corners because they span the whole parent). `sortperm(bcs_array, lt=fill_first)`
+ * (:42) runs an insertion sort with an `lt` that is true for every same-class pair, which REVERSES same-class
+ * entries of [west_and_east, south_and_north, bottom_and_top]: the order within a class is z, y, x. */
 void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs) {
-    for (int d = 0; d < 3; ++d)
+    for (int d = 2; d >= 0; --d)
         if (g->topo[d] == ORO_BOUNDED) fill_bounded(g, c, loc, d, fill_open_bcs);
-    for (int d = 0; d < 3; ++d)
+    for (int d = 2; d >= 0; --d)
         if (g->topo[d] == ORO_PERIODIC) fill_periodic(g, c, loc, d);
 }
 
