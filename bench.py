@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: ms/time-step and cell-updates/s of the NonhydrostaticModel RK3 time-step
+(WENO(order=5), tracers (T, S), FFT pressure solve) -- BASELINE.json's metric, measured like the reference measures it
+(benchmark/benchmarkable_nonhydrostatic_model.jl:23-27: device-synchronised `time_step!(model, Δt)` after warm-up).
+
+    python bench.py --gpus N --steps K --warmup W [--size 256] [--no-cpu-baseline]
+
+N = 1: 256^3 triply periodic on one MI355X (BASELINE.json configs[1]).
+N > 1: launched by torch.distributed.run, one rank per GPU; x-slab decomposition, WEAK scaling (256^3 per GPU, i.e.
+       global (256 N) x 256 x 256), RCCL halo exchange + all-to-all transposes inside the pressure solve.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job cell-updates/s with all inputs
+resident in HBM; "roofline" = the dominant kernel (fused WENO tendency evaluation) from HIP events recorded on the
+launch stream inside the timed region; "cpu_baseline" = the CPU oracle (a port, not the Julia reference) on the host
+cores over a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+TENDENCY_BYTES_PER_CELL = 80.0    # (5 fields read + 5 tendencies written) x 8 B
+V100_PUBLISHED_CELL_UPDATES = 256 ** 3 / 56.444e-3   # 256^3 F64 WENO 56.444 ms on a V100 (v0.58.8)
+
+
+def initial_state(ocn, model, seed=1234):
+    from helpers import smooth_state
+    g = model.grid
+    flds = model.fields()
+    nodes = {n: g.nodes(f.loc) for n, f in flds.items()}
+    return smooth_state(nodes, seed)
+
+
+def cpu_baseline(size, dt, budget_s=25.0):
+    """time the CPU oracle (oracle/, a port of the reference algorithm -- NOT the Julia reference, which cannot run
+    here) on the same workload, all host cores, bounded to ~budget_s of CPU work"""
+    from helpers import smooth_state
+    from oracle import oracle as O
+    cores = O.available_cpus()
+    O.lib().oro_set_num_threads(cores)
+    # estimate the rate on a 64^3 probe, then pick the largest power-of-two sample <= size that fits the budget
+    n = min(64, size)
+    g = O.Grid((n, n, n))
+    m = O.Model(g, 2)
+    m.time_step(dt)
+    t0 = time.perf_counter()
+    m.time_step(dt)
+    rate = n ** 3 / (time.perf_counter() - t0)
+    sample = size
+    while sample > 64 and 3 * sample ** 3 / rate > budget_s:
+        sample //= 2
+    g = O.Grid((sample, sample, sample))
+    m = O.Model(g, 2)
+    names = {"u": "u", "v": "v", "w": "w", "T": "c0", "S": "c1"}
+    locs = {"u": (1, 0, 0), "v": (0, 1, 0), "w": (0, 0, 1), "T": (0, 0, 0), "S": (0, 0, 0)}
+    d = 1.0 / sample
+    nodes = {}
+    for k, loc in locs.items():
+        ax = []
+        for dim in range(3):
+            shape = [1, 1, 1]
+            shape[dim] = sample
+            ax.append((d * (np.arange(sample) + (0.0 if loc[dim] else 0.5))).reshape(shape))
+        nodes[k] = ax
+    vals = smooth_state(nodes, 1234)
+    m.set(**{names[k]: v for k, v in vals.items()})
+    m.time_step(dt)                        # warm-up (also the iteration-0 update_state!)
+    nsteps = 2
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        m.time_step(dt)
+    el = time.perf_counter() - t0
+    return {"value": sample ** 3 * nsteps / el, "unit": "cell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{nsteps} RK3 steps of the same model at {sample}^3 (oracle/ C restatement, OpenMP)",
+            "ms_per_step": 1e3 * el / nsteps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=256, help="cells per side per GPU")
+    ap.add_argument("--tendency-impl", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import oldoceananigans_jl_amd as ocn
+    N = args.size
+    if world > 1:
+        from oldoceananigans_jl_amd import distributed as dist
+        ctx = dist.init_process_group(local_rank)
+        arch = ctx.arch
+        grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
+        model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+        step = lambda dt: dist.time_step(model, dt)          # noqa: E731
+        barrier = ctx.barrier
+        vals = dist.local_initial_state(model, initial_state)
+        dist.set_model(model, **vals)
+    else:
+        arch = ocn.GPU(local_rank)
+        grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
+        model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+        step = lambda dt: ocn.time_step(model, dt)            # noqa: E731
+        barrier = lambda: None                                # noqa: E731
+        ocn.set_model(model, **initial_state(ocn, model))
+    model.set_option("tendency_impl", args.tendency_impl)
+    dt = 0.1 * (1.0 / N) / 0.6                                # Δt = 0.1 Δx / max|u|
+
+    for _ in range(args.warmup):
+        step(dt)
+    model.set_option("profile", 1)
+    barrier()
+    ocn.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(dt)
+    ocn.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tend_ms, tend_n = model.profile_read()
+    model.set_option("profile", 0)
+    div = ocn.max_abs_divergence(model)
+
+    if world > 1:
+        elapsed = ctx.allreduce_max(elapsed)
+    if rank != 0:
+        return
+    cells = float(N) ** 3 * world
+    ms = 1e3 * elapsed / args.steps
+    value = cells * args.steps / elapsed
+    t_launch = 1e-3 * tend_ms / max(tend_n, 1)
+    achieved = TENDENCY_BYTES_PER_CELL * float(N) ** 3 / t_launch / 1e9 if tend_n else None
+    out = {
+        "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 else None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{N * world}x{N}x{N} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
+                               "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])",
+                   "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}), RCCL halo + all-to-all transposes",
+                   "dt": dt, "max_abs_divergence_after_run": div,
+                   "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
+                                       "benchmarks.md:128); older version without RK3/2 tracers -- context only"},
+        "roofline": {"kernel": "fused WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS)" if args.tendency_impl == 1
+                     else "per-field WENO-5 tendency kernels (5 launches)",
+                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                     "algorithmic_bytes_per_launch": TENDENCY_BYTES_PER_CELL * float(N) ** 3,
+                     "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
+                     "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(N, dt)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

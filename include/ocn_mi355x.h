@@ -144,8 +144,20 @@ int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *st
                     double *last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */
 int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
-/* tendency implementation: 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel */
+/* options: "tendency_impl" 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel;
+ * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "profile" 1 = record HIP
+ * events around every tendency evaluation on the launch stream */
 int ocn_model_set_option(ocn_model_t model, const char *key, int value);
+/* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
+ * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */
+int ocn_set_option(const char *key, int value);
+/* sum of the event-timed tendency evaluations since the last read (ms) and their count; synchronous. This is the
+ * measurement hook the reference lacks (it is profiled externally with nsys, .buildkite/pipeline-benchmarks.yml:57) */
+int ocn_model_profile_read(ocn_model_t model, double *tendency_ms, int *count);
+
+/* test hook: counts the Float32 significands (of 2^23, binade 2^exponent) for which the fast correctly-rounded
+ * reciprocal used inside newton_div (Utils/newton_div.jl:8-20) differs from the IEEE divide; must return 0 */
+int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ libocn_mi355x.so (include/ocn_mi355x.h). Import as `import oldoceananigans_jl_am
 from . import _lib
 from ._lib import OcnError, build
 from .advection import WENO
-from .architectures import GPU, architecture, synchronize
+from .architectures import GPU, architecture, set_option, synchronize
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
 from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state

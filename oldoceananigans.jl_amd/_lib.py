@@ -69,6 +69,9 @@ SYMBOLS = {
     "ocn_model_clock": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
     "ocn_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
+    "ocn_model_profile_read": (C.c_int, [_vp, _dp, _ip]),
+    "ocn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "ocn_debug_rcp_check": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
 }
 
 

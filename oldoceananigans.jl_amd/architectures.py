@@ -24,3 +24,8 @@ def architecture(obj):
 def synchronize(arch=None):
     """sync_device! (ext/OceananigansAMDGPUExt.jl:112-113)"""
     _lib.check(_lib.lib().ocn_sync())
+
+
+def set_option(key, value):
+    """library-wide tuning knobs (see include/ocn_mi355x.h: ocn_set_option)"""
+    _lib.check(_lib.lib().ocn_set_option(key.encode(), int(value)))

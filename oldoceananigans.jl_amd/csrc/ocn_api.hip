@@ -218,13 +218,13 @@ static Range6 default_range(const DGrid &g, const int loc[3], bool exclude_perip
     return Range6{lo[0], N[0], lo[1], N[1], lo[2], N[2]};
 }
 
-static int check_range(const DGrid &g, const int *range, Range6 *out, const int loc[3], bool exclude_periphery) {
-    if (!range) { *out = default_range(g, loc, exclude_periphery); return OCN_OK; }
+static int check_range(const DGrid &g, const int *range, Range6 *out, const int loc[3] = nullptr, bool exclude_periphery = false) {
+    if (!range) { if (out) *out = default_range(g, loc, exclude_periphery); return OCN_OK; }
     Range6 r{range[0], range[1], range[2], range[3], range[4], range[5]};
     // stencils reach 3 cells: the tendency of cell i needs psi[i-3 .. i+3]
     if (r.i0 < 1 || r.j0 < 1 || r.k0 < 1 || r.i1 > g.Nx || r.j1 > g.Ny || r.k1 > g.Nz)
         return fail(OCN_EINVAL, "kernel range (%d:%d, %d:%d, %d:%d) exceeds the interior", r.i0, r.i1, r.j0, r.j1, r.k0, r.k1);
-    *out = r;
+    if (out) *out = r;
     return OCN_OK;
 }
 
@@ -341,7 +341,14 @@ extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v,
 
 static int compute_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr,
                               int ntr, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range, int impl) {
-    if (impl == 1 && fused_tendency_supported(g, range)) return launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc);
+    if (impl == 1 && fused_tendency_supported(g, range) && ntr <= 3) {
+        int rc = check_range(g, range, nullptr);
+        if (rc) return rc;
+        rc = launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range);
+        if (rc) return fail(rc, "fused tendency launch failed");
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     int rc;
     if ((rc = launch_tendency<F_U>(g, u, v, w, nullptr, Gu, range))) return rc;
     if ((rc = launch_tendency<F_V>(g, u, v, w, nullptr, Gv, range))) return rc;
@@ -416,9 +423,13 @@ extern "C" int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const do
 // ---------------------------------------------------------------------------------------------------------------------
 // pressure source term / correction
 // ---------------------------------------------------------------------------------------------------------------------
-static int source_term(const DGrid &g, const double *u, const double *v, const double *w, double2 *rhs, bool weight) {
-    hipLaunchKernelGGL(source_term_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
+static int source_term(const DGrid &g, const double *u, const double *v, const double *w, void *rhs, bool weight, bool real_out = false) {
+    if (real_out)
+        hipLaunchKernelGGL(source_term_kernel<true>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
+    else
+        hipLaunchKernelGGL(source_term_kernel<false>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -427,7 +438,7 @@ extern "C" int ocn_compute_source_term(ocn_grid_t grid, const double *u, const d
                                        int weight_by_dz) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
-    return source_term(grid->d, u, v, w, (double2 *)rhs_complex, weight_by_dz != 0);
+    return source_term(grid->d, u, v, w, rhs_complex, weight_by_dz != 0);
 }
 
 static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p) {
@@ -458,6 +469,8 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Poisson solvers
 // ---------------------------------------------------------------------------------------------------------------------
+static int g_real_fft = 1, g_c2r_strided = 1;
+
 struct ocn_poisson_s {
     ocn_grid_t grid;
     int kind;
@@ -469,6 +482,15 @@ struct ocn_poisson_s {
     double2 *partial = nullptr, *mean = nullptr;
     hipfftHandle plan = 0;
     bool has_plan = false;
+    // real-transform fast path used by solve_for_pressure! (the source term is real by construction): D2Z of a dense real
+    // rhs into the Hermitian half spectrum (Nx/2+1, Ny, Nz), Z2D straight into the interior of the haloed pressure field
+    int Nxh = 0;
+    size_t nh = 0;
+    double *rrhs = nullptr;      // dense real right-hand side / fallback real output
+    double2 *hc = nullptr;       // half spectrum
+    double2 *hc2 = nullptr;      // kind 1: tridiagonal solution (separate from the rhs like the reference's storage)
+    hipfftHandle plan_r2c = 0, plan_c2r = 0;
+    bool has_r2c = false, has_c2r = false, c2r_strided = false;
 };
 
 // Solvers/poisson_eigenvalues.jl:8-23
@@ -484,6 +506,9 @@ static void poisson_eigenvalues(int N, double L, int topo, std::vector<double> &
 extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
     if (!s) return OCN_OK;
     if (s->has_plan) hipfftDestroy(s->plan);
+    if (s->has_r2c) hipfftDestroy(s->plan_r2c);
+    if (s->has_c2r) hipfftDestroy(s->plan_c2r);
+    hipFree(s->rrhs); hipFree(s->hc); hipFree(s->hc2);
     hipFree(s->storage); hipFree(s->source); hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     hipFree(s->partial); hipFree(s->mean);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
@@ -559,6 +584,43 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
         }
         hipfftResult r = hipfftSetStream(s->plan, g_stream);
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r); goto bad; }
+        // ---- real-transform path ----
+        s->Nxh = g.Nx / 2 + 1;
+        s->nh = (size_t)s->Nxh * g.Ny * g.Nz;
+        TRY_OR_FREE(hipMalloc((void **)&s->rrhs, s->n * sizeof(double)));
+        TRY_OR_FREE(hipMalloc((void **)&s->hc, s->nh * sizeof(double2)));
+        if (kind == 1) {
+            TRY_OR_FREE(hipMalloc((void **)&s->hc2, s->nh * sizeof(double2)));
+            TRY_OR_FREE(hipMemset(s->hc2, 0, s->nh * sizeof(double2)));
+        }
+        const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
+        if (kind == 0) {
+            int n3[3] = {g.Nz, g.Ny, g.Nx};
+            r = hipfftPlanMany(&s->plan_r2c, 3, n3, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, 1);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(D2Z 3-D) failed (%d)", (int)r); goto bad; }
+            s->has_r2c = true;
+            int inembed[3] = {g.Nz, g.Ny, s->Nxh}, onembed[3] = {Pz, Py, Px};
+            r = g_c2r_strided ? hipfftPlanMany(&s->plan_c2r, 3, n3, inembed, 1, (int)s->nh, onembed, 1, Px * Py * Pz, HIPFFT_Z2D, 1) : HIPFFT_NOT_SUPPORTED;
+            s->c2r_strided = r == HIPFFT_SUCCESS && g_c2r_strided;
+            if (!s->c2r_strided) r = hipfftPlanMany(&s->plan_c2r, 3, n3, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_Z2D, 1);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(Z2D 3-D) failed (%d)", (int)r); goto bad; }
+            s->has_c2r = true;
+        } else {
+            int n2[2] = {g.Ny, g.Nx};
+            int rin[2] = {g.Ny, g.Nx}, cemb[2] = {g.Ny, s->Nxh}, pemb[2] = {Py, Px};
+            r = hipfftPlanMany(&s->plan_r2c, 2, n2, rin, 1, g.Nx * g.Ny, cemb, 1, s->Nxh * g.Ny, HIPFFT_D2Z, g.Nz);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(D2Z 2-D) failed (%d)", (int)r); goto bad; }
+            s->has_r2c = true;
+            r = g_c2r_strided ? hipfftPlanMany(&s->plan_c2r, 2, n2, cemb, 1, s->Nxh * g.Ny, pemb, 1, Px * Py, HIPFFT_Z2D, g.Nz) : HIPFFT_NOT_SUPPORTED;
+            s->c2r_strided = r == HIPFFT_SUCCESS;
+            if (!s->c2r_strided) r = hipfftPlanMany(&s->plan_c2r, 2, n2, cemb, 1, s->Nxh * g.Ny, rin, 1, g.Nx * g.Ny, HIPFFT_Z2D, g.Nz);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(Z2D 2-D) failed (%d)", (int)r); goto bad; }
+            s->has_c2r = true;
+        }
+        if ((r = hipfftSetStream(s->plan_r2c, g_stream)) != HIPFFT_SUCCESS || (r = hipfftSetStream(s->plan_c2r, g_stream)) != HIPFFT_SUCCESS) {
+            rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r);
+            goto bad;
+        }
     }
     *solver = s;
     return OCN_OK;
@@ -583,7 +645,7 @@ static int poisson_solve(ocn_poisson_s *s, double *phi) {
         // fft_based_poisson_solver.jl:95-125
         FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_FORWARD));
         hipLaunchKernelGGL(spectral_divide_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->storage, s->lam[0],
-                           s->lam[1], s->lam[2], g.Nx, g.Ny, g.Nz);
+                           s->lam[1], s->lam[2], g.Nx, g.Ny, g.Nz, 1.0, false);
         FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_BACKWARD));
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
         hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vphi, s->storage, scale, true,
@@ -591,8 +653,8 @@ static int poisson_solve(ocn_poisson_s *s, double *phi) {
     } else {
         // fourier_tridiagonal_poisson_solver.jl:212-239
         FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->source, (hipfftDoubleComplex *)s->source, HIPFFT_FORWARD));
-        hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, g_stream, g.Nx, g.Ny, g.Nz, s->lower,
-                           s->D, s->lower, s->source, s->t, s->storage);
+        hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, g_stream, g.Nx, g.Nx, g.Ny, g.Nz, s->lower,
+                           s->D, s->lower, s->source, s->t, s->storage, 1.0, false);
         FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_BACKWARD));
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
         const int nb = 1024;
@@ -608,6 +670,47 @@ static int poisson_solve(ocn_poisson_s *s, double *phi) {
     return OCN_OK;
 }
 
+// solve_for_pressure! on the real-transform path: rrhs (dense real, already filled by the source-term kernel) -> phi
+static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
+    const DGrid &g = s->grid->d;
+    const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;
+    double *interior = phi + g.Hx + (size_t)Px * (g.Hy + (size_t)Py * g.Hz);
+    FFT_TRY(hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)s->hc));
+    double2 *sol = s->hc;
+    if (s->kind == 0) {
+        const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
+        hipLaunchKernelGGL(spectral_divide_kernel, grid3(s->Nxh, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->hc, s->lam[0], s->lam[1],
+                           s->lam[2], s->Nxh, g.Ny, g.Nz, scale, true);
+    } else {
+        const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
+        hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((s->Nxh + 63) / 64, g.Ny), dim3(64), 0, g_stream, s->Nxh, g.Nx, g.Ny, g.Nz,
+                           s->lower, s->D, s->lower, s->hc, s->t, s->hc2, scale, true);
+        hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, g_stream, s->hc2, (long)s->Nxh * g.Ny, g.Nz);
+        sol = s->hc2;
+    }
+    if (s->c2r_strided) {
+        FFT_TRY(hipfftExecZ2D(s->plan_c2r, (hipfftDoubleComplex *)sol, interior));
+    } else {
+        FFT_TRY(hipfftExecZ2D(s->plan_c2r, (hipfftDoubleComplex *)sol, s->rrhs));
+        hipLaunchKernelGGL(copy_dense_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C), s->rrhs);
+    }
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+
+
+static int solve_for_pressure(ocn_poisson_s *s, const double *u, const double *v, const double *w, double *p) {
+    const DGrid &g = s->grid->d;
+    int rc;
+    if (g_real_fft) {
+        if ((rc = source_term(g, u, v, w, s->rrhs, s->kind == 1, true))) return rc;
+        return poisson_solve_real(s, p);
+    }
+    if ((rc = source_term(g, u, v, w, s->kind == 0 ? s->storage : s->source, s->kind == 1))) return rc;
+    return poisson_solve(s, p);
+}
+
 extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *phi) {
     NEED_INIT();
     if (!s || !phi) return fail(OCN_EINVAL, "NULL argument");
@@ -617,17 +720,15 @@ extern "C" int ocn_poisson_solve(ocn_poisson_t s, double *phi) {
 extern "C" int ocn_solve_for_pressure(ocn_poisson_t s, const double *u, const double *v, const double *w, double *p) {
     NEED_INIT();
     if (!s || !u || !v || !w || !p) return fail(OCN_EINVAL, "NULL argument");
-    int rc = source_term(s->grid->d, u, v, w, s->kind == 0 ? s->storage : s->source, s->kind == 1);
-    if (rc) return rc;
-    return poisson_solve(s, p);
+    return solve_for_pressure(s, u, v, w, p);
 }
 
 extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c,
                                                const double *f_complex, double *t, double *phi_complex) {
     NEED_INIT();
     if (Nx < 1 || Ny < 1 || Nz < 1 || !a || !b || !c || !f_complex || !t || !phi_complex) return fail(OCN_EINVAL, "invalid argument");
-    hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, g_stream, Nx, Ny, Nz, a, b, c,
-                       (const double2 *)f_complex, t, (double2 *)phi_complex);
+    hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, g_stream, Nx, Nx, Ny, Nz, a, b, c,
+                       (const double2 *)f_complex, t, (double2 *)phi_complex, 1.0, false);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -649,10 +750,16 @@ struct ocn_model_s {
     int stage = 1;
     int tendency_impl = 1;
     int swap_tendencies = 1;
+    // live kernel timing for bench.py's roofline block: hipEvent pairs on the launch stream around every tendency
+    // evaluation (the dominant kernel), resolved by ocn_model_profile_read
+    int profile = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
 };
 
 extern "C" int ocn_model_destroy(ocn_model_t m) {
     if (!m) return OCN_OK;
+    for (auto &e : m->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
     hipFree(m->p); hipFree(m->blockmax);
     ocn_poisson_destroy(m->solver);
@@ -725,11 +832,23 @@ extern "C" int ocn_model_field(ocn_model_t m, const char *name, double **ptr, in
     return OCN_OK;
 }
 
+// library-wide tuning knobs (no reference equivalent; defaults are the tuned values)
+extern "C" int ocn_set_option(const char *key, int value) {
+    if (!key) return fail(OCN_EINVAL, "NULL argument");
+    if (!strcmp(key, "real_fft")) { g_real_fft = value; return OCN_OK; }
+    if (!strcmp(key, "c2r_strided")) { g_c2r_strided = value; return OCN_OK; }
+    if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
+    if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
+    if (!strcmp(key, "fused_kchunk")) { if (value < 1) return fail(OCN_EINVAL, "fused_kchunk must be >= 1"); g_fused_kchunk = value; return OCN_OK; }
+    return fail(OCN_EINVAL, "unknown option %s", key);
+}
+
 extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
     if (!strcmp(key, "tendency_impl")) { m->tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "swap_tendencies")) { m->swap_tendencies = value; return OCN_OK; }
-    return fail(OCN_EINVAL, "unknown option %s", key);
+    if (!strcmp(key, "profile")) { m->profile = value; m->events_used = 0; return OCN_OK; }
+    return ocn_set_option(key, value);
 }
 
 // update_state! (update_nonhydrostatic_model_state.jl:20-56), closure / buoyancy / forcing = nothing
@@ -737,9 +856,22 @@ static int update_state(ocn_model_s *m, bool compute_tend) {
     const DGrid &g = m->grid->d;
     int rc = fill_halo_regions(g, m->U, m->loc, m->nf, /*fill_open_bcs=*/false);
     if (rc) return rc;
-    if (compute_tend)
+    if (compute_tend) {
+        std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+        if (m->profile) {
+            if (m->events_used == m->events.size()) {
+                std::pair<hipEvent_t, hipEvent_t> e;
+                HIP_TRY(hipEventCreate(&e.first));
+                HIP_TRY(hipEventCreate(&e.second));
+                m->events.push_back(e);
+            }
+            ev = &m->events[m->events_used++];
+            HIP_TRY(hipEventRecord(ev->first, g_stream));
+        }
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl);
+        if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
+    }
     return rc;
 }
 
@@ -748,9 +880,7 @@ static int compute_pressure_correction(ocn_model_s *m) {
     const DGrid &g = m->grid->d;
     int rc = fill_halo_regions(g, m->U, m->loc, 3, true);
     if (rc) return rc;
-    ocn_poisson_s *s = m->solver;
-    if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], s->kind == 0 ? s->storage : s->source, s->kind == 1))) return rc;
-    if ((rc = poisson_solve(s, m->p))) return rc;
+    if ((rc = solve_for_pressure(m->solver, m->U[0], m->U[1], m->U[2], m->p))) return rc;
     double *pp[1] = {m->p};
     const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
     return fill_halo_regions(g, pp, pl, 1, true);
@@ -845,6 +975,40 @@ extern "C" int ocn_model_clock(ocn_model_t m, double *time, int64_t *iteration, 
     if (stage) *stage = m->stage;
     if (last_dt) *last_dt = m->last_dt;
     if (last_stage_dt) *last_stage_dt = m->last_stage_dt;
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_profile_read(ocn_model_t m, double *tendency_ms, int *count) {
+    NEED_INIT();
+    if (!m || !tendency_ms || !count) return fail(OCN_EINVAL, "NULL argument");
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    double total = 0;
+    for (size_t q = 0; q < m->events_used; ++q) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, m->events[q].first, m->events[q].second));
+        total += ms;
+    }
+    *tendency_ms = total;
+    *count = (int)m->events_used;
+    m->events_used = 0;
+    return OCN_OK;
+}
+
+// debug / test hook: number of significands (of 2^23) in the binade 2^(exponent) for which the fast Float32 reciprocal
+// differs from the IEEE divide
+extern "C" int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatches) {
+    NEED_INIT();
+    if (!mismatches || exponent < -120 || exponent > 120) return fail(OCN_EINVAL, "invalid argument");
+    unsigned long long *d;
+    HIP_TRY(hipMalloc((void **)&d, 8));
+    HIP_TRY(hipMemsetAsync(d, 0, 8, g_stream));
+    const int eb = exponent + 127;
+    if (variant == 1) hipLaunchKernelGGL(rcp_check_kernel<1>, dim3((1u << 23) / 256), dim3(256), 0, g_stream, eb, d);
+    else if (variant == 2) hipLaunchKernelGGL(rcp_check_kernel<2>, dim3((1u << 23) / 256), dim3(256), 0, g_stream, eb, d);
+    else hipLaunchKernelGGL(rcp_check_kernel<0>, dim3((1u << 23) / 256), dim3(256), 0, g_stream, eb, d);
+    HIP_TRY(hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipFree(d));
     return OCN_OK;
 }
 

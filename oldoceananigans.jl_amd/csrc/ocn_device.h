@@ -46,9 +46,28 @@ struct Range6 { int i0, i1, j0, j1, k0, k1; };
 // newton_div(Float32, a, b): src/Utils/newton_div.jl:8-20. The Float32 reciprocal must be the correctly rounded IEEE
 // quotient (the CPU reference evaluates `inv_fast` as a true divide); compiled with
 // -fhip-fp32-correctly-rounded-divide-sqrt so `1.0f / x` is exact, not v_rcp_f32.
+// Correctly rounded Float32 reciprocal without the generic IEEE-divide expansion (v_div_scale / v_div_fmas /
+// v_div_fixup, ~13 VALU): hardware v_rcp_f32 (1 ulp) + one Markstein correction step. Exact for every normal x whose
+// reciprocal is normal -- verified EXHAUSTIVELY over all 2^23 significands by ocn_debug_rcp_check (tests/test_gpu_parity.py);
+// the WENO argument beta + eps lies in [1e-8, ~1e19], far inside that range.
+#ifndef OCN_RCP_VARIANT
+#define OCN_RCP_VARIANT 1
+#endif
+template <int VARIANT> __device__ __forceinline__ float rcp_rn_f32(float x) {
+    if (VARIANT == 0) return 1.0f / x;                       // compiler's correctly rounded divide
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r, 1.0f);
+    r = __builtin_fmaf(r, e, r);
+    if (VARIANT == 2) {
+        e = __builtin_fmaf(-x, r, 1.0f);
+        r = __builtin_fmaf(r, e, r);
+    }
+    return r;
+}
+
 __device__ __forceinline__ double newton_div_f32(double a, double b) {
     float b_low = (float)b;
-    float inv_b = 1.0f / b_low;
+    float inv_b = rcp_rn_f32<OCN_RCP_VARIANT>(b_low);
     double inv_d = (double)inv_b;
     double x = a * inv_d;
     return __builtin_fma(__builtin_fma(x, -b, a), inv_d, x);

@@ -187,7 +187,8 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // pressure: source term, correction, scaling (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, double2 *rhs, bool weight_by_dz) {
+template <bool REAL_OUT>
+__global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, void *rhs, bool weight_by_dz) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
@@ -199,7 +200,9 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     double dz = az * w.at(i, j, k + 1) - az * w.at(i, j, k);
     double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
     double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
-    rhs[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))] = make_double2(val, 0.0);
+    const long q = (long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1));
+    if (REAL_OUT) ((double *)rhs)[q] = val;                 // real-to-complex transform path (rhs is real by construction)
+    else ((double2 *)rhs)[q] = make_double2(val, 0.0);      // the reference's complex storage
 }
 
 __global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p) {
@@ -225,17 +228,20 @@ __global__ void __launch_bounds__(256) divide_interior_kernel(DGrid g, FView p, 
 // Poisson solvers (src/Solvers)
 // ---------------------------------------------------------------------------------------------------------------------
 // `@. ϕc = -b / (λx + λy + λz - m)` with m = 0 and `ϕc[1,1,1] = 0` (fft_based_poisson_solver.jl:110,115)
+// Nxs = stored row length (Nx for complex-to-complex, Nx/2+1 for the Hermitian half spectrum of the real transform);
+// `scale` folds the inverse-FFT normalisation 1/prod(N) into the same pass when apply_scale is set.
 __global__ void __launch_bounds__(256) spectral_divide_kernel(double2 *b, const double *lx, const double *ly, const double *lz,
-                                                              int Nx, int Ny, int Nz) {
+                                                              int Nxs, int Ny, int Nz, double scale, bool apply_scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
     const int k = blockIdx.z;
-    if (i >= Nx || j >= Ny || k >= Nz) return;
-    const long q = (long)i + (long)Nx * (j + (long)Ny * k);
+    if (i >= Nxs || j >= Ny || k >= Nz) return;
+    const long q = (long)i + (long)Nxs * (j + (long)Ny * k);
     double lam = (lx[i] + ly[j]) + lz[k] - 0.0;
     double2 val = b[q];
     val.x = -val.x / lam;
     val.y = -val.y / lam;
+    if (apply_scale) { val.x *= scale; val.y *= scale; }
     if (q == 0) { val.x = 0.0; val.y = 0.0; }
     b[q] = val;
 }
@@ -257,24 +263,30 @@ __global__ void __launch_bounds__(256) copy_real_kernel(DGrid g, FView phi, cons
 
 // solve_batched_tridiagonal_system_kernel! z direction (batched_tridiagonal_solver.jl:213-245): one thread per (i, j)
 // column, coalesced across i. Complex f / phi, real a, b (3-D), c, scratch t (3-D real).
-__global__ void __launch_bounds__(256) tridiagonal_z_kernel(int Nx, int Ny, int Nz, const double *a, const double *b,
-                                                            const double *c, const double2 *f, double *t, double2 *phi) {
+// Nxs columns per row are solved; f / phi have row length Nxs, the real coefficient arrays b / t row length ldb
+// (ldb = Nx > Nxs = Nx/2+1 when only the Hermitian half spectrum is solved). fscale multiplies the right-hand side
+// (1 for the reference semantics; the folded inverse-FFT normalisation on the real-transform path).
+__global__ void __launch_bounds__(64) tridiagonal_z_kernel(int Nxs, int ldb, int Ny, int Nz, const double *a, const double *b,
+                                                           const double *c, const double2 *f, double *t, double2 *phi,
+                                                           double fscale, bool apply_scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
-    if (i >= Nx || j >= Ny) return;
-    const long st = (long)Nx * Ny;
-    long q = (long)i + (long)Nx * j;
-    double beta = b[q];
+    if (i >= Nxs || j >= Ny) return;
+    const long st = (long)Nxs * Ny, stb = (long)ldb * Ny;
+    long q = (long)i + (long)Nxs * j, qb = (long)i + (long)ldb * j;
+    double beta = b[qb];
     double2 f1 = f[q];
+    if (apply_scale) { f1.x *= fscale; f1.y *= fscale; }
     double2 prev = make_double2(f1.x / beta, f1.y / beta);
     phi[q] = prev;
     for (int k = 1; k < Nz; ++k) {
-        q += st;
-        double ck1 = c[k - 1], ak1 = a[k - 1], bk = b[q];
+        q += st; qb += stb;
+        double ck1 = c[k - 1], ak1 = a[k - 1], bk = b[qb];
         double tk = ck1 / beta;
-        t[q] = tk;
+        t[qb] = tk;
         beta = bk - ak1 * tk;
         double2 fk = f[q];
+        if (apply_scale) { fk.x *= fscale; fk.y *= fscale; }
         bool dd = fabs(beta) > 10.0 * 2.220446049250313e-16;
         double2 star = make_double2((fk.x - ak1 * prev.x) / beta, (fk.y - ak1 * prev.y) / beta);
         double2 old = phi[q];
@@ -282,14 +294,39 @@ __global__ void __launch_bounds__(256) tridiagonal_z_kernel(int Nx, int Ny, int 
         phi[q] = prev;
     }
     for (int k = Nz - 2; k >= 0; --k) {
-        double tk1 = t[q];          // t[k+1]
-        q -= st;
+        double tk1 = t[qb];          // t[k+1]
+        q -= st; qb -= stb;
         double2 cur = phi[q];
         cur.x -= tk1 * prev.x;
         cur.y -= tk1 * prev.y;
         phi[q] = cur;
         prev = cur;
     }
+}
+
+// `ϕ .= ϕ .- mean(ϕ)` (fourier_tridiagonal_poisson_solver.jl:233) applied in spectral space: the volume mean lives in
+// the (kx, ky) = (0, 0) column, mean(ϕ) * Nx*Ny = mean_k ϕ̂(0,0,k). One workgroup.
+__global__ void __launch_bounds__(256) remove_mean_mode_kernel(double2 *phi, long plane_stride, int Nz) {
+    __shared__ double sx[256], sy[256];
+    double ax = 0, ay = 0;
+    for (int k = threadIdx.x; k < Nz; k += 256) { ax += phi[k * plane_stride].x; ay += phi[k * plane_stride].y; }
+    sx[threadIdx.x] = ax; sy[threadIdx.x] = ay;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { sx[threadIdx.x] += sx[threadIdx.x + s]; sy[threadIdx.x] += sy[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    const double mx = sx[0] / (double)Nz, my = sy[0] / (double)Nz;
+    for (int k = threadIdx.x; k < Nz; k += 256) { phi[k * plane_stride].x -= mx; phi[k * plane_stride].y -= my; }
+}
+
+// dense real (Nx, Ny, Nz) -> interior of a haloed (C,C,C) field (fallback when the strided C2R plan is unavailable)
+__global__ void __launch_bounds__(256) copy_dense_real_kernel(DGrid g, FView phi, const double *src) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    phi.at(i, j, k) = src[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))];
 }
 
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
@@ -341,4 +378,14 @@ __global__ void __launch_bounds__(256) max_abs_div_kernel(DGrid g, FView u, FVie
         __syncthreads();
     }
     if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}
+
+// exhaustive check of rcp_rn_f32<VARIANT> against the compiler's correctly rounded divide over one binade
+template <int VARIANT>
+__global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsigned long long *mismatches) {
+    unsigned m = blockIdx.x * blockDim.x + threadIdx.x;          // 2^23 significands
+    if (m >= (1u << 23)) return;
+    float x = __uint_as_float(((unsigned)exponent_bits << 23) | m);
+    float a = rcp_rn_f32<VARIANT>(x), b = 1.0f / x;
+    if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1ULL);
 }

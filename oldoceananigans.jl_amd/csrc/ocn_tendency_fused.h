@@ -1,9 +1,307 @@
-// ocn_tendency_fused.h -- fused, flux-sharing WENO-5 tendency kernel (all of Gu, Gv, Gw, Gc in one pass).
+// ocn_tendency_fused.h -- fused, flux-sharing WENO-5 tendency kernel: Gu, Gv, Gw and all tracer tendencies in ONE pass.
+//
+// Reference formulation (compute_nonhydrostatic_tendencies.jl:49-163): 3 + ntracers launches, every thread evaluates
+// the fluxes on BOTH faces of its cell in all three directions, i.e. each face flux is computed twice, and u, v, w
+// are re-read by every launch (22 array passes for 2 tracers).
+//
+// MI355X formulation (this file): every face flux is evaluated exactly ONCE and handed to the neighbouring cell.
+//   * a workgroup owns a (64 x TY) column tile and MARCHES along z; each thread keeps the 6-deep z-windows of all
+//     prognostic fields in registers (coalesced 512-B row loads, one new plane per iteration), so the z-fluxes need no
+//     neighbour at all: the flux through the bottom face of cell k+1 is the top flux of cell k one iteration later;
+//   * each thread evaluates only the LOW-side x-, y-, z-fluxes of its cell for every field; the high-side x-flux comes
+//     from lane+1 through a wavefront shuffle, the high-side y-flux from the next row (next wave) through LDS
+//     (double-buffered, one s_barrier per plane);
+//   * one extra wave per workgroup evaluates the y-fluxes of the row just above the tile and the x-fluxes of the
+//     column just right of it, so tiles do not overlap and nothing is recomputed except those edge faces
+//     (1/TY of the y-fluxes + 1/64 of the x-fluxes);
+//   * x / y stencil neighbours are read straight from global memory (L1/L2 hits: the kernel is FP64-issue bound, not
+//     bandwidth bound -- see DESIGN.md roofline discussion).
+// The arithmetic of every flux is the same IEEE sequence as the per-field kernels => results are bit-identical.
 #pragma once
 #include "ocn_device.h"
 
-static inline bool fused_tendency_supported(const DGrid &, const int *) { return false; }
-static inline int launch_fused_tendency(const DGrid &, hipStream_t, const double *, const double *, const double *,
-                                        const double *const *, int, double *, double *, double *, double *const *) {
-    return -2;
+#define OCN_FUSED_MAXTR 8
+
+struct FusedArgs {
+    const double *u, *v, *w;
+    const double *c[OCN_FUSED_MAXTR];
+    double *Gu, *Gv, *Gw;
+    double *Gc[OCN_FUSED_MAXTR];
+    int s1;            // common x-row stride of all fields (x, y periodic => identical parent x/y extents)
+    long s2u, s2w;     // plane strides: (u, v, tracers) share s2u; w may have one more plane on Bounded z
+    long off;          // (Hx-1) + s1 (Hy-1): offset of 1-based (i, j) inside a plane; planes are indexed k-1+Hz
+    Range6 r;          // cell range of the launch
+    Range6 ru, rv, rw, rc;  // per-field store masks (exclude_periphery)
+    int kchunk;        // levels per workgroup along z
+};
+
+// window loaders ----------------------------------------------------------------------------------------------------
+struct Win6 { double s[6]; };
+
+__device__ __forceinline__ Win6 load_win(const double *p, long stride) {
+    Win6 w;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) w.s[n] = p[(n - 3) * stride];
+    return w;
+}
+
+__device__ __forceinline__ double sym4(const Win6 &q, double a, bool bounded, int idx, bool center, int N) {
+    return symmetric_interp(a * q.s[1], a * q.s[2], a * q.s[3], a * q.s[4], bounded, idx, center, N);
+}
+// symmetric interpolation along z: per-level area factors a[k-2 .. k+1]
+__device__ __forceinline__ double sym4z(const Win6 &q, const double *a, bool bounded, int idx, bool center, int N) {
+    return symmetric_interp(a[0] * q.s[1], a[1] * q.s[2], a[2] * q.s[3], a[3] * q.s[4], bounded, idx, center, N);
+}
+__device__ __forceinline__ double bias6(const Win6 &s, bool left, bool bounded, int idx, bool center, int N) {
+    return biased_interp(s.s[0], s.s[1], s.s[2], s.s[3], s.s[4], s.s[5], left, bounded, idx, center, N);
+}
+
+// The low-side fluxes of cell (i, j, k) (reference: upwind_biased_advective_fluxes.jl:23-121):
+//   x: Uu(i-1), Uv(i), Uw(i), cx(i);   y: Vu(j), Vv(j-1), Vw(j), cy(j);   z: Wu(k), Wv(k), Ww(k-1), cz(k)
+template <int NTR>
+__device__ __forceinline__ void x_fluxes(const DGrid &g, int i, int j, int k, double axk, const double *axz,
+                                         const Win6 &ux, const Win6 &uy, const Win6 &uz, const Win6 &vx, const Win6 &wx,
+                                         const Win6 *cx, double *F) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    double ut = sym4(ux, axk, bx, i - 1, true, g.Nx);                       // advective_momentum_flux_Uu :23-29
+    F[0] = ut * bias6(ux, ut > 0, bx, i - 1, true, g.Nx);
+    ut = sym4(uy, axk, by, j, false, g.Ny);                                 // Uv :47-53
+    F[1] = ut * bias6(vx, ut > 0, bx, i, false, g.Nx);
+    ut = sym4z(uz, axz, bz, k, false, g.Nz);                                // Uw :71-77
+    F[2] = ut * bias6(wx, ut > 0, bx, i, false, g.Nx);
+    const double u0 = ux.s[3];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) F[3 + t] = axk * u0 * bias6(cx[t], u0 > 0, bx, i, false, g.Nx);   // :99-105
+}
+
+template <int NTR>
+__device__ __forceinline__ void y_fluxes(const DGrid &g, int i, int j, int k, double ayk, const double *ayz,
+                                         const Win6 &vx, const Win6 &vy, const Win6 &vz, const Win6 &uy, const Win6 &wy,
+                                         const Win6 *cy, double *F) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    double vt = sym4(vx, ayk, bx, i, false, g.Nx);                          // Vu :31-37
+    F[0] = vt * bias6(uy, vt > 0, by, j, false, g.Ny);
+    vt = sym4(vy, ayk, by, j - 1, true, g.Ny);                              // Vv :55-61
+    F[1] = vt * bias6(vy, vt > 0, by, j - 1, true, g.Ny);
+    vt = sym4z(vz, ayz, bz, k, false, g.Nz);                                // Vw :79-85
+    F[2] = vt * bias6(wy, vt > 0, by, j, false, g.Ny);
+    const double v0 = vy.s[3];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) F[3 + t] = ayk * v0 * bias6(cy[t], v0 > 0, by, j, false, g.Ny);   // :107-113
+}
+
+template <int NTR>
+__device__ __forceinline__ void z_fluxes(const DGrid &g, int i, int j, int k, const Win6 &wx, const Win6 &wy, const Win6 &wz,
+                                         const Win6 &uz, const Win6 &vz, const Win6 *cz, double *F) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    const double az = g.az;
+    double wt = sym4(wx, az, bx, i, false, g.Nx);                           // Wu :39-45
+    F[0] = wt * bias6(uz, wt > 0, bz, k, false, g.Nz);
+    wt = sym4(wy, az, by, j, false, g.Ny);                                  // Wv :63-69
+    F[1] = wt * bias6(vz, wt > 0, bz, k, false, g.Nz);
+    wt = sym4(wz, az, bz, k - 1, true, g.Nz);                               // Ww :87-93
+    F[2] = wt * bias6(wz, wt > 0, bz, k - 1, true, g.Nz);
+    const double w0 = wz.s[3];
+#pragma unroll
+    for (int t = 0; t < NTR; ++t) F[3 + t] = az * w0 * bias6(cz[t], w0 > 0, bz, k, false, g.Nz);    // :115-121
+}
+
+__device__ __forceinline__ bool in_range(const Range6 &r, int i, int j, int k) {
+    return i >= r.i0 && i <= r.i1 && j >= r.j0 && j <= r.j1 && k >= r.k0 && k <= r.k1;
+}
+
+__device__ __forceinline__ double shfl_down1(double x) {
+    return __shfl_down(x, 1, 64);
+}
+
+// One workgroup = (TY + 1) wavefronts of 64 lanes: waves 0..TY-1 own tile rows, wave TY is the edge wave.
+// Register diet (v2): nothing but the previous plane's z-fluxes is carried across iterations; all low-side x / y fluxes of
+// a plane go to LDS (double buffered) and are read back -- own and neighbour's -- when the cell is closed one iteration
+// later, so the kernel fits 4+ waves per SIMD. BZ = z is Bounded (compile-time: the periodic build carries no fallback
+// reconstruction code).
+template <int NTR, int TY, bool BZ, int MINW>
+__global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGrid gin, FusedArgs a) {
+    constexpr int NF = 3 + NTR;
+    constexpr int NA = NTR > 0 ? NTR : 1;   // no zero-length arrays in device code
+    __shared__ double FX[2][NF][TY][66];            // low-side x-fluxes of columns 0..64 (65 used, padded)
+    __shared__ double FY[2][NF][TY + 1][64];        // low-side y-fluxes of rows 0..TY
+
+    DGrid g = gin;
+    g.tx = 0; g.ty = 0; g.tz = BZ ? 1 : 0;          // compile-time topology (x, y periodic is a launch precondition)
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int i0 = a.r.i0 + blockIdx.x * 64, j0 = a.r.j0 + blockIdx.y * TY;
+    const int kc0 = a.r.k0 + blockIdx.z * a.kchunk;
+    const int kc1 = min(kc0 + a.kchunk - 1, a.r.k1);
+    const bool edge = wave == TY;
+    const int i = i0 + lane;
+    const int j = j0 + wave;                          // edge wave: row j0 + TY
+    // cells whose tendencies this thread produces / faces whose low fluxes it must evaluate
+    const bool cell_ij = !edge && i <= a.r.i1 && j <= a.r.j1;
+    const bool flux_ij = !edge && i <= a.r.i1 + 1 && j <= a.r.j1 + 1;
+    // edge wave roles: the row above the tile (all lanes) and the column right of it (one lane per row)
+    const bool edge_y = edge && i <= a.r.i1 && j <= a.r.j1 + 1;
+    const int ie = i0 + 64, je = j0 + lane;
+    const bool edge_x = edge && lane < TY && ie <= a.r.i1 + 1 && je <= a.r.j1;
+
+    const long s1 = a.s1, s2 = a.s2u;
+    const int Hz = g.Hz;
+    const long col = a.off + i + s1 * (long)j;       // (i, j) of this thread inside a plane (edge wave: row j0+TY)
+    const long cole = a.off + ie + s1 * (long)je;
+
+    double fz_prev[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) fz_prev[f] = 0;
+
+    for (int k = kc0; k <= kc1 + 1; ++k) {
+        const bool last = k == kc1 + 1;               // peeled plane: only the z-fluxes closing cell kc1
+        const int buf = k & 1;
+        const long pk = (long)(k - 1 + Hz);
+        const double axk = g.ax[pk], ayk = g.ay[pk];
+        if (flux_ij) {
+            const double *pu = a.u + col + s2 * pk, *pv = a.v + col + s2 * pk, *pw = a.w + col + s2 * pk;
+            // ---- z-fluxes of plane k, then close cell k-1 ----
+            double fz[NF];
+            {
+                Win6 cz[NA];
+#pragma unroll
+                for (int t = 0; t < NTR; ++t) cz[t] = load_win(a.c[t] + col + s2 * pk, s2);
+                z_fluxes<NTR>(g, i, j, k, load_win(pw, 1), load_win(pw, s1), load_win(pw, s2), load_win(pu, s2),
+                              load_win(pv, s2), cz, fz);
+            }
+            if (k > kc0 && cell_ij) {
+                const int pb = buf ^ 1;
+                const long pkm = pk - 1;
+                const double vc = g.vinv_c[pkm], vf = g.vinv_f[pkm];
+                const long q = col + s2 * pkm;
+                const int km = k - 1;
+                double Gn_[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const double dx = FX[pb][f][wave][lane + 1] - FX[pb][f][wave][lane];
+                    const double dy = FY[pb][f][wave + 1][lane] - FY[pb][f][wave][lane];
+                    const double div = (f == 2 ? vf : vc) * ((dx + dy) + (fz[f] - fz_prev[f]));
+                    Gn_[f] = -div + 0.0;
+                }
+                if (in_range(a.ru, i, j, km)) a.Gu[q] = Gn_[0];
+                if (in_range(a.rv, i, j, km)) a.Gv[q] = Gn_[1];
+                if (in_range(a.rw, i, j, km)) a.Gw[q] = Gn_[2];
+#pragma unroll
+                for (int t = 0; t < NTR; ++t)
+                    if (in_range(a.rc, i, j, km)) a.Gc[t][q] = Gn_[3 + t];
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) fz_prev[f] = fz[f];
+            if (!last) {
+                // ---- low-side x- and y-fluxes of plane k -> LDS ----
+                double fl[NF];
+                {
+                    Win6 cx[NA];
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t] + col + s2 * pk, 1);
+                    x_fluxes<NTR>(g, i, j, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), load_win(pu, s2),
+                                  load_win(pv, 1), load_win(pw, 1), cx, fl);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) FX[buf][f][wave][lane] = fl[f];
+                }
+                {
+                    Win6 cy[NA];
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t] + col + s2 * pk, s1);
+                    y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), load_win(pv, s2),
+                                  load_win(pu, s1), load_win(pw, s1), cy, fl);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) FY[buf][f][wave][lane] = fl[f];
+                }
+            }
+        } else if (edge && !last) {
+            double fl[NF];
+            if (edge_y) {
+                // y-fluxes of row j0+TY (this wave's `j`), all 64 columns
+                const double *pu = a.u + col + s2 * pk, *pv = a.v + col + s2 * pk, *pw = a.w + col + s2 * pk;
+                Win6 cy[NA];
+#pragma unroll
+                for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t] + col + s2 * pk, s1);
+                y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), load_win(pv, s2),
+                              load_win(pu, s1), load_win(pw, s1), cy, fl);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) FY[buf][f][TY][lane] = fl[f];
+            }
+            if (edge_x) {
+                // x-fluxes of column i0+64, rows j0 .. j0+TY-1 (one lane per row)
+                const double *pu = a.u + cole + s2 * pk, *pv = a.v + cole + s2 * pk, *pw = a.w + cole + s2 * pk;
+                Win6 cx[NA];
+#pragma unroll
+                for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t] + cole + s2 * pk, 1);
+                x_fluxes<NTR>(g, ie, je, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), load_win(pu, s2),
+                              load_win(pv, 1), load_win(pw, 1), cx, fl);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) FX[buf][f][lane][64] = fl[f];
+            }
+        }
+        if (!last) __syncthreads();
+    }
+}
+
+static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
+    (void)range;
+    return g.tx == 0 && g.ty == 0;       // identical x / y parent extents for all fields
+}
+
+static int g_fused_ty = 7, g_fused_kchunk = 16, g_fused_minw = 4;
+
+template <int NTR, int TY>
+static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a) {
+    const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    dim3 grid((nx + 63) / 64, (ny + TY - 1) / TY, (nz + a.kchunk - 1) / a.kchunk);
+    constexpr int MW = (TY + 1) <= 4 ? 4 : ((TY + 1) <= 8 ? 4 : 3);   // waves per SIMD the register allocator must allow
+    if (g_fused_minw == 2) {
+        if (g.tz != 0) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, true, 2>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+        else           hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, false, 2>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+    } else {
+        if (g.tz != 0) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, true, MW>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+        else           hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, false, MW>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+    }
+    return 0;
+}
+
+
+
+static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,
+                                        const double *const *tr, int ntr, double *Gu, double *Gv, double *Gw,
+                                        double *const *Gc, const int *range) {
+    FusedArgs a;
+    a.u = u; a.v = v; a.w = w; a.Gu = Gu; a.Gv = Gv; a.Gw = Gw;
+    for (int t = 0; t < ntr; ++t) { a.c[t] = tr[t]; a.Gc[t] = Gc[t]; }
+    const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;
+    a.s1 = Px;
+    a.s2u = (long)Px * Py;
+    a.s2w = (long)Px * Py;
+    a.off = (g.Hx - 1) + (long)Px * (g.Hy - 1);
+    const int ofs = (g.tz != 0 && g.Nz > 1) ? 1 : 0;      // exclude_periphery: w tendencies start at k = 2 on Bounded z
+    if (range) {
+        a.r = Range6{range[0], range[1], range[2], range[3], range[4], range[5]};
+        a.ru = a.rv = a.rw = a.rc = a.r;                  // KernelParameters launches ignore exclude_periphery
+    } else {
+        a.r = Range6{1, g.Nx, 1, g.Ny, 1, g.Nz};
+        a.ru = a.rv = a.rc = a.r;
+        a.rw = Range6{1, g.Nx, 1, g.Ny, 1 + ofs, g.Nz};
+    }
+    a.kchunk = g_fused_kchunk;
+#define OCN_FUSED_CASE(NTR)                                                          \
+    case NTR:                                                                        \
+        if (g_fused_ty == 3) return launch_fused_t<NTR, 3>(g, stream, a);            \
+        if (g_fused_ty == 4) return launch_fused_t<NTR, 4>(g, stream, a);            \
+        if (g_fused_ty == 8) return launch_fused_t<NTR, 8>(g, stream, a);            \
+        return launch_fused_t<NTR, 7>(g, stream, a);
+    switch (ntr) {
+        OCN_FUSED_CASE(0)
+        OCN_FUSED_CASE(1)
+        OCN_FUSED_CASE(2)
+        OCN_FUSED_CASE(3)
+        default: return -2;
+    }
+#undef OCN_FUSED_CASE
 }

@@ -85,6 +85,12 @@ class NonhydrostaticModel:
     def set_option(self, key, value):
         _lib.check(_lib.lib().ocn_model_set_option(self.handle, key.encode(), int(value)))
 
+    def profile_read(self):
+        """(total ms, count) of the event-timed tendency evaluations since the last read"""
+        ms, n = C.c_double(), C.c_int()
+        _lib.check(_lib.lib().ocn_model_profile_read(self.handle, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def __del__(self):
         try:
             _lib.lib().ocn_model_destroy(self.handle)

@@ -488,7 +488,25 @@ void oro_scale_parent(const oro_grid *g, double *p, const int loc[3], double div
  * FFT (own implementation: iterative radix-2 + Bluestein for other lengths) and FFTW-convention DCTs
  * The reference calls FFTW (Solvers/plan_transforms.jl:16-34); bitwise FFT parity is unpinned by the reference.
  * ------------------------------------------------------------------------------------------------------------------ */
+/* twiddle cache: w[k] = exp(-2 pi i k / n), k < n/2, built once per length (not thread safe to build: built
+ * serially before the parallel line loops via fft_prepare) */
+#define ORO_MAX_TW 64
+static struct { int n; cplx *w; } g_tw[ORO_MAX_TW];
+static int g_ntw = 0;
+static const cplx *twiddles(int n) {
+    for (int q = 0; q < g_ntw; ++q) if (g_tw[q].n == n) return g_tw[q].w;
+    if (g_ntw == ORO_MAX_TW) g_ntw = 0;
+    cplx *w = (cplx *)malloc(sizeof(cplx) * (size_t)(n / 2 + 1));
+    for (int k = 0; k < n / 2; ++k) {
+        double ang = -2.0 * M_PI * (double)k / (double)n;
+        w[k] = cos(ang) + I * sin(ang);
+    }
+    g_tw[g_ntw].n = n; g_tw[g_ntw].w = w;
+    return g_tw[g_ntw++].w;
+}
+
 static void fft_pow2(cplx *x, int n, int sign) {
+    const cplx *w = twiddles(n);
     for (int i = 1, j = 0; i < n; ++i) {
         int bit = n >> 1;
         for (; j & bit; bit >>= 1) j ^= bit;
@@ -496,11 +514,10 @@ static void fft_pow2(cplx *x, int n, int sign) {
         if (i < j) { cplx t = x[i]; x[i] = x[j]; x[j] = t; }
     }
     for (int len = 2; len <= n; len <<= 1) {
-        int half = len >> 1;
+        int half = len >> 1, step = n / len;
         for (int i = 0; i < n; i += len)
             for (int k = 0; k < half; ++k) {
-                double ang = sign * 2.0 * M_PI * (double)k / (double)len;
-                cplx wk = cos(ang) + I * sin(ang);
+                cplx wk = sign < 0 ? w[k * step] : conj(w[k * step]);
                 cplx a = x[i + k], b = x[i + k + half] * wk;
                 x[i + k] = a + b;
                 x[i + k + half] = a - b;
@@ -508,12 +525,23 @@ static void fft_pow2(cplx *x, int n, int sign) {
     }
 }
 
+static int bluestein_len(int n) {
+    int m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    return m;
+}
+
+static void fft_prepare(int n) {            /* call serially before threaded use */
+    if (n <= 1) return;
+    if ((n & (n - 1)) == 0) (void)twiddles(n);
+    else (void)twiddles(bluestein_len(n));
+}
+
 static void fft_any(cplx *x, int n, int sign) {
     if (n <= 1) return;
     if ((n & (n - 1)) == 0) { fft_pow2(x, n, sign); return; }
     /* Bluestein */
-    int m = 1;
-    while (m < 2 * n - 1) m <<= 1;
+    int m = bluestein_len(n);
     cplx *a = (cplx *)calloc((size_t)m, sizeof(cplx)), *b = (cplx *)calloc((size_t)m, sizeof(cplx));
     cplx *wv = (cplx *)malloc(sizeof(cplx) * (size_t)n);
     for (int k = 0; k < n; ++k) {
@@ -533,11 +561,13 @@ static void fft_any(cplx *x, int n, int sign) {
 }
 
 void oro_fft_line(cplx *x, int n, int stride, int sign) {
-    cplx *tmp = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    fft_prepare(n);
+    cplx stackbuf[512];
+    cplx *tmp = n <= 512 ? stackbuf : (cplx *)malloc(sizeof(cplx) * (size_t)n);
     for (int i = 0; i < n; ++i) tmp[i] = x[(size_t)i * stride];
     fft_any(tmp, n, sign);
     for (int i = 0; i < n; ++i) x[(size_t)i * stride] = tmp[i];
-    free(tmp);
+    if (tmp != stackbuf) free(tmp);
 }
 
 /* FFTW REDFT10: Y_k = 2 sum_j X_j cos(pi (j+1/2) k / n); REDFT01: Y_k = X_0 + 2 sum_{j>=1} X_j cos(pi j (k+1/2) / n).
@@ -562,6 +592,7 @@ static void dct_line(cplx *x, int n, int stride, int backward) {
 static void transform_dim(cplx *A, const int n[3], int d, int kind /*0 fft fwd,1 fft bwd(unnormalised),2 dct fwd,3 dct bwd*/) {
     size_t st[3] = {1, (size_t)n[0], (size_t)n[0] * n[1]};
     int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    fft_prepare(n[d]);
 #pragma omp parallel for collapse(2) schedule(static)
     for (int b = 0; b < n[d2]; ++b)
         for (int a = 0; a < n[d1]; ++a) {

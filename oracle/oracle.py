@@ -24,9 +24,32 @@ LOC = {"u": (FACE, CENTER, CENTER), "v": (CENTER, FACE, CENTER), "w": (CENTER, C
 def build(force=False):
     so = os.path.join(_HERE, "libocn_oracle.so")
     src = os.path.join(_HERE, "ocn_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    stamp = os.path.join(_HERE, ".build_arch")
+    built_with_fma = os.path.exists(stamp) and "-mfma" in open(stamp).read()
+    try:
+        host_has_fma = " fma " in open("/proc/cpuinfo").read().replace("\n", " ")
+    except OSError:
+        host_has_fma = False
+    stale = not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+    if force or stale or (built_with_fma and not host_has_fma):     # never run -mfma code on a CPU without FMA
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
+
+
+def available_cpus():
+    """CPU share of this process: affinity mask, cgroup quota and a cap of 16 (the GPU box's per-GPU share; a fresh box
+    reports 256 hardware threads in its affinity mask but oversubscribing them stalls every OpenMP region)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("OCN_ORACLE_THREADS", "16"))))
 
 
 def lib():
@@ -34,6 +57,8 @@ def lib():
     if _LIB is None:
         _LIB = C.CDLL(build())
         L = _LIB
+        L.oro_set_num_threads.argtypes = [C.c_int]
+        L.oro_set_num_threads(available_cpus())
         dp, ip, vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
         L.oro_grid_create.restype = vp
         L.oro_grid_create.argtypes = [ip, ip, ip, dp] + [dp] * 6
