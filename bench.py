@@ -99,9 +99,12 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":
+        import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so (see distributed.init_process_group)
     import oldoceananigans_jl_amd as ocn
     N = args.size
-    if world > 1:
+    distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1"
+    if distributed:
         from oldoceananigans_jl_amd import distributed as dist
         ctx = dist.init_process_group(local_rank)
         arch = ctx.arch
@@ -134,9 +137,9 @@ def main():
     elapsed = time.perf_counter() - t0
     tend_ms, tend_n = model.profile_read()
     model.set_option("profile", 0)
-    div = ocn.max_abs_divergence(model)
+    div = dist.max_abs_divergence(model) if distributed else ocn.max_abs_divergence(model)
 
-    if world > 1:
+    if distributed:
         elapsed = ctx.allreduce_max(elapsed)
     if rank != 0:
         return

@@ -31,6 +31,7 @@ extern "C" {
 
 #define OCN_PERIODIC 0
 #define OCN_BOUNDED 1
+#define OCN_CONNECTED 2     /* FullyConnected: halo owned by a neighbouring rank (distributed_grids.jl:339-346); x only */
 #define OCN_CENTER 0
 #define OCN_FACE 1
 
@@ -55,6 +56,10 @@ int ocn_memcpy_d2h(void *dst, const void *src, size_t bytes); /* on_architecture
 int ocn_memcpy_d2d(void *dst, const void *src, size_t bytes); /* device_copy_to! (stream ordered) */
 int ocn_memset_zero(void *dst, size_t bytes);
 void *ocn_stream(void);                                       /* the hipStream_t all work is enqueued on */
+/* enqueue all subsequent work on a caller-owned stream (e.g. torch.cuda.current_stream(), so RCCL collectives issued
+ * through torch.distributed are stream-ordered with the kernels; the reference instead calls sync_device! before every
+ * MPI call, halo_communication.jl:181) */
+int ocn_set_stream(void *hip_stream);
 
 /* ---------------------------------------------------------------- grid (src/Grids/rectilinear_grid.jl:3-25) ------ */
 /* N, H, topo, L: per dimension. dx, dy: regular spacings. dzc / dzf: HOST arrays of Δzᵃᵃᶜ / Δzᵃᵃᶠ for index
@@ -125,6 +130,27 @@ int ocn_solve_for_pressure(ocn_poisson_t solver, const double *u, const double *
 int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, const double *b, const double *c,
                                     const double *f_complex, double *t, double *phi_complex);
 
+/* ---------------------------------------------------------------- distributed x-slab pieces --------------------- */
+/* fill_send_buffers! / recv_from_buffers! (DistributedComputations/communication_buffers.jl:281-313) for Partition(R):
+ * west/east buffers of Hx x Py x Pz doubles per field (whole parent extent in y, z: corners ride along), field-major.
+ * The exchange itself (MPI.Isend/Irecv in the reference, halo_communication.jl:300,326) is issued by the host layer
+ * over RCCL. */
+int ocn_pack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, double *west_send,
+                     double *east_send);
+int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, const double *west_recv,
+                       const double *east_recv);
+/* DistributedFFTBasedPoissonSolver for Partition(R,1,1) (distributed_fft_based_poisson_solver.jl:92-188), split at the
+ * two transposes (MPI.Alltoallv!, distributed_transpose.jl:185-191) which the host layer runs as RCCL all-to-alls on the
+ * send/recv buffers: rhs -> forward_yz -> [all_to_all] -> solve_x -> [all_to_all] -> backward_yz -> phi. */
+typedef struct ocn_dist_poisson_s *ocn_dist_poisson_t;
+int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t local_grid, int R, int rank, double Lx_global);
+int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
+int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t solver, double *send_complex, double *recv_complex);
+int ocn_dist_poisson_rhs(ocn_dist_poisson_t solver, double **rhs_complex);   /* solver.storage.zfield, (Nxl, Ny, Nz) */
+int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver);
+int ocn_dist_poisson_solve_x(ocn_dist_poisson_t solver);
+int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *phi);
+
 /* ---------------------------------------------------------------- model fast path ------------------------------- */
 /* NonhydrostaticModel(; grid, advection = WENO(), tracers, timestepper = :RungeKutta3) with coriolis / buoyancy /
  * closure / forcing = nothing (nonhydrostatic_model.jl:115-244). Fields are allocated (zeroed) by the library. */
@@ -144,6 +170,7 @@ int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *st
                     double *last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */
 int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
+int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value);
 /* options: "tendency_impl" 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel;
  * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "profile" 1 = record HIP
  * events around every tendency evaluation on the launch stream */

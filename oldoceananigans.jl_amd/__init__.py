@@ -7,7 +7,7 @@ from ._lib import OcnError, build
 from .advection import WENO
 from .architectures import GPU, architecture, set_option, synchronize
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
-from .grids import Bounded, Center, Face, Flat, Periodic, RectilinearGrid
+from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
 from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
                       solve_for_pressure)

@@ -39,6 +39,16 @@ SYMBOLS = {
     "ocn_memcpy_d2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ocn_memset_zero": (C.c_int, [_vp, C.c_size_t]),
     "ocn_stream": (_vp, []),
+    "ocn_set_stream": (C.c_int, [_vp]),
+    "ocn_pack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
+    "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
+    "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),
+    "ocn_dist_poisson_destroy": (C.c_int, [_vp]),
+    "ocn_dist_poisson_set_buffers": (C.c_int, [_vp, _vp, _vp]),
+    "ocn_dist_poisson_rhs": (C.c_int, [_vp, _pp]),
+    "ocn_dist_poisson_forward_yz": (C.c_int, [_vp]),
+    "ocn_dist_poisson_solve_x": (C.c_int, [_vp]),
+    "ocn_dist_poisson_backward_yz": (C.c_int, [_vp, _vp]),
     "ocn_grid_create": (C.c_int, [_pp, _ip, _ip, _ip, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]),
     "ocn_grid_destroy": (C.c_int, [_vp]),
     "ocn_grid_parent_size": (C.c_int, [_vp, _ip, _ip]),
@@ -68,6 +78,7 @@ SYMBOLS = {
     "ocn_model_time_step": (C.c_int, [_vp, C.c_double]),
     "ocn_model_clock": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
     "ocn_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
+    "ocn_max_abs_divergence": (C.c_int, [_vp, _vp, _vp, _vp, _dp]),
     "ocn_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),
     "ocn_model_profile_read": (C.c_int, [_vp, _dp, _ip]),
     "ocn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
@@ -75,9 +86,14 @@ SYMBOLS = {
 }
 
 
+LOADED_BEFORE_TORCH = False
+
+
 def lib():
-    global _lib
+    global _lib, LOADED_BEFORE_TORCH
     if _lib is None:
+        import sys
+        LOADED_BEFORE_TORCH = "torch" not in sys.modules
         if not os.path.exists(SO_PATH):
             raise OcnError(f"HIP extension {SO_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback in the product path)")

@@ -16,8 +16,10 @@
 // runtime state / error handling
 // ---------------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;   // may legitimately be the null (legacy default) stream after ocn_set_stream
 static int g_device = -1;
+static bool g_initialized = false;
+static bool g_stream_owned = true;
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -39,7 +41,7 @@ static int fail(int code, const char *fmt, ...) {
     } while (0)
 #define NEED_INIT()                                                                              \
     do {                                                                                         \
-        if (!g_stream) return fail(OCN_ESTATE, "ocn_init() has not been called");                \
+        if (!g_initialized) return fail(OCN_ESTATE, "ocn_init() has not been called");           \
     } while (0)
 #define KERNEL_CHECK()                                                                           \
     do {                                                                                         \
@@ -56,10 +58,22 @@ extern "C" int ocn_init(int device_id) {
     if (count <= 0) return fail(OCN_ESTATE, "no HIP device visible");
     if (device_id < 0 || device_id >= count) return fail(OCN_EINVAL, "device_id %d out of range [0, %d)", device_id, count);
     HIP_TRY(hipSetDevice(device_id));
-    if (g_stream && g_device == device_id) return OCN_OK;
-    if (g_stream) { hipStreamDestroy(g_stream); g_stream = nullptr; }
+    if (g_initialized && g_device == device_id) return OCN_OK;
+    if (g_initialized && g_stream_owned && g_stream) { hipStreamDestroy(g_stream); g_stream = nullptr; }
     HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_stream_owned = true;
     g_device = device_id;
+    g_initialized = true;
+    return OCN_OK;
+}
+
+// run all subsequent work on a stream owned by the caller (e.g. torch.cuda.current_stream() so that RCCL collectives
+// issued through torch.distributed are ordered with the kernels without host synchronisation)
+extern "C" int ocn_set_stream(void *stream) {
+    if (!g_initialized) return fail(OCN_ESTATE, "ocn_init() has not been called");
+    if (g_stream && g_stream_owned) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipStreamDestroy(g_stream)); }
+    g_stream = (hipStream_t)stream;
+    g_stream_owned = false;
     return OCN_OK;
 }
 
@@ -135,8 +149,9 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
     if (!grid || !N || !H || !topo || !L) return fail(OCN_EINVAL, "NULL argument");
     for (int d = 0; d < 3; ++d) {
         if (N[d] < 1) return fail(OCN_EINVAL, "size must be positive (dimension %d)", d);
-        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED)
-            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic and Bounded are accelerated", topo[d], d);
+        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(topo[d] == OCN_CONNECTED && d == 0))
+            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded and (x only) FullyConnected "
+                                     "are accelerated", topo[d], d);
         // WENO(order=5) needs a halo of 3 (nonhydrostatic_model.jl:184, inflate_grid_halo_size) and N >= 3 so that
         // adapt_advection_order (Advection/adapt_advection_order.jl:90-96) keeps the scheme
         if (H[d] < 3) return fail(OCN_EINVAL, "halo %d < 3 in dimension %d: WENO(order=5) requires halo >= 3", H[d], d);
@@ -516,6 +531,12 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
     return OCN_OK;
 }
 
+// FFT plans capture a stream at creation; re-point them when the library stream changed (ocn_set_stream)
+static int plan_set_stream(hipfftHandle plan) {
+    FFT_TRY(hipfftSetStream(plan, g_stream));
+    return OCN_OK;
+}
+
 extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int kind) {
     NEED_INIT();
     if (!solver || !grid) return fail(OCN_EINVAL, "NULL argument");
@@ -641,6 +662,7 @@ extern "C" int ocn_poisson_rhs(ocn_poisson_t s, double **rhs_complex) {
 static int poisson_solve(ocn_poisson_s *s, double *phi) {
     const DGrid &g = s->grid->d;
     FView vphi = make_view(g, phi, LOC_C);
+    { int rc_ = plan_set_stream(s->plan); if (rc_) return rc_; }
     if (s->kind == 0) {
         // fft_based_poisson_solver.jl:95-125
         FFT_TRY(hipfftExecZ2Z(s->plan, (hipfftDoubleComplex *)s->storage, (hipfftDoubleComplex *)s->storage, HIPFFT_FORWARD));
@@ -675,6 +697,7 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
     const DGrid &g = s->grid->d;
     const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;
     double *interior = phi + g.Hx + (size_t)Px * (g.Hy + (size_t)Py * g.Hz);
+    { int rc_; if ((rc_ = plan_set_stream(s->plan_r2c)) || (rc_ = plan_set_stream(s->plan_c2r))) return rc_; }
     FFT_TRY(hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)s->hc));
     double2 *sol = s->hc;
     if (s->kind == 0) {
@@ -729,6 +752,179 @@ extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const dou
     if (Nx < 1 || Ny < 1 || Nz < 1 || !a || !b || !c || !f_complex || !t || !phi_complex) return fail(OCN_EINVAL, "invalid argument");
     hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, g_stream, Nx, Nx, Ny, Nz, a, b, c,
                        (const double2 *)f_complex, t, (double2 *)phi_complex, 1.0, false);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// distributed x-slab pieces (src/DistributedComputations): the collectives themselves (RCCL send/recv, all-to-all) are
+// issued by the host layer through torch.distributed on buffers it owns; the library packs / unpacks / transforms.
+// ---------------------------------------------------------------------------------------------------------------------
+static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east, bool pack) {
+    if (n <= 0) return OCN_OK;
+    if (n > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
+    int P[3];
+    parent_size(g, locs[0], P);
+    for (int f = 1; f < n; ++f) {
+        int Q[3];
+        parent_size(g, locs[f], Q);
+        if (Q[0] != P[0] || Q[1] != P[1] || Q[2] != P[2]) return fail(OCN_EINVAL, "fields of one exchange must share the parent shape");
+    }
+    FieldList fl;
+    fl.n = n;
+    for (int f = 0; f < n; ++f) fl.p[f] = fields[f];
+    const long slab = (long)g.Hx * P[1] * P[2];
+    const int nb = (int)((slab + 255) / 256);
+    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], g.Nx, g.Hx, west, east);
+    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], g.Nx, g.Hx, west, east);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_pack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, double *west_send,
+                                double *east_send) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || !west_send || !east_send) return fail(OCN_EINVAL, "NULL argument");
+    return x_halo_buffers(grid->d, fields, locs, nfields, west_send, east_send, true);
+}
+
+extern "C" int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields,
+                                  const double *west_recv, const double *east_recv) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || !west_recv || !east_recv) return fail(OCN_EINVAL, "NULL argument");
+    return x_halo_buffers(grid->d, fields, locs, nfields, const_cast<double *>(west_recv), const_cast<double *>(east_recv), false);
+}
+
+// DistributedFFTBasedPoissonSolver for Partition(R, 1, 1) (distributed_fft_based_poisson_solver.jl:92-188)
+struct ocn_dist_poisson_s {
+    ocn_grid_t grid;            // LOCAL grid (Nxl, Ny, Nz)
+    int R, rank, Nxl, Nxg, Nyl, Ny, Nz;
+    size_t n;                   // local element count Nxl*Ny*Nz == Nxg*Nyl*Nz
+    double2 *zfield = nullptr, *xfield = nullptr;
+    double2 *send = nullptr, *recv = nullptr;   // borrowed (host layer owns them: torch tensors)
+    double *lam[3] = {nullptr, nullptr, nullptr};
+    hipfftHandle plan_yz = 0, plan_x = 0;
+    bool has_yz = false, has_x = false;
+};
+
+extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
+    if (!s) return OCN_OK;
+    if (s->has_yz) hipfftDestroy(s->plan_yz);
+    if (s->has_x) hipfftDestroy(s->plan_x);
+    hipFree(s->zfield); hipFree(s->xfield);
+    for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
+    delete s;
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t local_grid, int R, int rank, double Lx_global) {
+    NEED_INIT();
+    if (!solver || !local_grid) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = local_grid->d;
+    if (R < 1 || rank < 0 || rank >= R) return fail(OCN_EINVAL, "invalid rank %d of %d", rank, R);
+    if (g.ty != OCN_PERIODIC || g.tz != OCN_PERIODIC || (R > 1 && g.tx != OCN_CONNECTED) || (R == 1 && g.tx != OCN_PERIODIC))
+        return fail(OCN_ENOTSUP, "the distributed FFT solver is accelerated for (Periodic, Periodic, Periodic) x-slab partitions");
+    // validate_poisson_solver_distributed_grid (:194-229): Ny must be divisible by Rx
+    if (g.Ny % R != 0) return fail(OCN_EINVAL, "Ny = %d must be divisible by the number of ranks %d (transpose y -> x)", g.Ny, R);
+    if (!local_grid->z_regular) return fail(OCN_EINVAL, "DistributedFFTBasedPoissonSolver requires a regular grid");
+    ocn_dist_poisson_s *s = new ocn_dist_poisson_s();
+    s->grid = local_grid; s->R = R; s->rank = rank;
+    s->Nxl = g.Nx; s->Nxg = g.Nx * R; s->Ny = g.Ny; s->Nyl = g.Ny / R; s->Nz = g.Nz;
+    s->n = (size_t)g.Nx * g.Ny * g.Nz;
+    int rc = OCN_OK;
+#define TRY_OR_FREE(expr)                                                                                  \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) { rc = fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); goto bad; }   \
+    } while (0)
+    {
+        TRY_OR_FREE(hipMalloc((void **)&s->zfield, s->n * sizeof(double2)));
+        TRY_OR_FREE(hipMalloc((void **)&s->xfield, s->n * sizeof(double2)));
+        const int N[3] = {s->Nxg, s->Ny, s->Nz};
+        const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
+        for (int d = 0; d < 3; ++d) {
+            std::vector<double> lam;
+            poisson_eigenvalues(N[d], L[d], OCN_PERIODIC, lam);
+            TRY_OR_FREE(hipMalloc((void **)&s->lam[d], N[d] * sizeof(double)));
+            TRY_OR_FREE(hipMemcpy(s->lam[d], lam.data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
+        }
+        // (y, z) transform of the x-fastest local block: element stride Nxl along y, one batch entry per local i
+        int nyz[2] = {s->Nz, s->Ny};
+        int embed[2] = {s->Nz, s->Ny};
+        hipfftResult r = hipfftPlanMany(&s->plan_yz, 2, nyz, embed, s->Nxl, 1, embed, s->Nxl, 1, HIPFFT_Z2Z, s->Nxl);
+        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(yz) failed (%d)", (int)r); goto bad; }
+        s->has_yz = true;
+        int nx[1] = {s->Nxg};
+        r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyl * s->Nz);
+        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
+        s->has_x = true;
+    }
+    *solver = s;
+    return OCN_OK;
+bad:
+    ocn_dist_poisson_destroy(s);
+    return rc;
+#undef TRY_OR_FREE
+}
+
+extern "C" int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t s, double *send_complex, double *recv_complex) {
+    if (!s || !send_complex || !recv_complex) return fail(OCN_EINVAL, "NULL argument");
+    s->send = (double2 *)send_complex; s->recv = (double2 *)recv_complex;
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_poisson_rhs(ocn_dist_poisson_t s, double **rhs_complex) {
+    if (!s || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
+    *rhs_complex = (double *)s->zfield;
+    return OCN_OK;
+}
+
+static int transpose_stage(ocn_dist_poisson_s *s, int dir, const double2 *src, double2 *dst) {
+    const long total = (long)s->n;
+    hipLaunchKernelGGL(transpose_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, dir, s->R, s->Nxl, s->Nyl,
+                       s->Nz, src, dst);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// stage 1: forward FFT in z and y on zfield (:148-151), pack for transpose_y_to_x!. Afterwards the host layer runs
+// all_to_all(recv, send).
+extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s) {
+    NEED_INIT();
+    if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
+    int rc;
+    if ((rc = plan_set_stream(s->plan_yz))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_yz, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
+    return transpose_stage(s, 0, s->zfield, s->send);
+}
+
+// stage 2: unpack into the x-local layout, forward FFT in x, spectral divide, backward FFT in x (:152-166), pack for
+// transpose_x_to_y!. Afterwards the host layer runs all_to_all(recv, send) again.
+extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s) {
+    NEED_INIT();
+    if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
+    int rc;
+    if ((rc = transpose_stage(s, 1, s->recv, s->xfield))) return rc;
+    if ((rc = plan_set_stream(s->plan_x))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)s->xfield, (hipfftDoubleComplex *)s->xfield, HIPFFT_FORWARD));
+    hipLaunchKernelGGL(dist_spectral_divide_kernel, grid3(s->Nxg, s->Nyl, s->Nz, BLK), BLK, 0, g_stream, s->xfield, s->lam[0], s->lam[1],
+                       s->lam[2], s->Nxg, s->Nyl, s->Nz, s->rank * s->Nyl);
+    FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)s->xfield, (hipfftDoubleComplex *)s->xfield, HIPFFT_BACKWARD));
+    return transpose_stage(s, 2, s->xfield, s->send);
+}
+
+// stage 3: unpack into zfield, backward FFT in y and z, copy the (normalised) real part into the haloed pressure (:167-178)
+extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
+    NEED_INIT();
+    if (!s || !s->recv || !phi) return fail(OCN_EINVAL, "solver / buffers not set");
+    const DGrid &g = s->grid->d;
+    int rc;
+    if ((rc = transpose_stage(s, 3, s->recv, s->zfield))) return rc;
+    if ((rc = plan_set_stream(s->plan_yz))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_yz, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    const double scale = 1.0 / ((double)s->Nxg * (double)s->Ny * (double)s->Nz);
+    hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C), s->zfield, scale, true,
+                       (const double2 *)nullptr);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -1012,19 +1208,28 @@ extern "C" int ocn_debug_rcp_check(int variant, int exponent, unsigned long long
     return OCN_OK;
 }
 
-extern "C" int ocn_model_max_abs_divergence(ocn_model_t m, double *value) {
+extern "C" int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value) {
     NEED_INIT();
-    if (!m || !value) return fail(OCN_EINVAL, "NULL argument");
-    const DGrid &g = m->grid->d;
+    if (!grid || !u || !v || !w || !value) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = grid->d;
     const int nb = 1024;
-    hipLaunchKernelGGL(max_abs_div_kernel, dim3(nb), dim3(256), 0, g_stream, g, make_view(g, m->U[0], LOC_U),
-                       make_view(g, m->U[1], LOC_V), make_view(g, m->U[2], LOC_W), m->blockmax);
-    KERNEL_CHECK();
+    double *blockmax;
+    HIP_TRY(hipMalloc((void **)&blockmax, nb * sizeof(double)));
+    hipLaunchKernelGGL(max_abs_div_kernel, dim3(nb), dim3(256), 0, g_stream, g, make_view(g, u, LOC_U), make_view(g, v, LOC_V),
+                       make_view(g, w, LOC_W), blockmax);
     std::vector<double> h(nb);
-    HIP_TRY(hipMemcpyAsync(h.data(), m->blockmax, nb * sizeof(double), hipMemcpyDeviceToHost, g_stream));
-    HIP_TRY(hipStreamSynchronize(g_stream));
+    hipError_t e = hipMemcpyAsync(h.data(), blockmax, nb * sizeof(double), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    hipFree(blockmax);
+    if (e != hipSuccess) return fail((int)e, "max_abs_divergence: %s", hipGetErrorString(e));
     double mx = 0;
     for (double x : h) mx = std::max(mx, x);
     *value = mx;
     return OCN_OK;
+}
+
+extern "C" int ocn_model_max_abs_divergence(ocn_model_t m, double *value) {
+    NEED_INIT();
+    if (!m || !value) return fail(OCN_EINVAL, "NULL argument");
+    return ocn_max_abs_divergence(m->grid, m->U[0], m->U[1], m->U[2], value);
 }

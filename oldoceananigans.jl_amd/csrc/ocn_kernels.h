@@ -26,7 +26,7 @@ __device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, 
         int m = o - 2 + n;
         q[n] = D == 0 ? area_q<AQ>(g, f, i + m, j, k) : (D == 1 ? area_q<AQ>(g, f, i, j + m, k) : area_q<AQ>(g, f, i, j, k + m));
     }
-    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) != 0;
+    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
     return symmetric_interp(q[0], q[1], q[2], q[3], bounded, idx, CEN, N);
 }
@@ -38,7 +38,7 @@ __device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, b
     const long st = c.stride<D>();
     const double *p = c.p + c.lin(i, j, k) + (o - 3) * st;
     double s0 = p[0], s1 = p[st], s2 = p[2 * st], s3 = p[3 * st], s4 = p[4 * st], s5 = p[5 * st];
-    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) != 0;
+    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
     return biased_interp(s0, s1, s2, s3, s4, s5, left, bounded, idx, CEN, N);
 }
@@ -388,4 +388,72 @@ __global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsig
     float x = __uint_as_float(((unsigned)exponent_bits << 23) | m);
     float a = rcp_rn_f32<VARIANT>(x), b = 1.0f / x;
     if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// distributed x-slab support (src/DistributedComputations)
+// ---------------------------------------------------------------------------------------------------------------------
+// fill_send_buffers! / recv_from_buffers! for a 1-D x partition (communication_buffers.jl:281-313): the west / east
+// buffers hold Hx x Py x Pz slabs -- the whole parent extent in y and z, so corners ride along (:53,71-76).
+// PACK: west_send <- parent[Hx .. 2Hx), east_send <- parent[Nx .. Nx+Hx);  UNPACK: parent[0 .. Hx) <- west_recv,
+// parent[Nx+Hx .. Nx+2Hx) <- east_recv. Buffers are field-major: field f at offset f * Hx*Py*Pz.
+template <bool PACK>
+__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, int P0, int P1, int P2, int N, int H,
+                                                            double *west, double *east) {
+    const long slab = (long)H * P1 * P2;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= slab) return;
+    const int h = t % H;
+    const long r = t / H;                      // j + P1 * k
+    const long row = r * P0;
+    for (int f = 0; f < fl.n; ++f) {
+        double *p = fl.p[f];
+        if (PACK) {
+            west[f * slab + t] = p[row + H + h];
+            east[f * slab + t] = p[row + N + h];
+        } else {
+            p[row + h] = west[f * slab + t];
+            p[row + N + H + h] = east[f * slab + t];
+        }
+    }
+}
+
+// transpose staging for the distributed FFT (distributed_transpose.jl:25-95), x-slab partition over R ranks:
+//   y->x pack : zfield (Nxl, Ny, Nz)   -> send chunk d = { (i, jl, k) : j = d*Nyl + jl },  chunk-major
+//   y->x unpack: recv chunk s          -> xfield (Nxg, Nyl, Nz) at i_g = s*Nxl + i
+// and the inverse pair. dir 0: zfield -> chunks; 1: chunks -> xfield; 2: xfield -> chunks; 3: chunks -> zfield
+__global__ void __launch_bounds__(256) transpose_stage_kernel(int dir, int R, int Nxl, int Nyl, int Nz, const double2 *src,
+                                                              double2 *dst) {
+    const long chunk = (long)Nxl * Nyl * Nz;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= chunk * R) return;
+    const int c = t / chunk;                   // peer rank index
+    long q = t % chunk;
+    const int i = q % Nxl;
+    const int jl = (q / Nxl) % Nyl;
+    const int k = q / ((long)Nxl * Nyl);
+    const long Ny = (long)Nyl * R, Nxg = (long)Nxl * R;
+    const long zidx = i + Nxl * ((long)(c * Nyl + jl) + Ny * k);        // zfield element (i, j = c*Nyl + jl, k)
+    const long xidx = ((long)c * Nxl + i) + Nxg * (jl + (long)Nyl * k);  // xfield element (i_g = c*Nxl + i, jl, k)
+    if (dir == 0) dst[t] = src[zidx];
+    else if (dir == 1) dst[xidx] = src[t];
+    else if (dir == 2) dst[t] = src[xidx];
+    else dst[zidx] = src[t];
+}
+
+// _solve_poisson_in_spectral_space! (distributed_fft_based_poisson_solver.jl:180-188) on the x-local layout
+// (Nxg, Nyl, Nz): ϕ̂ = -b̂ / (λx + λy + λz), λy indexed with the rank's y offset; zeroth mode zeroed on the rank owning it
+__global__ void __launch_bounds__(256) dist_spectral_divide_kernel(double2 *b, const double *lx, const double *ly, const double *lz,
+                                                                   int Nxg, int Nyl, int Nz, int joff) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= Nxg || j >= Nyl || k >= Nz) return;
+    const long q = (long)i + (long)Nxg * (j + (long)Nyl * k);
+    double lam = (lx[i] + ly[joff + j]) + lz[k] - 0.0;
+    double2 val = b[q];
+    val.x = -val.x / lam;
+    val.y = -val.y / lam;
+    if (i == 0 && joff + j == 0 && k == 0) { val.x = 0.0; val.y = 0.0; }
+    b[q] = val;
 }

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
 
 static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
     (void)range;
-    return g.tx == 0 && g.ty == 0;       // identical x / y parent extents for all fields
+    return g.tx != 1 && g.ty != 1;       // x, y Periodic or FullyConnected: identical x / y parent extents for all fields
 }
 
 static int g_fused_ty = 7, g_fused_kchunk = 16, g_fused_minw = 4;

@@ -1,0 +1,452 @@
+"""Distributed x-slab NonhydrostaticModel (reference: src/DistributedComputations/, src/Models/interleave_communication_and_computation.jl).
+
+MI355X-first design: ONE process per GPU; collectives are RCCL over xGMI issued through `torch.distributed`
+(backend "nccl" is RCCL on ROCm); all kernels and collectives are ordered on ONE HIP stream per rank (torch's current
+stream, handed to the library with `ocn_set_stream`), so there is no host synchronisation on the hot path -- the
+reference calls `sync_device!` before every MPI call (halo_communication.jl:181, distributed_transpose.jl:187).
+
+  * halo exchange (fill_halo_regions! of a partitioned field, halo_communication.jl:87-110,170-187): local y / z fills,
+    then ONE batched send/recv pair with the two ring neighbours carrying all fields of the call
+    (Hx x Py x Pz x nfields doubles per side -- corners ride along, communication_buffers.jl:53,71-76);
+  * distributed FFT pressure solve (distributed_fft_based_poisson_solver.jl:141-188): local (y, z) FFT -> all-to-all
+    (transpose y -> x) -> x FFT, spectral divide, inverse x FFT -> all-to-all (x -> y) -> inverse (y, z) FFT;
+  * the time-step orchestration below is written against a small `backend` protocol: the product backend
+    (`DeviceBackend`) drives the HIP kernels through the C ABI; the world_size-2 CPU tests plug a test-only backend
+    (tests/cpu_backend.py, built on the oracle) into the SAME orchestration and run it over gloo.
+"""
+import ctypes as C
+
+import numpy as np
+import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so in this process (see init_process_group)
+
+from . import _lib
+from .advection import WENO
+from .fields import Field, _loc_array, _ptr_array
+from .grids import Bounded, Center, Face, FullyConnected, Periodic, RectilinearGrid, _regular_coordinate
+
+RK3 = dict(γ1=8 / 15, γ2=5 / 12, γ3=3 / 4, ζ2=-17 / 60, ζ3=-5 / 12)   # runge_kutta_3.jl:69-74 (FT rationals)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# architecture / communicator
+# ----------------------------------------------------------------------------------------------------------------------
+class Partition:
+    """Partition(Rx) (distributed_architectures.jl:14-63): x-slabs. Rank r has local index r (k fastest, :354) and ring
+    neighbours with periodic wrap (:391-434)."""
+
+    def __init__(self, R):
+        self.R = int(R)
+
+    def neighbours(self, rank, periodic=True):
+        west, east = rank - 1, rank + 1
+        if periodic:
+            return west % self.R, east % self.R
+        return (west if west >= 0 else None), (east if east < self.R else None)
+
+
+class DistributedContext:
+    """`Distributed(GPU(); partition = Partition(R))`: torch.distributed process group + the library bound to this rank's
+    GPU and to torch's current stream."""
+
+    def __init__(self, rank, world, device, torch, dist, arch):
+        self.rank, self.world, self.device = rank, world, device
+        self.torch, self.dist, self.arch = torch, dist, arch
+        self.partition = Partition(world)
+        self.west, self.east = self.partition.neighbours(rank)
+
+    # -- collectives ---------------------------------------------------------------------------------------------
+    def exchange_start(self, west_send, east_send, west_recv, east_recv):
+        """MPI.Isend/Irecv! to both neighbours (halo_communication.jl:300,326). Order of the ops makes the pairing
+        unambiguous even when both neighbours are the same rank (R = 2). Returns the pending requests: on RCCL the
+        transfers run on the communicator's stream, concurrently with kernels launched afterwards."""
+        d = self.dist
+        ops = [d.P2POp(d.isend, west_send, self.west), d.P2POp(d.irecv, east_recv, self.east),
+               d.P2POp(d.isend, east_send, self.east), d.P2POp(d.irecv, west_recv, self.west)]
+        return d.batch_isend_irecv(ops)
+
+    @staticmethod
+    def exchange_wait(reqs):
+        """MPI.Waitall (halo_communication.jl:164-165): later work on the stream waits for the transfers"""
+        for req in reqs:
+            req.wait()
+
+    def exchange(self, west_send, east_send, west_recv, east_recv):
+        self.exchange_wait(self.exchange_start(west_send, east_send, west_recv, east_recv))
+
+    def all_to_all(self, recv, send):
+        """MPI.Alltoallv! with equal counts (distributed_transpose.jl:185-191)"""
+        self.dist.all_to_all_single(recv, send)
+
+    def allreduce_max(self, value):
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+def init_process_group(local_rank=0, backend=None):
+    """one process per GPU; MASTER_ADDR/PORT, RANK, WORLD_SIZE come from torch.distributed.run"""
+    if _lib._lib is not None and _lib.LOADED_BEFORE_TORCH:
+        raise _lib.OcnError("libocn_mi355x.so was loaded before torch: torch bundles its own ROCm runtime under the same "
+                            "sonames and cannot initialise on top of the system one. Import torch (or this module) and call "
+                            "init_process_group() before creating any ocn.GPU().")
+    import torch
+    import torch.distributed as dist
+    from .architectures import GPU
+    use_gpu = torch.cuda.is_available()
+    if backend is None:
+        backend = "nccl" if use_gpu else "gloo"
+    if not dist.is_initialized():
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if use_gpu:
+        arch = GPU(local_rank)
+        # all library work goes to torch's current stream so RCCL ops are stream-ordered with the kernels
+        _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        device = torch.device("cuda", local_rank)
+    else:
+        arch, device = None, torch.device("cpu")
+    return DistributedContext(rank, world, device, torch, dist, arch)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# grid
+# ----------------------------------------------------------------------------------------------------------------------
+def partition_coordinate(c, n_local, R, r):
+    """partition_coordinate(c::Tuple, n, arch, dim) (partition_assemble.jl:57-70), equal local sizes"""
+    N = n_local * R
+    dl = (c[1] - c[0]) / N
+    lo = c[0]
+    for _ in range(r):
+        lo = lo + dl * n_local
+    return (lo, lo + dl * n_local)
+
+
+class DistributedRectilinearGrid:
+    """RectilinearGrid(arch::Distributed; size = GLOBAL size, ...) (distributed_grids.jl:75-117): the rank-local grid of
+    an x-slab partition. `local` is the RectilinearGrid-like object the kernels run on."""
+
+    def __init__(self, ctx, size, x=None, y=None, z=None, extent=None, topology=(Periodic, Periodic, Periodic),
+                 halo=(3, 3, 3), make_local_grid=None):
+        self.ctx = ctx
+        R, r = ctx.world, ctx.rank
+        if extent is not None:
+            x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
+        self.global_size = tuple(int(n) for n in size)
+        if self.global_size[0] % R != 0:
+            raise ValueError(f"Nx = {size[0]} must be divisible by the number of ranks {R} (equal x-slabs)")
+        if topology[0] is not Periodic:
+            raise NotImplementedError("only a Periodic partitioned direction is accelerated")
+        nxl = self.global_size[0] // R
+        self.x_global = (float(x[0]), float(x[1]))
+        self.Lx_global = _regular_coordinate(x, self.global_size[0], "x")[1]
+        xl = x if R == 1 else partition_coordinate(x, nxl, R, r)
+        topo = (topology[0] if R == 1 else FullyConnected, topology[1], topology[2])
+        self.local_size = (nxl, self.global_size[1], self.global_size[2])
+        self.i_offset = r * nxl                      # global index of local i = 1 minus one
+        if make_local_grid is None:
+            self.local = RectilinearGrid(ctx.arch, self.local_size, x=xl, y=y, z=z, topology=topo, halo=halo)
+        else:
+            self.local = make_local_grid(self.local_size, xl, y, z, topo, halo)
+
+    def __getattr__(self, name):
+        return getattr(self.local, name)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# product backend: HIP kernels through the C ABI, torch CUDA tensors as communication buffers
+# ----------------------------------------------------------------------------------------------------------------------
+class DeviceBackend:
+    def __init__(self, ctx, grid, ntracers):
+        self.ctx, self.grid, self.ntracers = ctx, grid, ntracers
+        torch = ctx.torch
+        g = grid.local
+        L = _lib.lib()
+        locs = [(Face, Center, Center), (Center, Face, Center), (Center, Center, Face)] + [(Center,) * 3] * ntracers
+        self.U = [Field(l, g) for l in locs]
+        self.Gn = [Field(l, g) for l in locs]
+        self.Gm = [Field(l, g) for l in locs]
+        self.p = Field((Center,) * 3, g)
+        nf = len(locs)
+        Px, Py, Pz = g.total_size((Center,) * 3)
+        slab = g.Hx * Py * Pz
+        mk = lambda n: torch.zeros(n, dtype=torch.float64, device=ctx.device)   # noqa: E731
+        self.ws, self.es, self.wr, self.er = mk(slab * nf), mk(slab * nf), mk(slab * nf), mk(slab * nf)
+        self.slab = slab
+        h = C.c_void_p()
+        _lib.check(L.ocn_dist_poisson_create(C.byref(h), g.handle, ctx.world, ctx.rank, grid.Lx_global))
+        self.solver = h
+        n = g.Nx * g.Ny * g.Nz
+        self.send = torch.zeros(2 * n, dtype=torch.float64, device=ctx.device)
+        self.recv = torch.zeros(2 * n, dtype=torch.float64, device=ctx.device)
+        _lib.check(L.ocn_dist_poisson_set_buffers(h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
+        rhs = C.c_void_p()
+        _lib.check(L.ocn_dist_poisson_rhs(h, C.byref(rhs)))
+        self.rhs = rhs
+        self.profile, self.events, self.n_evals = False, [], 0
+
+    # -- halos ---------------------------------------------------------------------------------------------------
+    def fill_local_halos(self, fields, fill_open_bcs):
+        L = _lib.lib()
+        _lib.check(L.ocn_fill_halo_regions(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
+                                           int(fill_open_bcs)))
+
+    def pack_x(self, fields):
+        n = len(fields) * self.slab
+        _lib.check(_lib.lib().ocn_pack_x_halos(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
+                                               C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.es.data_ptr())))
+        return self.ws[:n], self.es[:n], self.wr[:n], self.er[:n]
+
+    def unpack_x(self, fields):
+        _lib.check(_lib.lib().ocn_unpack_x_halos(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
+                                                 C.c_void_p(self.wr.data_ptr()), C.c_void_p(self.er.data_ptr())))
+
+    # -- kernels -------------------------------------------------------------------------------------------------
+    def rk3_substep(self, dt, γ, ζ):
+        from . import kernels
+        kernels.rk3_substep(self.grid.local, self.U, self.Gn, self.Gm, dt, γ, ζ)
+
+    def swap_tendencies(self):
+        self.Gn, self.Gm = self.Gm, self.Gn
+
+    def compute_tendencies(self, rng=None):
+        from . import kernels
+        U = self.U
+        ev = None
+        if self.profile:
+            torch = self.ctx.torch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        kernels.compute_tendencies(self.grid.local, U[0], U[1], U[2], U[3:], self.Gn[0], self.Gn[1], self.Gn[2], self.Gn[3:],
+                                   kernel_parameters=rng)
+        if ev:
+            ev[1].record()
+            self.events.append(ev)
+
+    def profile_read(self):
+        """(total ms of the event-timed tendency launches, number of tendency EVALUATIONS) since the last read"""
+        self.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        n = self.n_evals
+        self.events, self.n_evals = [], 0
+        return ms, n
+
+    def source_term(self):
+        U = self.U
+        _lib.check(_lib.lib().ocn_compute_source_term(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.rhs, 0))
+
+    def poisson_forward_yz(self):
+        _lib.check(_lib.lib().ocn_dist_poisson_forward_yz(self.solver))
+
+    def poisson_solve_x(self):
+        _lib.check(_lib.lib().ocn_dist_poisson_solve_x(self.solver))
+
+    def poisson_backward_yz(self):
+        _lib.check(_lib.lib().ocn_dist_poisson_backward_yz(self.solver, self.p.data))
+
+    def pressure_correction(self):
+        U = self.U
+        _lib.check(_lib.lib().ocn_make_pressure_correction(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.p.data))
+
+    def divide_pressure(self, divisor):
+        _lib.check(_lib.lib().ocn_divide_interior(self.grid.local.handle, self.p.data, float(divisor)))
+
+    def max_abs_divergence(self):
+        U, v = self.U, C.c_double()
+        _lib.check(_lib.lib().ocn_max_abs_divergence(self.grid.local.handle, U[0].data, U[1].data, U[2].data, C.byref(v)))
+        return v.value
+
+    def synchronize(self):
+        self.ctx.torch.cuda.current_stream().synchronize()
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# model + time stepping (backend-agnostic orchestration)
+# ----------------------------------------------------------------------------------------------------------------------
+class DistributedNonhydrostaticModel:
+    """NonhydrostaticModel on a Distributed architecture (x-slabs): WENO(order=5), RK3, DistributedFFTBasedPoissonSolver."""
+
+    def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None):
+        if advection is not None and not isinstance(advection, WENO):
+            raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
+        self.grid, self.ctx = grid, grid.ctx
+        self.tracer_names = tuple(tracers)
+        self.backend = backend if backend is not None else DeviceBackend(grid.ctx, grid, len(self.tracer_names))
+        self.time, self.iteration, self.stage = 0.0, 0, 1
+        self.last_Δt = self.last_stage_Δt = float("inf")
+        self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
+
+    # field access ---------------------------------------------------------------------------------------------
+    def fields(self):
+        names = ["u", "v", "w"] + list(self.tracer_names)
+        return dict(zip(names, self.backend.U))
+
+    @property
+    def pressure(self):
+        return self.backend.p
+
+    def set_option(self, key, value):
+        if key == "profile":
+            self.backend.profile = bool(value)
+            self.backend.events, self.backend.n_evals = [], 0
+            return
+        if key == "tendency_impl":
+            if int(value) != 1:
+                raise NotImplementedError("the distributed path always uses the fused tendency kernel")
+            return
+        from .architectures import set_option
+        set_option(key, value)
+
+    def profile_read(self):
+        return self.backend.profile_read()
+
+
+def fill_halo_regions(model, fields, fill_open_bcs=True):
+    """fill_halo_regions! of partitioned fields (halo_communication.jl:87-110): local boundary conditions first
+    (boundary_condition_ordering.jl: DCBC last), then the x exchange."""
+    b, ctx = model.backend, model.ctx
+    b.fill_local_halos(fields, fill_open_bcs)
+    if ctx.world > 1:
+        ws, es, wr, er = b.pack_x(fields)
+        ctx.exchange(ws, es, wr, er)
+        b.unpack_x(fields)
+
+
+def solve_for_pressure(model):
+    """solve_for_pressure! + solve!(::DistributedFFTBasedPoissonSolver) (distributed_fft_based_poisson_solver.jl:141-178)"""
+    b, ctx = model.backend, model.ctx
+    b.source_term()
+    b.poisson_forward_yz()
+    ctx.all_to_all(b.recv, b.send)        # transpose_y_to_x!
+    b.poisson_solve_x()
+    ctx.all_to_all(b.recv, b.send)        # transpose_x_to_y!
+    b.poisson_backward_yz()
+
+
+def update_state(model, compute_tendencies=True):
+    """update_state! (update_nonhydrostatic_model_state.jl:20-56) + compute_tendencies! with the interior / buffer split of
+    interleave_communication_and_computation.jl:9-67 when halos are exchanged asynchronously."""
+    b, ctx = model.backend, model.ctx
+    g = model.grid.local
+    if compute_tendencies and hasattr(b, "n_evals"):
+        b.n_evals += 1
+    if not compute_tendencies or ctx.world == 1 or not model.async_halos or g.Nx <= 2 * g.Hx:
+        fill_halo_regions(model, b.U, fill_open_bcs=False)
+        if compute_tendencies:
+            b.compute_tendencies(None)
+        return
+    # async: start the exchange, compute the interior that does not depend on x halos, finish, compute the two strips
+    b.fill_local_halos(b.U, False)
+    ws, es, wr, er = b.pack_x(b.U)
+    Nx, Ny, Nz, Hx = g.Nx, g.Ny, g.Nz, g.Hx
+    reqs = ctx.exchange_start(ws, es, wr, er)                         # halos fly ...
+    b.compute_tendencies((Hx + 1, Nx - Hx, 1, Ny, 1, Nz))            # ... while the interior is computed (:27-67)
+    ctx.exchange_wait(reqs)                                           # synchronize_communication! (distributed_fields.jl:71-88)
+    b.unpack_x(b.U)                                                   # complete_communication_and_compute_buffer! (:9-20)
+    b.compute_tendencies((1, Hx, 1, Ny, 1, Nz))                       # compute_buffer_tendencies! west strip
+    b.compute_tendencies((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))             # east strip
+
+
+def compute_pressure_correction(model):
+    """compute_pressure_correction! (pressure_correction.jl:8-20)"""
+    b = model.backend
+    fill_halo_regions(model, b.U[:3], fill_open_bcs=True)
+    solve_for_pressure(model)
+    fill_halo_regions(model, [b.p], fill_open_bcs=True)
+
+
+def make_pressure_correction(model, Δt):
+    b = model.backend
+    b.pressure_correction()
+    b.divide_pressure(max(np.finfo(np.float64).eps, Δt))
+
+
+def set_model(model, enforce_incompressibility=True, **kwargs):
+    """set!(model; kwargs...) with LOCAL interior arrays / functions of the local nodes (set_nonhydrostatic_model.jl:33-60)"""
+    flds = model.fields()
+    for name, value in kwargs.items():
+        if name not in flds:
+            raise ValueError(f"name {name} not found in model.velocities or model.tracers.")
+        flds[name].set(value)
+    b = model.backend
+    fill_halo_regions(model, b.U, fill_open_bcs=True)
+    update_state(model, compute_tendencies=False)
+    if enforce_incompressibility:
+        compute_pressure_correction(model)
+        make_pressure_correction(model, 1.0)
+        update_state(model, compute_tendencies=False)
+
+
+def _tick(model, Δt, stage):
+    model.time += Δt
+    if stage:
+        model.stage += 1
+        model.last_stage_Δt = Δt
+    else:
+        model.iteration += 1
+        model.stage = 1
+        model.last_Δt = model.last_stage_Δt = Δt
+
+
+def time_step(model, Δt):
+    """time_step!(model, Δt) for RungeKutta3 (runge_kutta_3.jl:93-170) on the partitioned model"""
+    b = model.backend
+    if model.iteration == 0:
+        update_state(model, True)
+    γ = (RK3["γ1"], RK3["γ2"], RK3["γ3"])
+    ζ = (None, RK3["ζ2"], RK3["ζ3"])
+    stage_dt = (Δt * γ[0], Δt * (γ[1] + ζ[1]), Δt * (γ[2] + ζ[2]))
+    tn1 = model.time + Δt
+    for s in range(3):
+        b.rk3_substep(Δt, γ[s], ζ[s])
+        if s < 2:
+            _tick(model, stage_dt[s], True)
+        else:
+            corrected = tn1 - model.time
+            _tick(model, stage_dt[2], False)
+            model.last_stage_Δt, model.last_Δt = corrected, Δt
+        compute_pressure_correction(model)
+        make_pressure_correction(model, stage_dt[s])
+        if s < 2:
+            b.swap_tendencies()           # cache_previous_tendencies! as a pointer swap (see ocn_api.hip)
+        update_state(model, True)
+
+
+def local_initial_state(model, fn):
+    """evaluate a global initial-state generator on this rank's slab: `fn(ocn, model_like)` is called with an object whose
+    grid.nodes() are the LOCAL node coordinates"""
+    import sys
+    return fn(sys.modules[__name__.rsplit(".", 1)[0]], _LocalView(model))
+
+
+class _LocalView:
+    def __init__(self, model):
+        self.grid = model.grid.local
+        self._model = model
+
+    def fields(self):
+        return self._model.fields()
+
+
+def max_abs_divergence(model):
+    """global max |div u| (test helper)"""
+    b, ctx = model.backend, model.ctx
+    fill_halo_regions(model, b.U[:3], fill_open_bcs=True)
+    if hasattr(b, "max_abs_divergence"):
+        local = b.max_abs_divergence()
+    else:
+        g = model.grid.local
+        u, v, w = (f.parent() for f in b.U[:3])
+        H = g.Hx
+        core = (slice(H, -H),) * 3
+        dx, dy, dz = g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, g.Δzᵃᵃᶜ[0]
+        div = ((u[H + 1:u.shape[0] - H + 1, H:-H, H:-H] - u[core]) / dx + (v[H:-H, H + 1:v.shape[1] - H + 1, H:-H] - v[core]) / dy +
+               (w[H:-H, H:-H, H + 1:w.shape[2] - H + 1] - w[core]) / dz)
+        local = float(np.abs(div).max())
+    return ctx.allreduce_max(local)

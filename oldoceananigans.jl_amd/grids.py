@@ -16,8 +16,13 @@ class Bounded:
     code = 1
 
 
-class Flat:
+class FullyConnected:
+    """a partitioned Periodic direction (distributed_grids.jl:339-346): halos are owned by the neighbouring ranks"""
     code = 2
+
+
+class Flat:
+    code = 3
 
 
 class Center:

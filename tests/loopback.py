@@ -1,0 +1,61 @@
+"""TEST-ONLY in-process 'communicator': R virtual ranks = R Python threads sharing ONE GPU, with the collectives of
+DistributedContext implemented as stream-ordered tensor copies between the ranks' buffers. It exercises the product's
+DeviceBackend (pack / unpack kernels, distributed FFT stages, interior/strip tendency split) on the 1-GPU box, where RCCL
+cannot run two ranks on the same device. The real multi-GPU path differs only in who moves the bytes (RCCL)."""
+import threading
+
+
+class LoopbackWorld:
+    def __init__(self, R, torch, arch):
+        self.R, self.torch, self.arch = R, torch, arch
+        self.barrier_obj = threading.Barrier(R)
+        self.slots = [None] * R
+        self.vals = [0.0] * R
+
+    def context(self, rank):
+        return LoopbackContext(self, rank)
+
+
+class LoopbackContext:
+    def __init__(self, world, rank):
+        self.w = world
+        self.rank, self.world = rank, world.R
+        self.torch, self.arch = world.torch, world.arch
+        self.device = world.torch.device("cuda", 0)
+        self.west, self.east = (rank - 1) % world.R, (rank + 1) % world.R
+
+    def exchange_start(self, ws, es, wr, er):
+        w = self.w
+        w.slots[self.rank] = (ws, es)
+        w.barrier_obj.wait()                 # every rank has SUBMITTED its pack kernel (same stream => ordered)
+        er.copy_(w.slots[self.east][0])      # east neighbour's west slab -> my east halo
+        wr.copy_(w.slots[self.west][1])      # west neighbour's east slab -> my west halo
+        w.barrier_obj.wait()
+        return []
+
+    @staticmethod
+    def exchange_wait(reqs):
+        pass
+
+    def exchange(self, ws, es, wr, er):
+        self.exchange_start(ws, es, wr, er)
+
+    def all_to_all(self, recv, send):
+        w = self.w
+        w.slots[self.rank] = send
+        w.barrier_obj.wait()
+        n = send.numel() // self.world
+        for s in range(self.world):
+            recv[s * n:(s + 1) * n].copy_(w.slots[s][self.rank * n:(self.rank + 1) * n])
+        w.barrier_obj.wait()
+
+    def allreduce_max(self, value):
+        w = self.w
+        w.vals[self.rank] = float(value)
+        w.barrier_obj.wait()
+        m = max(w.vals)
+        w.barrier_obj.wait()
+        return m
+
+    def barrier(self):
+        self.w.barrier_obj.wait()
