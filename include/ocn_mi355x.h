@@ -39,6 +39,7 @@ extern "C" {
 #define OCN_EINVAL (-1)      /* invalid argument (ArgumentError in the reference) */
 #define OCN_ENOTSUP (-2)     /* configuration outside the accelerated hot path */
 #define OCN_ESTATE (-3)      /* call sequence error (e.g. library not initialised) */
+#define OCN_EFFT (-4)        /* an FFT plan failed its creation-time round-trip self-check (rocFFT note) */
 
 typedef struct ocn_grid_s *ocn_grid_t;
 typedef struct ocn_poisson_s *ocn_poisson_t;

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,6 +50,15 @@ static int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail((int)e_, "kernel launch: %s", hipGetErrorString(e_)); \
     } while (0)
 
+// every device allocation of the library goes through here; OCN_POISON=1 fills fresh memory with NaN bytes so that a
+// read of uninitialised device memory shows up as NaN in the parity tests instead of depending on allocator history
+static hipError_t dev_alloc(void **p, size_t bytes) {
+    static const bool poison = getenv("OCN_POISON") != nullptr;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipSuccess && poison) e = hipMemset(*p, 0xFF, bytes);
+    return e;
+}
+
 extern "C" const char *ocn_last_error(void) { return g_err; }
 extern "C" const char *ocn_version(void) { return "ocn_mi355x 0.1 (gfx950; reference Oceananigans v0.100.5)"; }
 
@@ -83,7 +93,7 @@ extern "C" void *ocn_stream(void) { return (void *)g_stream; }
 extern "C" int ocn_malloc(void **ptr, size_t bytes) {
     NEED_INIT();
     if (!ptr) return fail(OCN_EINVAL, "ptr is NULL");
-    HIP_TRY(hipMalloc(ptr, bytes ? bytes : 8));
+    HIP_TRY(dev_alloc(ptr, bytes ? bytes : 8));
     HIP_TRY(hipMemsetAsync(*ptr, 0, bytes ? bytes : 8, g_stream));
     return OCN_OK;
 }
@@ -193,8 +203,8 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
         tab[5 * n + q] = 1.0 / ((dx * dy) * zf);
         tab[6 * n + q] = 1.0 / zf;
     }
-    hipError_t e = hipMalloc((void **)&g->tables, tab.size() * sizeof(double));
-    if (e != hipSuccess) { delete g; return fail((int)e, "hipMalloc(grid tables): %s", hipGetErrorString(e)); }
+    hipError_t e = dev_alloc((void **)&g->tables, tab.size() * sizeof(double));
+    if (e != hipSuccess) { delete g; return fail((int)e, "dev_alloc(grid tables): %s", hipGetErrorString(e)); }
     e = hipMemcpy(g->tables, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(g->tables); delete g; return fail((int)e, "hipMemcpy(grid tables): %s", hipGetErrorString(e)); }
     D.dzc = g->tables; D.dzf = g->tables + n; D.ax = g->tables + 2 * n; D.ay = g->tables + 3 * n;
@@ -531,6 +541,97 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
     return OCN_OK;
 }
 
+// ---- FFT plan self-checks -------------------------------------------------------------------------------------------
+// rocFFT (7.0 and 7.2 tested) can return WRONG transforms from a freshly created plan while plans of other sizes are alive
+// in the process (tools/fft_real_test2.hip reproduces it without this library: e.g. a 64x16x8 real 3-D plan created while
+// 32^3 / 16^3 plans exist). Every plan set is therefore verified once, at creation, by a round trip on a pseudo-random
+// pattern; a solver whose plans fail the check is refused (OCN_EFFT) instead of silently producing wrong pressure.
+static int reduce_blockmax(double *d_blockmax, int nb, double *out) {
+    std::vector<double> h(nb);
+    HIP_TRY(hipMemcpyAsync(h.data(), d_blockmax, nb * sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    double m = 0;
+    for (double x : h) m = (x > m || x != x) ? x : m;
+    *out = m;
+    return OCN_OK;
+}
+
+static int verify_real_plans(ocn_poisson_s *s) {
+    const DGrid &g = s->grid->d;
+    const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
+    const long n = (long)s->n;
+    const int nb = 256;
+    double *tmp = nullptr, *bm = nullptr;
+    HIP_TRY(dev_alloc((void **)&bm, nb * sizeof(double)));
+    hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, s->rrhs, n);
+    hipfftResult r = hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)s->hc);
+    const double scale = s->kind == 0 ? 1.0 / ((double)g.Nx * g.Ny * g.Nz) : 1.0 / ((double)g.Nx * g.Ny);
+    if (r == HIPFFT_SUCCESS) {
+        if (s->c2r_strided) {
+            hipError_t e = dev_alloc((void **)&tmp, (size_t)Px * Py * Pz * sizeof(double));
+            if (e != hipSuccess) { hipFree(bm); return fail((int)e, "self-check allocation: %s", hipGetErrorString(e)); }
+            r = hipfftExecZ2D(s->plan_c2r, (hipfftDoubleComplex *)s->hc, tmp + g.Hx + (size_t)Px * (g.Hy + (size_t)Py * g.Hz));
+            hipLaunchKernelGGL(selfcheck_compare_real, dim3(nb), dim3(256), 0, g_stream, tmp, g.Nx, g.Ny, g.Nz, Px, Py, g.Hx, g.Hy, g.Hz, scale, bm);
+        } else {
+            r = hipfftExecZ2D(s->plan_c2r, (hipfftDoubleComplex *)s->hc, s->rrhs);
+            hipLaunchKernelGGL(selfcheck_compare_real, dim3(nb), dim3(256), 0, g_stream, s->rrhs, g.Nx, g.Ny, g.Nz, g.Nx, g.Ny, 0, 0, 0, scale, bm);
+        }
+    }
+    double err = 0;
+    int rc = r == HIPFFT_SUCCESS ? reduce_blockmax(bm, nb, &err) : fail(1000 + (int)r, "hipFFT exec failed in the plan self-check (%d)", (int)r);
+    hipFree(tmp); hipFree(bm);
+    if (rc) return rc;
+    if (!(err < 1e-10))
+        return fail(OCN_EFFT, "rocFFT self-check failed for the %dx%dx%d real transform pair (round-trip error %.3g): rocFFT returns wrong "
+                              "results from this plan while plans of other sizes are alive in the process; destroy the other "
+                              "models/solvers first", g.Nx, g.Ny, g.Nz, err);
+    return OCN_OK;
+}
+
+static int verify_complex_plan(hipfftHandle plan, double2 *buf, long n, double scale, const char *what) {
+    const int nb = 256;
+    double *bm = nullptr;
+    HIP_TRY(dev_alloc((void **)&bm, nb * sizeof(double)));
+    hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, buf, n);
+    hipfftResult r = hipfftExecZ2Z(plan, (hipfftDoubleComplex *)buf, (hipfftDoubleComplex *)buf, HIPFFT_FORWARD);
+    if (r == HIPFFT_SUCCESS) r = hipfftExecZ2Z(plan, (hipfftDoubleComplex *)buf, (hipfftDoubleComplex *)buf, HIPFFT_BACKWARD);
+    hipLaunchKernelGGL(selfcheck_compare_complex, dim3(nb), dim3(256), 0, g_stream, buf, n, scale, bm);
+    double err = 0;
+    int rc = r == HIPFFT_SUCCESS ? reduce_blockmax(bm, nb, &err) : fail(1000 + (int)r, "hipFFT exec failed in the plan self-check (%d)", (int)r);
+    hipFree(bm);
+    if (rc) return rc;
+    if (!(err < 1e-10))
+        return fail(OCN_EFFT, "rocFFT self-check failed for the %s plan (round-trip error %.3g): rocFFT returns wrong results from this "
+                              "plan while plans of other sizes are alive in the process; destroy the other models/solvers first", what, err);
+    HIP_TRY(hipMemsetAsync(buf, 0, n * sizeof(double2), g_stream));
+    return OCN_OK;
+}
+
+// complex-to-complex resources of the reference's API (solve!(ϕ, solver, b) with a complex b): created on first use so
+// that the model fast path keeps only its two real plans alive
+static int ensure_complex(ocn_poisson_s *s) {
+    if (s->has_plan) return OCN_OK;
+    const DGrid &g = s->grid->d;
+    HIP_TRY(dev_alloc((void **)&s->storage, s->n * sizeof(double2)));
+    HIP_TRY(hipMemsetAsync(s->storage, 0, s->n * sizeof(double2), g_stream));
+    hipfftResult r;
+    if (s->kind == 0) {
+        r = hipfftPlan3d(&s->plan, g.Nz, g.Ny, g.Nx, HIPFFT_Z2Z);
+    } else {
+        HIP_TRY(dev_alloc((void **)&s->source, s->n * sizeof(double2)));
+        HIP_TRY(hipMemsetAsync(s->source, 0, s->n * sizeof(double2), g_stream));
+        HIP_TRY(dev_alloc((void **)&s->partial, 1024 * sizeof(double2)));
+        HIP_TRY(dev_alloc((void **)&s->mean, sizeof(double2)));
+        int nfft[2] = {g.Ny, g.Nx};
+        r = hipfftPlanMany(&s->plan, 2, nfft, nullptr, 1, g.Nx * g.Ny, nullptr, 1, g.Nx * g.Ny, HIPFFT_Z2Z, g.Nz);
+    }
+    if (r != HIPFFT_SUCCESS) return fail(1000 + (int)r, "hipfftPlan (Z2Z) failed (%d)", (int)r);
+    s->has_plan = true;
+    FFT_TRY(hipfftSetStream(s->plan, g_stream));
+    const double scale = s->kind == 0 ? 1.0 / ((double)g.Nx * g.Ny * g.Nz) : 1.0 / ((double)g.Nx * g.Ny);
+    return verify_complex_plan(s->plan, s->storage, (long)s->n, scale, "complex-to-complex");
+}
+
 // FFT plans capture a stream at creation; re-point them when the library stream changed (ocn_set_stream)
 static int plan_set_stream(hipfftHandle plan) {
     FFT_TRY(hipfftSetStream(plan, g_stream));
@@ -560,29 +661,19 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
         if (e_ != hipSuccess) { rc = fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); goto bad; }   \
     } while (0)
     {
-        TRY_OR_FREE(hipMalloc((void **)&s->storage, s->n * sizeof(double2)));
-        TRY_OR_FREE(hipMemset(s->storage, 0, s->n * sizeof(double2)));
         const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
         std::vector<double> lam[3];
         for (int d = 0; d < 3; ++d) {
             poisson_eigenvalues(N[d], grid->L[d], T[d], lam[d]);
-            TRY_OR_FREE(hipMalloc((void **)&s->lam[d], N[d] * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->lam[d], N[d] * sizeof(double)));
             TRY_OR_FREE(hipMemcpy(s->lam[d], lam[d].data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
         }
-        if (kind == 0) {
-            hipfftResult r = hipfftPlan3d(&s->plan, g.Nz, g.Ny, g.Nx, HIPFFT_Z2Z);
-            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlan3d failed (%d)", (int)r); goto bad; }
-            s->has_plan = true;
-        } else {
+        if (kind == 1) {
             // fourier_tridiagonal_poisson_solver.jl:75-134; diagonals :180-210 (HomogeneousZFormulation), host-built
-            TRY_OR_FREE(hipMalloc((void **)&s->source, s->n * sizeof(double2)));
-            TRY_OR_FREE(hipMemset(s->source, 0, s->n * sizeof(double2)));
-            TRY_OR_FREE(hipMalloc((void **)&s->D, s->n * sizeof(double)));
-            TRY_OR_FREE(hipMalloc((void **)&s->t, s->n * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->D, s->n * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->t, s->n * sizeof(double)));
             TRY_OR_FREE(hipMemset(s->t, 0, s->n * sizeof(double)));
-            TRY_OR_FREE(hipMalloc((void **)&s->lower, std::max(1, g.Nz - 1) * sizeof(double)));
-            TRY_OR_FREE(hipMalloc((void **)&s->partial, 1024 * sizeof(double2)));
-            TRY_OR_FREE(hipMalloc((void **)&s->mean, sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->lower, std::max(1, g.Nz - 1) * sizeof(double)));
             const int Nx = g.Nx, Ny = g.Ny, Nz = g.Nz, Hz = g.Hz;
             auto dzf = [&](int k) { return grid->h_dzf[k - 1 + Hz]; };
             auto dzc = [&](int k) { return grid->h_dzc[k - 1 + Hz]; };
@@ -598,20 +689,15 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             for (int q = 1; q <= Nz - 1; ++q) lower[q - 1] = 1.0 / dzf(q + 1);
             TRY_OR_FREE(hipMemcpy(s->D, D.data(), s->n * sizeof(double), hipMemcpyHostToDevice));
             TRY_OR_FREE(hipMemcpy(s->lower, lower.data(), lower.size() * sizeof(double), hipMemcpyHostToDevice));
-            int nfft[2] = {g.Ny, g.Nx};
-            hipfftResult r = hipfftPlanMany(&s->plan, 2, nfft, nullptr, 1, g.Nx * g.Ny, nullptr, 1, g.Nx * g.Ny, HIPFFT_Z2Z, g.Nz);
-            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany failed (%d)", (int)r); goto bad; }
-            s->has_plan = true;
         }
-        hipfftResult r = hipfftSetStream(s->plan, g_stream);
-        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r); goto bad; }
-        // ---- real-transform path ----
+        hipfftResult r;
+        // ---- real-transform path (the complex-to-complex resources of the reference API are created on first use) ----
         s->Nxh = g.Nx / 2 + 1;
         s->nh = (size_t)s->Nxh * g.Ny * g.Nz;
-        TRY_OR_FREE(hipMalloc((void **)&s->rrhs, s->n * sizeof(double)));
-        TRY_OR_FREE(hipMalloc((void **)&s->hc, s->nh * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->rrhs, s->n * sizeof(double)));
+        TRY_OR_FREE(dev_alloc((void **)&s->hc, s->nh * sizeof(double2)));
         if (kind == 1) {
-            TRY_OR_FREE(hipMalloc((void **)&s->hc2, s->nh * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->hc2, s->nh * sizeof(double2)));
             TRY_OR_FREE(hipMemset(s->hc2, 0, s->nh * sizeof(double2)));
         }
         const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
@@ -642,6 +728,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r);
             goto bad;
         }
+        if ((rc = verify_real_plans(s))) goto bad;
     }
     *solver = s;
     return OCN_OK;
@@ -655,12 +742,15 @@ extern "C" int ocn_poisson_kind(ocn_poisson_t s) { return s ? s->kind : OCN_EINV
 
 extern "C" int ocn_poisson_rhs(ocn_poisson_t s, double **rhs_complex) {
     if (!s || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
+    NEED_INIT();
+    { int rc_ = ensure_complex(s); if (rc_) return rc_; }
     *rhs_complex = (double *)(s->kind == 0 ? s->storage : s->source);
     return OCN_OK;
 }
 
 static int poisson_solve(ocn_poisson_s *s, double *phi) {
     const DGrid &g = s->grid->d;
+    { int rc_ = ensure_complex(s); if (rc_) return rc_; }
     FView vphi = make_view(g, phi, LOC_C);
     { int rc_ = plan_set_stream(s->plan); if (rc_) return rc_; }
     if (s->kind == 0) {
@@ -730,6 +820,7 @@ static int solve_for_pressure(ocn_poisson_s *s, const double *u, const double *v
         if ((rc = source_term(g, u, v, w, s->rrhs, s->kind == 1, true))) return rc;
         return poisson_solve_real(s, p);
     }
+    if ((rc = ensure_complex(s))) return rc;
     if ((rc = source_term(g, u, v, w, s->kind == 0 ? s->storage : s->source, s->kind == 1))) return rc;
     return poisson_solve(s, p);
 }
@@ -838,14 +929,14 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if (e_ != hipSuccess) { rc = fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); goto bad; }   \
     } while (0)
     {
-        TRY_OR_FREE(hipMalloc((void **)&s->zfield, s->n * sizeof(double2)));
-        TRY_OR_FREE(hipMalloc((void **)&s->xfield, s->n * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->zfield, s->n * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->xfield, s->n * sizeof(double2)));
         const int N[3] = {s->Nxg, s->Ny, s->Nz};
         const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
         for (int d = 0; d < 3; ++d) {
             std::vector<double> lam;
             poisson_eigenvalues(N[d], L[d], OCN_PERIODIC, lam);
-            TRY_OR_FREE(hipMalloc((void **)&s->lam[d], N[d] * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->lam[d], N[d] * sizeof(double)));
             TRY_OR_FREE(hipMemcpy(s->lam[d], lam.data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
         }
         // (y, z) transform of the x-fastest local block: element stride Nxl along y, one batch entry per local i
@@ -858,6 +949,9 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyl * s->Nz);
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
         s->has_x = true;
+        if ((rc = plan_set_stream(s->plan_yz)) || (rc = plan_set_stream(s->plan_x))) goto bad;
+        if ((rc = verify_complex_plan(s->plan_yz, s->zfield, (long)s->n, 1.0 / ((double)s->Ny * s->Nz), "distributed (y, z)"))) goto bad;
+        if ((rc = verify_complex_plan(s->plan_x, s->xfield, (long)s->n, 1.0 / (double)s->Nxg, "distributed x"))) goto bad;
     }
     *solver = s;
     return OCN_OK;
@@ -977,8 +1071,8 @@ extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracer
         int P[3];
         parent_size(grid->d, loc, P);
         size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
-        hipError_t e = hipMalloc((void **)p, bytes);
-        if (e != hipSuccess) return fail((int)e, "hipMalloc(field): %s", hipGetErrorString(e));
+        hipError_t e = dev_alloc((void **)p, bytes);
+        if (e != hipSuccess) return fail((int)e, "dev_alloc(field): %s", hipGetErrorString(e));
         e = hipMemsetAsync(*p, 0, bytes, g_stream);
         if (e != hipSuccess) return fail((int)e, "hipMemset(field): %s", hipGetErrorString(e));
         return OCN_OK;
@@ -992,7 +1086,7 @@ extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracer
     }
     if (!rc) rc = alloc(&m->p, LOC_C);
     if (!rc) {
-        hipError_t e = hipMalloc((void **)&m->blockmax, 1024 * sizeof(double));
+        hipError_t e = dev_alloc((void **)&m->blockmax, 1024 * sizeof(double));
         if (e != hipSuccess) rc = fail((int)e, "hipMalloc: %s", hipGetErrorString(e));
     }
     if (!rc) rc = ocn_poisson_create(&m->solver, grid, -1);
@@ -1196,7 +1290,7 @@ extern "C" int ocn_debug_rcp_check(int variant, int exponent, unsigned long long
     NEED_INIT();
     if (!mismatches || exponent < -120 || exponent > 120) return fail(OCN_EINVAL, "invalid argument");
     unsigned long long *d;
-    HIP_TRY(hipMalloc((void **)&d, 8));
+    HIP_TRY(dev_alloc((void **)&d, 8));
     HIP_TRY(hipMemsetAsync(d, 0, 8, g_stream));
     const int eb = exponent + 127;
     if (variant == 1) hipLaunchKernelGGL(rcp_check_kernel<1>, dim3((1u << 23) / 256), dim3(256), 0, g_stream, eb, d);
@@ -1214,7 +1308,7 @@ extern "C" int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const do
     const DGrid &g = grid->d;
     const int nb = 1024;
     double *blockmax;
-    HIP_TRY(hipMalloc((void **)&blockmax, nb * sizeof(double)));
+    HIP_TRY(dev_alloc((void **)&blockmax, nb * sizeof(double)));
     hipLaunchKernelGGL(max_abs_div_kernel, dim3(nb), dim3(256), 0, g_stream, g, make_view(g, u, LOC_U), make_view(g, v, LOC_V),
                        make_view(g, w, LOC_W), blockmax);
     std::vector<double> h(nb);

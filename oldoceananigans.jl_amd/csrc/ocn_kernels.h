@@ -457,3 +457,55 @@ __global__ void __launch_bounds__(256) dist_spectral_divide_kernel(double2 *b, c
     if (i == 0 && joff + j == 0 && k == 0) { val.x = 0.0; val.y = 0.0; }
     b[q] = val;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FFT plan self-check (see ocn_api.hip: verify_*): deterministic pseudo-random pattern, round trip, compare
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double selfcheck_pattern(long q) {
+    unsigned h = (unsigned)(q * 2654435761u + 12345u);
+    h ^= h >> 13; h *= 0x5bd1e995u; h ^= h >> 15;
+    return (double)(h & 0xFFFFFu) / 1048576.0 - 0.5;
+}
+__global__ void __launch_bounds__(256) selfcheck_fill_real(double *x, long n) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) x[q] = selfcheck_pattern(q);
+}
+__global__ void __launch_bounds__(256) selfcheck_fill_complex(double2 *x, long n) {
+    long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) x[q] = make_double2(selfcheck_pattern(q), selfcheck_pattern(q + n));
+}
+// max |out * scale - pattern| over the dense index space; `out` is either dense (P == N, H == 0) or the interior of a haloed array
+__global__ void __launch_bounds__(256) selfcheck_compare_real(const double *out, int Nx, int Ny, int Nz, int Px, int Py, int Hx, int Hy,
+                                                              int Hz, double scale, double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    const long n = (long)Nx * Ny * Nz;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        int i = q % Nx, j = (q / Nx) % Ny, k = q / ((long)Nx * Ny);
+        double v = out[(long)(i + Hx) + (long)Px * ((j + Hy) + (long)Py * (k + Hz))];
+        double d = fabs(v * scale - selfcheck_pattern(q));
+        m = (d > m || d != d) ? d : m;
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { double o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x] || o != o) sm[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}
+__global__ void __launch_bounds__(256) selfcheck_compare_complex(const double2 *out, long n, double scale, double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) {
+        double d = fmax(fabs(out[q].x * scale - selfcheck_pattern(q)), fabs(out[q].y * scale - selfcheck_pattern(q + n)));
+        m = (d > m || d != d) ? d : m;
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { double o = sm[threadIdx.x + s]; if (o > sm[threadIdx.x] || o != o) sm[threadIdx.x] = o; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}

@@ -265,6 +265,17 @@ class DeviceBackend:
     def synchronize(self):
         self.ctx.torch.cuda.current_stream().synchronize()
 
+    def close(self):
+        if getattr(self, "solver", None) is not None:
+            _lib.lib().ocn_dist_poisson_destroy(self.solver)
+            self.solver = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 # ----------------------------------------------------------------------------------------------------------------------
 # model + time stepping (backend-agnostic orchestration)

@@ -18,7 +18,7 @@ class Field:
         self.loc = tuple(loc)
         self.shape = grid.total_size(self.loc)
         self.nbytes = int(np.prod(self.shape)) * 8
-        self._owner = owner
+        self._owner = None   # views into a model's memory do NOT keep the model alive (no reference cycles)
         if data is None:
             p = C.c_void_p()
             _lib.check(_lib.lib().ocn_malloc(C.byref(p), self.nbytes))   # zeros(arch, FT, sz...)

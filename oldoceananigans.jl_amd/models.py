@@ -2,6 +2,7 @@
 src/TimeSteppers/runge_kutta_3.jl:93-170). The whole time-step runs inside libocn_mi355x.so (`ocn_model_time_step`);
 this module is the host-side mirror of the reference's API."""
 import ctypes as C
+import weakref
 from collections import namedtuple
 
 from . import _lib
@@ -11,14 +12,18 @@ from .grids import Center, Face
 
 
 class Clock:
-    """TimeSteppers/clock.jl:39-45 (read-only view of the library's clock)"""
+    """TimeSteppers/clock.jl:39-45 (read-only view of the library's clock). Holds a WEAK reference to its model: no reference
+    cycle, so a model is destroyed (and its FFT plans released) as soon as the last user reference goes away."""
 
     def __init__(self, model):
-        self._model = model
+        self._model = weakref.ref(model)
 
     def _get(self):
+        model = self._model()
+        if model is None or model.handle is None:
+            raise _lib.OcnError("the model of this clock has been destroyed")
         t, it, st, ldt, lsdt = C.c_double(), C.c_int64(), C.c_int(), C.c_double(), C.c_double()
-        _lib.check(_lib.lib().ocn_model_clock(self._model.handle, C.byref(t), C.byref(it), C.byref(st), C.byref(ldt),
+        _lib.check(_lib.lib().ocn_model_clock(model.handle, C.byref(t), C.byref(it), C.byref(st), C.byref(ldt),
                                               C.byref(lsdt)))
         return t.value, it.value, st.value, ldt.value, lsdt.value
 
@@ -64,7 +69,7 @@ class NonhydrostaticModel:
     def _field(self, cname):
         p, loc = C.c_void_p(), (C.c_int * 3)()
         _lib.check(_lib.lib().ocn_model_field(self.handle, cname.encode(), C.byref(p), loc))
-        return Field(tuple(Face if l else Center for l in loc), self.grid, data=p, owner=self)
+        return Field(tuple(Face if l else Center for l in loc), self.grid, data=p)   # a VIEW: valid while the model lives
 
     def tendency(self, name, previous=False):
         """timestepper.Gⁿ[name] / G⁻[name]; pointers are stable at time-step boundaries."""
@@ -91,9 +96,15 @@ class NonhydrostaticModel:
         _lib.check(_lib.lib().ocn_model_profile_read(self.handle, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def close(self):
+        """release the model's device memory and FFT plans now (also called by the destructor)"""
+        if getattr(self, "handle", None) is not None:
+            _lib.lib().ocn_model_destroy(self.handle)
+            self.handle = None
+
     def __del__(self):
         try:
-            _lib.lib().ocn_model_destroy(self.handle)
+            self.close()
         except Exception:
             pass
 

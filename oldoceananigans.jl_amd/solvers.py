@@ -16,9 +16,6 @@ class _PoissonSolver:
         h = C.c_void_p()
         _lib.check(_lib.lib().ocn_poisson_create(C.byref(h), grid.handle, self.kind))
         self.handle = h
-        p = C.c_void_p()
-        _lib.check(_lib.lib().ocn_poisson_rhs(self.handle, C.byref(p)))
-        self.storage_ptr = p
 
     @property
     def architecture(self):
@@ -29,11 +26,18 @@ class _PoissonSolver:
         a = np.asfortranarray(rhs, dtype=np.complex128)
         if a.shape != self.grid.size:
             raise ValueError(f"source term shape {a.shape} != {self.grid.size}")
-        _lib.check(_lib.lib().ocn_memcpy_h2d(self.storage_ptr, a.ctypes.data, a.nbytes))
+        p = C.c_void_p()
+        _lib.check(_lib.lib().ocn_poisson_rhs(self.handle, C.byref(p)))     # creates the complex storage on first use
+        _lib.check(_lib.lib().ocn_memcpy_h2d(p, a.ctypes.data, a.nbytes))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            _lib.lib().ocn_poisson_destroy(self.handle)
+            self.handle = None
 
     def __del__(self):
         try:
-            _lib.lib().ocn_poisson_destroy(self.handle)
+            self.close()
         except Exception:
             pass
 

@@ -6,7 +6,8 @@ import pytest
 # torch bundles its own ROCm user-space (libamdhip64.so.7, hipfft, rccl ...) under the same sonames as /opt/rocm. Whoever is
 # loaded first wins for the whole process, and torch cannot initialise its GPU runtime on top of the system one -- so in
 # any process that uses torch on the GPU (the distributed path), torch must be imported BEFORE libocn_mi355x.so is loaded.
-import torch  # noqa: F401,E402
+if os.environ.get("OCN_TEST_NO_TORCH") != "1":
+    import torch  # noqa: F401,E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:

@@ -1,0 +1,105 @@
+"""CPU tests of the drop-in boundary and the host-side mirror (no compute calls: there is no GPU here):
+  * libocn_mi355x.so loads and exports EVERY symbol include/ocn_mi355x.h declares (and the binding table covers them all);
+  * the product fails LOUDLY without a GPU / without the extension (no CPU fallback);
+  * host logic: grid generation (product, Fraction arithmetic) against the oracle's independent restatement (Decimal),
+    field shapes, argument validation mirroring the reference's ArgumentErrors."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import tanh_faces
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ocn_mi355x.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocn_[A-Za-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from oldoceananigans_jl_amd import _lib
+    names = _declared_symbols()
+    assert len(names) > 40
+    lib = C.CDLL(_lib.SO_PATH)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    unbound = [n for n in names if n not in _lib.SYMBOLS]
+    assert not unbound, f"declared in the header but not bound in _lib.SYMBOLS: {unbound}"
+    undeclared = [n for n in _lib.SYMBOLS if n not in names]
+    assert not undeclared, f"bound but not declared in the header: {undeclared}"
+    _lib.lib()      # resolves restype/argtypes for every symbol
+
+
+def test_product_fails_loudly_without_a_gpu():
+    import oldoceananigans_jl_amd as ocn
+    from oldoceananigans_jl_amd import _lib
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    with pytest.raises(ocn.OcnError):
+        ocn.GPU(0)
+    # entry points refuse to run before ocn_init (status OCN_ESTATE = -3), they never fall back to a CPU path
+    p = C.c_void_p()
+    assert _lib.lib().ocn_malloc(C.byref(p), 8) == -3
+    assert b"ocn_init" in _lib.lib().ocn_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: no file of the product package may import, link or call it"""
+    pkg = os.path.join(ROOT, "oldoceananigans.jl_amd")
+    pattern = re.compile(r"^\s*(from|import)\s+oracle\b|libocn_oracle|\boro_[a-z]|ocn_oracle\.h", flags=re.M)
+    checked = 0
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".sh")):
+                checked += 1
+                assert not pattern.search(open(os.path.join(dirpath, f)).read()), f
+    assert checked >= 10
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# host logic
+# ---------------------------------------------------------------------------------------------------------------------
+def test_regular_spacing_matches_oracle_restatement(oracle):
+    from oldoceananigans_jl_amd.grids import _regular_coordinate
+    for interval, N in (((0.0, 1.0), 256), ((-1.0, 0.0), 128), ((0.0, 2 * np.pi), 67), ((0.3, 1.7), 11), ((0.0, 1.0), 3)):
+        d1, L1, _ = _regular_coordinate(interval, N, "x")
+        d2, L2 = oracle.regular_spacing(interval, N)
+        assert d1 == d2 and L1 == L2
+    with pytest.raises(ValueError):
+        _regular_coordinate((1.0, 0.0), 4, "x")
+
+
+def test_stretched_spacings_match_oracle_restatement(oracle):
+    from oldoceananigans_jl_amd.grids import _stretched_coordinate
+    for N in (8, 16, 33):
+        faces = tanh_faces(N)
+        L1, F, Cn, dzc, dzf = _stretched_coordinate(faces, N, 3, True, "z")
+        L2, dc, df = oracle.stretched_spacings(faces, N, 3, True)
+        assert L1 == L2 and np.array_equal(dzc, dc) and np.array_equal(dzf, df)
+        # Δzᶜ[k] = F[k+1] - F[k] on the interior; Δzᶠ[k] = C[k] - C[k-1]; Bounded halos repeat the end spacings
+        assert np.allclose(dzc[3:3 + N], np.diff(faces), rtol=0, atol=1e-16)
+        assert dzc[0] == dzc[3] and dzc[N + 5] == dzc[N + 2]
+    with pytest.raises(ValueError):
+        _stretched_coordinate(faces[::-1], N, 3, True, "z")
+
+
+def test_weno_descriptor_validation():
+    import oldoceananigans_jl_amd as ocn
+    assert "WENO{3, Float64, Float32}(order=5)" in repr(ocn.WENO())          # weno_reconstruction.jl:53-57
+    with pytest.raises(ValueError):
+        ocn.WENO(order=4)                                                    # "defined only for odd orders"
+    with pytest.raises(NotImplementedError):
+        ocn.WENO(order=7)
+
+
+def test_partition_coordinate_is_contiguous():
+    from oldoceananigans_jl_amd.distributed import partition_coordinate
+    for R in (2, 4, 8):
+        pieces = [partition_coordinate((0.0, float(R)), 64, R, r) for r in range(R)]
+        assert pieces[0][0] == 0.0 and pieces[-1][1] == float(R)
+        assert all(a[1] == b[0] for a, b in zip(pieces[:-1], pieces[1:]))

@@ -1,0 +1,296 @@
+"""CPU tests that PIN THE ORACLE with the reference's own data-free tests and docstring KATs -- the oracle is
+"parity unpinned" against Julia output (no Julia here, regression data are remote DataDeps), so these properties are what
+anchors it. Each test names the reference test it restates."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import tanh_faces
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P, B = 0, 1
+
+
+def dptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# coefficients (Advection/reconstruction_coefficients.jl docstrings)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_coefficient_kats_and_header_is_current():
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_coefficients.py")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+    assert res.stdout == open(os.path.join(ROOT, "include", "ocn_weno_coeffs.h")).read()
+
+
+def test_rk3_stage_fractions_sum_to_one():
+    """runge_kutta_3.jl:69-78,176-177"""
+    g1, g2, g3, z2, z3 = 8 / 15, 5 / 12, 3 / 4, -17 / 60, -5 / 12
+    assert abs(g1 + (g2 + z2) + (g3 + z3) - 1) < 1e-15
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# WENO reconstruction (Advection/weno_interpolants.jl)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_newton_div_is_a_double_precision_quotient(oracle):
+    rng = np.random.default_rng(0)
+    a, b = rng.random(1000) * 10, rng.random(1000) * 10 + 1e-8
+    got = np.array([oracle.lib().oro_newton_div_f32(x, y) for x, y in zip(a, b)])
+    assert np.max(np.abs(got - a / b) / (a / b)) < 1e-13        # Float32 reciprocal + one Newton step (newton_div.jl:8-20)
+
+
+def test_weno5_exact_for_quadratics_and_mirror_symmetric(oracle):
+    L = oracle.lib()
+    x = np.arange(-3, 3) + 0.5
+    S = (1 + 2 * x + 3 * (x * x + 1 / 12)).astype(np.float64)      # cell averages of 1 + 2x + 3x^2, face at x = 0
+    for left in (1, 0):
+        assert abs(L.oro_weno5_biased(dptr(S), left) - 1.0) < 1e-14
+    rng = np.random.default_rng(1)
+    for _ in range(100):
+        S = rng.standard_normal(6)
+        R = np.ascontiguousarray(S[::-1])
+        # right-biased reconstruction == left-biased reconstruction of the mirrored stencil (S₀₃..S₂₃, :435-437)
+        assert L.oro_weno5_biased(dptr(S), 0) == L.oro_weno5_biased(dptr(R), 1)
+    S4 = rng.standard_normal(4)
+    assert L.oro_weno3_biased(dptr(S4), 0) == L.oro_weno3_biased(dptr(np.ascontiguousarray(S4[::-1])), 1)
+
+
+def test_weno5_fifth_order_on_smooth_data(oracle):
+    L = oracle.lib()
+    errs = []
+    for n in (16, 32, 64, 128):
+        h = 1.0 / n
+        xs = (np.arange(-3, 3) + 0.5) * h + 0.3
+        S = (np.cos(2 * np.pi * (xs - h / 2)) - np.cos(2 * np.pi * (xs + h / 2))) / (2 * np.pi * h)   # cell averages of sin
+        errs.append(abs(L.oro_weno5_biased(dptr(S), 1) - np.sin(2 * np.pi * 0.3)))
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert rates[-1] > 4.7, rates          # expected 2K-1 = 5 (validation/convergence_tests/one_dimensional_advection_schemes.jl:56-58)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# halo regions (test/test_halo_regions.jl:22-41)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [(8, 8, 8), (3, 8, 8), (8, 3, 8), (8, 8, 3)])
+def test_periodic_and_no_flux_halos_are_exact(oracle, N):
+    rng = np.random.default_rng(2)
+    for topo in ((P, P, P), (P, P, B), (B, B, B)):
+        g = oracle.Grid(N, topology=topo)
+        a = g.zeros(oracle.LOC["c"])
+        g.interior_cells(a)[...] = rng.standard_normal(N)
+        g.fill_halo_regions(a, oracle.LOC["c"])
+        H = 3
+        for d in range(3):
+            sl = lambda s: tuple(s if q == d else slice(H, -H) for q in range(3))   # noqa: E731
+            if topo[d] == P:
+                assert np.array_equal(a[sl(slice(0, H))], a[sl(slice(N[d], N[d] + H))])
+                assert np.array_equal(a[sl(slice(N[d] + H, N[d] + 2 * H))], a[sl(slice(H, 2 * H))])
+            else:       # no-flux: c[0] == c[1], c[N+1] == c[N]
+                assert np.array_equal(a[sl(slice(H - 1, H))], a[sl(slice(H, H + 1))])
+                assert np.array_equal(a[sl(slice(N[d] + H, N[d] + H + 1))], a[sl(slice(N[d] + H - 1, N[d] + H))])
+
+
+def test_impenetrable_walls_and_fill_open_bcs_flag(oracle):
+    g = oracle.Grid((6, 5, 4), topology=(P, P, B))
+    w = g.zeros(oracle.LOC["w"])
+    assert w.shape == (12, 11, 11)                 # Face field on a Bounded dim has N+1 interior points (grid_utils.jl:66-72)
+    w[...] = 1.0
+    g.fill_halo_regions(w, oracle.LOC["w"], fill_open_bcs=False)
+    assert np.all(w[3:-3, 3:-3, 3] == 1.0)
+    g.fill_halo_regions(w, oracle.LOC["w"], fill_open_bcs=True)
+    assert np.all(w[:, :, 3] == 0.0) and np.all(w[:, :, 3 + 4] == 0.0)      # wall faces k = 1 and k = Nz+1, x/y halos included
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Poisson solvers (test/test_poisson_solvers.jl:58-108, dependencies_for_poisson_solvers.jl:111-173,195-220)
+# ---------------------------------------------------------------------------------------------------------------------
+def _laplacian(g, p):
+    """∇²p on the interior with the grid's own spacings: (δ(δp/Δᶠ))/Δᶜ per direction"""
+    H = 3
+    out = 0.0
+    for ax in range(3):
+        n = g.N[ax]
+        other = tuple(slice(H, -H) if q != ax else slice(None) for q in range(3))
+        a = p[other]
+        lo, mid, hi = (np.take(a, range(H - 1 + s, H - 1 + s + n), axis=ax) for s in (0, 1, 2))
+        shp = [1, 1, 1]
+        shp[ax] = n
+        dc = np.asarray(g.dc[ax][H:H + n]).reshape(shp)          # Δᶜ at cells 1..N   (array position idx-1+H)
+        dfl = np.asarray(g.df[ax][H:H + n]).reshape(shp)         # Δᶠ at faces 1..N
+        dfh = np.asarray(g.df[ax][H + 1:H + 1 + n]).reshape(shp)  # Δᶠ at faces 2..N+1
+        out = out + ((hi - mid) / dfh - (mid - lo) / dfl) / dc
+    return out
+
+
+def _random_divergence_free_test(oracle, g, solver_kind):
+    """∇²ϕ ≈ ∇·U for random U with impenetrable walls"""
+    rng = np.random.default_rng(3)
+    u, v, w = (g.zeros(oracle.LOC[k]) for k in "uvw")
+    for a, k in ((u, "u"), (v, "v"), (w, "w")):
+        view = g.interior(a, oracle.LOC[k])
+        view[...] = rng.standard_normal(view.shape)
+        g.fill_halo_regions(a, oracle.LOC[k])
+    R = g.source_term(u, v, w, weight_by_dz=False).real.copy()
+    s = oracle.PoissonSolver(g, solver_kind)
+    s.rhs[...] = g.source_term(u, v, w, weight_by_dz=(solver_kind == 1))
+    p = g.zeros(oracle.LOC["c"])
+    s.solve(p)
+    g.fill_halo_regions(p, oracle.LOC["c"])
+    lap = _laplacian(g, p)
+    assert np.allclose(lap, R, atol=1e-10 * max(1.0, np.abs(R).max())), np.abs(lap - R).max()
+
+
+@pytest.mark.parametrize("topo", [(P, P, P), (P, P, B), (P, B, B), (B, B, B), (B, P, P), (P, B, P)])
+@pytest.mark.parametrize("N", [(7, 7, 7), (16, 16, 16), (11, 16, 7)])
+def test_fft_poisson_solver_divergence_free(oracle, topo, N):
+    _random_divergence_free_test(oracle, oracle.Grid(N, topology=topo), 0)
+
+
+@pytest.mark.parametrize("N", [(8, 8, 16), (7, 11, 9)])
+def test_fourier_tridiagonal_solver_on_stretched_grid(oracle, N):
+    g = oracle.Grid(N, topology=(P, P, B), z=tanh_faces(N[2]))
+    _random_divergence_free_test(oracle, g, 1)
+
+
+def test_fourier_tridiagonal_equals_fft_solver_on_regular_bounded_z(oracle):
+    """the product routes z-Bounded grids through the tridiagonal solver: same discrete operator"""
+    rng = np.random.default_rng(4)
+    g = oracle.Grid((8, 8, 8), topology=(P, P, B), z=(-1.0, 0.0))
+    R = rng.standard_normal(g.N)
+    R -= R.mean()
+    s0, s1 = oracle.PoissonSolver(g, 0), oracle.PoissonSolver(g, 1)
+    s0.rhs[...] = R
+    s1.rhs[...] = R * g.dc[2][0]
+    p0, p1 = g.zeros(oracle.LOC["c"]), g.zeros(oracle.LOC["c"])
+    s0.solve(p0)
+    s1.solve(p1)
+    assert np.allclose(p0, p1, atol=1e-13)
+
+
+def test_poisson_second_order_convergence(oracle):
+    """analytic cosines, rate ≈ 2 (dependencies_for_poisson_solvers.jl:135-173)"""
+    errs = []
+    for n in (16, 32, 64):
+        g = oracle.Grid((n, n, n), topology=(P, P, B), x=(0.0, 2 * np.pi), y=(0.0, 2 * np.pi), z=(0.0, np.pi))
+        h = [g.dc[d][0] for d in range(3)]
+        x = (np.arange(n) + 0.5) * h[0]
+        y = (np.arange(n) + 0.5) * h[1]
+        z = (np.arange(n) + 0.5) * h[2]
+        X, Y, Z = np.meshgrid(x, y, z, indexing="ij")
+        phi = np.cos(2 * X) * np.sin(3 * Y) * np.cos(2 * Z)
+        s = oracle.PoissonSolver(g, 0)
+        s.rhs[...] = -(4 + 9 + 4) * phi
+        p = g.zeros(oracle.LOC["c"])
+        s.solve(p)
+        errs.append(np.abs(g.interior_cells(p) - phi).max())
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert np.all(np.abs(rates - 2) < 0.1), rates
+
+
+def test_batched_tridiagonal_solver_vs_dense(oracle):
+    """test/test_batched_tridiagonal_solver.jl:7-93"""
+    rng = np.random.default_rng(5)
+    Nx, Ny, Nz = 3, 4, 12
+    a, c = rng.random(Nz - 1), rng.random(Nz - 1)
+    b = np.asfortranarray(3 + rng.random((Nx, Ny, Nz)))
+    f = np.asfortranarray(rng.standard_normal((Nx, Ny, Nz)) + 1j * rng.standard_normal((Nx, Ny, Nz)))
+    t = np.zeros((Nx, Ny, Nz), order="F")
+    phi = np.zeros((Nx, Ny, Nz), dtype=np.complex128, order="F")
+    oracle.lib().oro_batched_tridiagonal_solve_z(Nx, Ny, Nz, dptr(a), dptr(b), dptr(c), f.ctypes.data, dptr(t), phi.ctypes.data)
+    for i in range(Nx):
+        for j in range(Ny):
+            M = np.diag(b[i, j]) + np.diag(a, -1) + np.diag(c, 1)
+            assert np.allclose(phi[i, j], np.linalg.solve(M, f[i, j]), rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# time stepping (test/test_time_stepping.jl:124-199,432-460; test/test_dynamics.jl:216-261)
+# ---------------------------------------------------------------------------------------------------------------------
+def _random_model(oracle, g, seed=6):
+    rng = np.random.default_rng(seed)
+    m = oracle.Model(g, 2)
+    vals = {n: rng.standard_normal(g.interior(m.field(n), m.loc(n)).shape) for n in m.names()}
+    m.set(**vals)
+    return m
+
+
+@pytest.mark.parametrize("kind", ["regular", "stretched", "bounded-regular"])
+def test_incompressibility_after_1_and_10_rk3_steps(oracle, kind):
+    N = (16, 16, 16)
+    if kind == "regular":
+        g = oracle.Grid(N)
+    elif kind == "stretched":
+        g = oracle.Grid(N, topology=(P, P, B), z=tanh_faces(16))
+    else:
+        g = oracle.Grid(N, topology=(P, P, B), z=(-1.0, 0.0))
+    m = _random_model(oracle, g)
+    assert m.max_abs_divergence() < 5e-8
+    for nsteps in (1, 9):
+        for _ in range(nsteps):
+            m.time_step(1e-3)
+        assert m.max_abs_divergence() < 5e-8
+    assert m.iteration == 10 and abs(m.time - 1e-2) < 1e-15
+
+
+def test_tracer_volume_integral_is_conserved_in_bounded_channel(oracle):
+    """test/test_time_stepping.jl:165-199"""
+    g = oracle.Grid((12, 10, 8), topology=(P, B, B), z=tanh_faces(8))
+    m = _random_model(oracle, g, seed=7)
+    vol = np.asarray(g.dc[2][3:3 + 8]).reshape(1, 1, 8)
+
+    def total(name):
+        return float((g.interior_cells(m.field(name)) * vol).sum())
+    before = [total("c0"), total("c1")]
+    for _ in range(10):
+        m.time_step(5e-4)
+    after = [total("c0"), total("c1")]
+    assert np.allclose(before, after, rtol=0, atol=1e-11 * 12 * 10 * 8)
+
+
+def test_taylor_green_vortex_is_steady(oracle):
+    """2-D Taylor-Green flow is an exact steady Euler solution (closure = nothing); cf. test/test_dynamics.jl:216-261"""
+    n = 32
+    g = oracle.Grid((n, n, 4), x=(0.0, 2 * np.pi), y=(0.0, 2 * np.pi), z=(0.0, 1.0))
+    h = g.dc[0][0]
+    xf, xc = np.arange(n) * h, (np.arange(n) + 0.5) * h
+    u0 = (np.cos(xf)[:, None, None] * np.sin(xc)[None, :, None]) * np.ones((1, 1, 4))
+    v0 = (-np.sin(xc)[:, None, None] * np.cos(xf)[None, :, None]) * np.ones((1, 1, 4))
+    m = oracle.Model(g, 1)
+    m.set(u=u0, v=v0, w=0 * u0, c0=0 * u0)
+    for _ in range(20):
+        m.time_step(0.1 * h)
+    u = g.interior_cells(m.field("u"))
+    assert np.abs(u - u0).max() < 5e-4 and np.abs(g.interior_cells(m.field("w"))).max() < 1e-12
+
+
+def test_advection_order_and_directional_symmetry(oracle):
+    """validation/convergence_tests/one_dimensional_advection_schemes.jl:21-36,108-118: errors of x-, y-, z-oriented
+    advection agree and converge at high order"""
+    def run(n, axis):
+        size = [4, 4, 4]
+        size[axis] = n
+        ext = [(0.0, 4.0 / n)] * 3
+        ext[axis] = (0.0, 1.0)
+        g = oracle.Grid(tuple(size), x=ext[0], y=ext[1], z=ext[2])
+        h = 1.0 / n
+        s = (np.arange(n) + 0.5) * h
+        shp = [1, 1, 1]
+        shp[axis] = n
+        c0 = np.exp(-((s - 0.5) ** 2) / 0.01).reshape(shp) * np.ones(size)
+        m = oracle.Model(g, 1)
+        vel = {"u": 0.0, "v": 0.0, "w": 0.0}
+        vel["uvw"[axis]] = 1.0
+        m.set(u=vel["u"] + 0 * c0, v=vel["v"] + 0 * c0, w=vel["w"] + 0 * c0, c0=c0)
+        dt, nsteps = 0.01 * h, 10
+        for _ in range(nsteps):
+            m.time_step(dt)
+        exact = np.exp(-((s - 0.5 - dt * nsteps) ** 2) / 0.01).reshape(shp) * np.ones(size)
+        return np.abs(g.interior_cells(m.field("c0")) - exact).max()
+    e = {ax: [run(n, ax) for n in (32, 64)] for ax in range(3)}
+    for ax in (1, 2):
+        assert np.allclose(e[ax], e[0], rtol=1e-9), (e[0], e[ax])
+    assert np.log2(e[0][0] / e[0][1]) > 3.5, e[0]
