@@ -31,6 +31,18 @@ TENDENCY_BYTES_PER_CELL = 80.0    # (5 fields read + 5 tendencie
 V100_PUBLISHED_CELL_UPDATES = 256 ** 3 / 56.444e-3   # 256^3 F64 WENO 56.444 ms on a V100 (v0.58.8)
 
 
+def measured_traffic(tendency_impl, N):
+    """HBM bytes per tendency launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE and WRITE_SIZE collected
+    in separate runs and calibrated as MI355X_MICROARCH.md prescribes); None when no profile matches this configuration"""
+    path = os.path.join(ROOT, "profiles", "r01_tendency_traffic.json")
+    if tendency_impl != 1 or N != 256 or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def initial_state(ocn, model, seed=1234):
     from helpers import smooth_state
     g = model.grid
@@ -162,7 +174,9 @@ def main():
         "roofline": {"kernel": "fused WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS)" if args.tendency_impl == 1
                      else "per-field WENO-5 tendency kernels (5 launches)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": measured_traffic(args.tendency_impl, N) if world == 1 else None,
+                     "traffic_source": "profiles/r01_tendency_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                      "algorithmic_bytes_per_launch": TENDENCY_BYTES_PER_CELL * float(N) ** 3,
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
                      "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},

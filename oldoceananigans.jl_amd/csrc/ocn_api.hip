@@ -1129,6 +1129,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "c2r_strided")) { g_c2r_strided = value; return OCN_OK; }
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
+    if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 1) return fail(OCN_EINVAL, "fused_kchunk must be >= 1"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

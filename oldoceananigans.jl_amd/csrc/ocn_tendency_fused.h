@@ -119,7 +119,7 @@ __device__ __forceinline__ double shfl_down1(double x) {
 // a plane go to LDS (double buffered) and are read back -- own and neighbour's -- when the cell is closed one iteration
 // later, so the kernel fits 4+ waves per SIMD. BZ = z is Bounded (compile-time: the periodic build carries no fallback
 // reconstruction code).
-template <int NTR, int TY, bool BZ, int MINW>
+template <int NTR, int TY, bool BZ, int MINW, bool ZWIN>
 __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGrid gin, FusedArgs a) {
     constexpr int NF = 3 + NTR;
     constexpr int NA = NTR > 0 ? NTR : 1;   // no zero-length arrays in device code
@@ -154,6 +154,22 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
 #pragma unroll
     for (int f = 0; f < NF; ++f) fz_prev[f] = 0;
 
+    // ZWIN: the 6-deep z-windows of the thread's own column live in registers and slide by one plane per iteration, so
+    // every plane of every field is fetched from HBM once per tile instead of six times (the L2 cannot hold the windows
+    // of all co-resident workgroups: 5 fields x 6 planes x tile ~ 0.2 MB per workgroup)
+    Win6 uz, vz, wz, czw[NA];
+    if (ZWIN && flux_ij) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+            const long pz = (long)(kc0 - 3 + n - 1 + Hz);
+            uz.s[n + 1] = a.u[col + s2 * pz];
+            vz.s[n + 1] = a.v[col + s2 * pz];
+            wz.s[n + 1] = a.w[col + s2 * pz];
+#pragma unroll
+            for (int t = 0; t < NTR; ++t) czw[t].s[n + 1] = a.c[t][col + s2 * pz];
+        }
+    }
+
     for (int k = kc0; k <= kc1 + 1; ++k) {
         const bool last = k == kc1 + 1;               // peeled plane: only the z-fluxes closing cell kc1
         const int buf = k & 1;
@@ -163,7 +179,21 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
             const double *pu = a.u + col + s2 * pk, *pv = a.v + col + s2 * pk, *pw = a.w + col + s2 * pk;
             // ---- z-fluxes of plane k, then close cell k-1 ----
             double fz[NF];
-            {
+            if (ZWIN) {
+#pragma unroll
+                for (int n = 0; n < 5; ++n) {
+                    uz.s[n] = uz.s[n + 1]; vz.s[n] = vz.s[n + 1]; wz.s[n] = wz.s[n + 1];
+#pragma unroll
+                    for (int t = 0; t < NTR; ++t) czw[t].s[n] = czw[t].s[n + 1];
+                }
+                const long pt = pk + 2;
+                uz.s[5] = a.u[col + s2 * pt];
+                vz.s[5] = a.v[col + s2 * pt];
+                wz.s[5] = a.w[col + s2 * pt];
+#pragma unroll
+                for (int t = 0; t < NTR; ++t) czw[t].s[5] = a.c[t][col + s2 * pt];
+                z_fluxes<NTR>(g, i, j, k, load_win(pw, 1), load_win(pw, s1), wz, uz, vz, czw, fz);
+            } else {
                 Win6 cz[NA];
 #pragma unroll
                 for (int t = 0; t < NTR; ++t) cz[t] = load_win(a.c[t] + col + s2 * pk, s2);
@@ -200,7 +230,7 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                     Win6 cx[NA];
 #pragma unroll
                     for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t] + col + s2 * pk, 1);
-                    x_fluxes<NTR>(g, i, j, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), load_win(pu, s2),
+                    x_fluxes<NTR>(g, i, j, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), ZWIN ? uz : load_win(pu, s2),
                                   load_win(pv, 1), load_win(pw, 1), cx, fl);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) FX[buf][f][wave][lane] = fl[f];
@@ -209,7 +239,7 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                     Win6 cy[NA];
 #pragma unroll
                     for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t] + col + s2 * pk, s1);
-                    y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), load_win(pv, s2),
+                    y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), ZWIN ? vz : load_win(pv, s2),
                                   load_win(pu, s1), load_win(pw, s1), cy, fl);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) FY[buf][f][wave][lane] = fl[f];
@@ -249,21 +279,25 @@ static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
     return g.tx != 1 && g.ty != 1;       // x, y Periodic or FullyConnected: identical x / y parent extents for all fields
 }
 
-static int g_fused_ty = 7, g_fused_kchunk = 16, g_fused_minw = 4;
+static int g_fused_ty = 7, g_fused_kchunk = 16, g_fused_minw = 4, g_fused_zwin = 0;
 
 template <int NTR, int TY>
 static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a) {
     const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
     if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
     dim3 grid((nx + 63) / 64, (ny + TY - 1) / TY, (nz + a.kchunk - 1) / a.kchunk);
-    constexpr int MW = (TY + 1) <= 4 ? 4 : ((TY + 1) <= 8 ? 4 : 3);   // waves per SIMD the register allocator must allow
-    if (g_fused_minw == 2) {
-        if (g.tz != 0) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, true, 2>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
-        else           hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, false, 2>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+    const dim3 blk(64 * (TY + 1));
+#define OCN_LAUNCH_FUSED(BZV, MWV, ZWV) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, BZV, MWV, ZWV>), grid, blk, 0, stream, g, a)
+    // waves per SIMD the register allocator must allow: two (TY+1)-wave workgroups per CU
+    constexpr int MW2 = (2 * (TY + 1) + 3) / 4;
+    if (g_fused_zwin) {
+        if (g.tz != 0) OCN_LAUNCH_FUSED(true, MW2, true); else OCN_LAUNCH_FUSED(false, MW2, true);
+    } else if (g_fused_minw == 2) {
+        if (g.tz != 0) OCN_LAUNCH_FUSED(true, 2, false); else OCN_LAUNCH_FUSED(false, 2, false);
     } else {
-        if (g.tz != 0) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, true, MW>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
-        else           hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, false, MW>), grid, dim3(64 * (TY + 1)), 0, stream, g, a);
+        if (g.tz != 0) OCN_LAUNCH_FUSED(true, MW2, false); else OCN_LAUNCH_FUSED(false, MW2, false);
     }
+#undef OCN_LAUNCH_FUSED
     return 0;
 }
 
@@ -293,6 +327,7 @@ static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, cons
 #define OCN_FUSED_CASE(NTR)                                                          \
     case NTR:                                                                        \
         if (g_fused_ty == 3) return launch_fused_t<NTR, 3>(g, stream, a);            \
+        if (g_fused_ty == 5) return launch_fused_t<NTR, 5>(g, stream, a);            \
         if (g_fused_ty == 4) return launch_fused_t<NTR, 4>(g, stream, a);            \
         if (g_fused_ty == 8) return launch_fused_t<NTR, 8>(g, stream, a);            \
         return launch_fused_t<NTR, 7>(g, stream, a);
