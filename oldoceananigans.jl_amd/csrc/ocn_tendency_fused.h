@@ -38,10 +38,19 @@ struct FusedArgs {
 // window loaders ----------------------------------------------------------------------------------------------------
 struct Win6 { double s[6]; };
 
-__device__ __forceinline__ Win6 load_win(const double *p, long stride) {
+// Addressing: every field shares one parent layout, so a thread carries ONE 32-bit byte offset per plane and each access is
+// `uniform base (SGPR pair) + 32-bit VGPR offset (+ immediate)` -- the gfx950 global_load saddr form; no 64-bit per-lane
+// address arithmetic (it was 16 % of the VALU stream). Parent arrays are < 4 GiB (checked on the host).
+__device__ __forceinline__ double ld8(const double *base, unsigned byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void st8(double *base, unsigned byte_off, double v) {
+    *reinterpret_cast<double *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+__device__ __forceinline__ Win6 load_win(const double *base, unsigned o, unsigned stride) {
     Win6 w;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) w.s[n] = p[(n - 3) * stride];
+    for (int n = 0; n < 6; ++n) w.s[n] = ld8(base, o + (unsigned)(n - 3) * stride);
     return w;
 }
 
@@ -145,10 +154,10 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
     const int ie = i0 + 64, je = j0 + lane;
     const bool edge_x = edge && lane < TY && ie <= a.r.i1 + 1 && je <= a.r.j1;
 
-    const long s1 = a.s1, s2 = a.s2u;
+    const unsigned s1 = 8u * (unsigned)a.s1, s2 = 8u * (unsigned)a.s2u, sx = 8u;     // byte strides
     const int Hz = g.Hz;
-    const long col = a.off + i + s1 * (long)j;       // (i, j) of this thread inside a plane (edge wave: row j0+TY)
-    const long cole = a.off + ie + s1 * (long)je;
+    const unsigned col = 8u * (unsigned)(a.off + i + (long)a.s1 * j);       // (i, j) of this thread inside a plane (edge wave: row j0+TY)
+    const unsigned cole = 8u * (unsigned)(a.off + ie + (long)a.s1 * je);
 
     double fz_prev[NF];
 #pragma unroll
@@ -161,12 +170,12 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
     if (ZWIN && flux_ij) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) {
-            const long pz = (long)(kc0 - 3 + n - 1 + Hz);
-            uz.s[n + 1] = a.u[col + s2 * pz];
-            vz.s[n + 1] = a.v[col + s2 * pz];
-            wz.s[n + 1] = a.w[col + s2 * pz];
+            const unsigned oz = col + s2 * (unsigned)(kc0 - 3 + n - 1 + Hz);
+            uz.s[n + 1] = ld8(a.u, oz);
+            vz.s[n + 1] = ld8(a.v, oz);
+            wz.s[n + 1] = ld8(a.w, oz);
 #pragma unroll
-            for (int t = 0; t < NTR; ++t) czw[t].s[n + 1] = a.c[t][col + s2 * pz];
+            for (int t = 0; t < NTR; ++t) czw[t].s[n + 1] = ld8(a.c[t], oz);
         }
     }
 
@@ -176,7 +185,8 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
         const long pk = (long)(k - 1 + Hz);
         const double axk = g.ax[pk], ayk = g.ay[pk];
         if (flux_ij) {
-            const double *pu = a.u + col + s2 * pk, *pv = a.v + col + s2 * pk, *pw = a.w + col + s2 * pk;
+            const unsigned o = col + s2 * (unsigned)pk;
+            const double *pu = a.u, *pv = a.v, *pw = a.w;
             // ---- z-fluxes of plane k, then close cell k-1 ----
             double fz[NF];
             if (ZWIN) {
@@ -186,25 +196,25 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
 #pragma unroll
                     for (int t = 0; t < NTR; ++t) czw[t].s[n] = czw[t].s[n + 1];
                 }
-                const long pt = pk + 2;
-                uz.s[5] = a.u[col + s2 * pt];
-                vz.s[5] = a.v[col + s2 * pt];
-                wz.s[5] = a.w[col + s2 * pt];
+                const unsigned ot = o + 2u * s2;
+                uz.s[5] = ld8(a.u, ot);
+                vz.s[5] = ld8(a.v, ot);
+                wz.s[5] = ld8(a.w, ot);
 #pragma unroll
-                for (int t = 0; t < NTR; ++t) czw[t].s[5] = a.c[t][col + s2 * pt];
-                z_fluxes<NTR>(g, i, j, k, load_win(pw, 1), load_win(pw, s1), wz, uz, vz, czw, fz);
+                for (int t = 0; t < NTR; ++t) czw[t].s[5] = ld8(a.c[t], ot);
+                z_fluxes<NTR>(g, i, j, k, load_win(pw, o, sx), load_win(pw, o, s1), wz, uz, vz, czw, fz);
             } else {
                 Win6 cz[NA];
 #pragma unroll
-                for (int t = 0; t < NTR; ++t) cz[t] = load_win(a.c[t] + col + s2 * pk, s2);
-                z_fluxes<NTR>(g, i, j, k, load_win(pw, 1), load_win(pw, s1), load_win(pw, s2), load_win(pu, s2),
-                              load_win(pv, s2), cz, fz);
+                for (int t = 0; t < NTR; ++t) cz[t] = load_win(a.c[t], o, s2);
+                z_fluxes<NTR>(g, i, j, k, load_win(pw, o, sx), load_win(pw, o, s1), load_win(pw, o, s2), load_win(pu, o, s2),
+                              load_win(pv, o, s2), cz, fz);
             }
             if (k > kc0 && cell_ij) {
                 const int pb = buf ^ 1;
                 const long pkm = pk - 1;
                 const double vc = g.vinv_c[pkm], vf = g.vinv_f[pkm];
-                const long q = col + s2 * pkm;
+                const unsigned q = o - s2;
                 const int km = k - 1;
                 double Gn_[NF];
 #pragma unroll
@@ -214,12 +224,12 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                     const double div = (f == 2 ? vf : vc) * ((dx + dy) + (fz[f] - fz_prev[f]));
                     Gn_[f] = -div + 0.0;
                 }
-                if (in_range(a.ru, i, j, km)) a.Gu[q] = Gn_[0];
-                if (in_range(a.rv, i, j, km)) a.Gv[q] = Gn_[1];
-                if (in_range(a.rw, i, j, km)) a.Gw[q] = Gn_[2];
+                if (in_range(a.ru, i, j, km)) st8(a.Gu, q, Gn_[0]);
+                if (in_range(a.rv, i, j, km)) st8(a.Gv, q, Gn_[1]);
+                if (in_range(a.rw, i, j, km)) st8(a.Gw, q, Gn_[2]);
 #pragma unroll
                 for (int t = 0; t < NTR; ++t)
-                    if (in_range(a.rc, i, j, km)) a.Gc[t][q] = Gn_[3 + t];
+                    if (in_range(a.rc, i, j, km)) st8(a.Gc[t], q, Gn_[3 + t]);
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) fz_prev[f] = fz[f];
@@ -229,18 +239,18 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                 {
                     Win6 cx[NA];
 #pragma unroll
-                    for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t] + col + s2 * pk, 1);
-                    x_fluxes<NTR>(g, i, j, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), ZWIN ? uz : load_win(pu, s2),
-                                  load_win(pv, 1), load_win(pw, 1), cx, fl);
+                    for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t], o, sx);
+                    x_fluxes<NTR>(g, i, j, k, axk, g.ax + pk - 2, load_win(pu, o, sx), load_win(pu, o, s1), ZWIN ? uz : load_win(pu, o, s2),
+                                  load_win(pv, o, sx), load_win(pw, o, sx), cx, fl);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) FX[buf][f][wave][lane] = fl[f];
                 }
                 {
                     Win6 cy[NA];
 #pragma unroll
-                    for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t] + col + s2 * pk, s1);
-                    y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), ZWIN ? vz : load_win(pv, s2),
-                                  load_win(pu, s1), load_win(pw, s1), cy, fl);
+                    for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t], o, s1);
+                    y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, o, sx), load_win(pv, o, s1), ZWIN ? vz : load_win(pv, o, s2),
+                                  load_win(pu, o, s1), load_win(pw, o, s1), cy, fl);
 #pragma unroll
                     for (int f = 0; f < NF; ++f) FY[buf][f][wave][lane] = fl[f];
                 }
@@ -249,23 +259,23 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
             double fl[NF];
             if (edge_y) {
                 // y-fluxes of row j0+TY (this wave's `j`), all 64 columns
-                const double *pu = a.u + col + s2 * pk, *pv = a.v + col + s2 * pk, *pw = a.w + col + s2 * pk;
+                const unsigned o = col + s2 * (unsigned)pk;
                 Win6 cy[NA];
 #pragma unroll
-                for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t] + col + s2 * pk, s1);
-                y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(pv, 1), load_win(pv, s1), load_win(pv, s2),
-                              load_win(pu, s1), load_win(pw, s1), cy, fl);
+                for (int t = 0; t < NTR; ++t) cy[t] = load_win(a.c[t], o, s1);
+                y_fluxes<NTR>(g, i, j, k, ayk, g.ay + pk - 2, load_win(a.v, o, sx), load_win(a.v, o, s1), load_win(a.v, o, s2),
+                              load_win(a.u, o, s1), load_win(a.w, o, s1), cy, fl);
 #pragma unroll
                 for (int f = 0; f < NF; ++f) FY[buf][f][TY][lane] = fl[f];
             }
             if (edge_x) {
                 // x-fluxes of column i0+64, rows j0 .. j0+TY-1 (one lane per row)
-                const double *pu = a.u + cole + s2 * pk, *pv = a.v + cole + s2 * pk, *pw = a.w + cole + s2 * pk;
+                const unsigned o = cole + s2 * (unsigned)pk;
                 Win6 cx[NA];
 #pragma unroll
-                for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t] + cole + s2 * pk, 1);
-                x_fluxes<NTR>(g, ie, je, k, axk, g.ax + pk - 2, load_win(pu, 1), load_win(pu, s1), load_win(pu, s2),
-                              load_win(pv, 1), load_win(pw, 1), cx, fl);
+                for (int t = 0; t < NTR; ++t) cx[t] = load_win(a.c[t], o, sx);
+                x_fluxes<NTR>(g, ie, je, k, axk, g.ax + pk - 2, load_win(a.u, o, sx), load_win(a.u, o, s1), load_win(a.u, o, s2),
+                              load_win(a.v, o, sx), load_win(a.w, o, sx), cx, fl);
 #pragma unroll
                 for (int f = 0; f < NF; ++f) FX[buf][f][lane][64] = fl[f];
             }
@@ -276,10 +286,13 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
 
 static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
     (void)range;
-    return g.tx != 1 && g.ty != 1;       // x, y Periodic or FullyConnected: identical x / y parent extents for all fields
+    const double bytes = 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy) * (g.Nz + 2.0 * g.Hz + 1.0);
+    return g.tx != 1 && g.ty != 1 &&     // x, y Periodic or FullyConnected: identical x / y parent extents for all fields
+           bytes < 4294967296.0;         // 32-bit byte offsets inside a parent array
 }
 
-static int g_fused_ty = 7, g_fused_kchunk = 16, g_fused_minw = 4, g_fused_zwin = 0;
+// tuned on MI355X at 256^3 (tools/tune_fused.py): 64 x 7 tiles, register z-windows, 2 waves/SIMD (no spills), 32 levels per workgroup
+static int g_fused_ty = 7, g_fused_kchunk = 32, g_fused_minw = 2, g_fused_zwin = 1;
 
 template <int NTR, int TY>
 static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a) {
@@ -290,7 +303,9 @@ static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a
 #define OCN_LAUNCH_FUSED(BZV, MWV, ZWV) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, BZV, MWV, ZWV>), grid, blk, 0, stream, g, a)
     // waves per SIMD the register allocator must allow: two (TY+1)-wave workgroups per CU
     constexpr int MW2 = (2 * (TY + 1) + 3) / 4;
-    if (g_fused_zwin) {
+    if (g_fused_zwin && g_fused_minw == 2) {
+        if (g.tz != 0) OCN_LAUNCH_FUSED(true, 2, true); else OCN_LAUNCH_FUSED(false, 2, true);
+    } else if (g_fused_zwin) {
         if (g.tz != 0) OCN_LAUNCH_FUSED(true, MW2, true); else OCN_LAUNCH_FUSED(false, MW2, true);
     } else if (g_fused_minw == 2) {
         if (g.tz != 0) OCN_LAUNCH_FUSED(true, 2, false); else OCN_LAUNCH_FUSED(false, 2, false);
