@@ -133,21 +133,28 @@ int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const double *a, con
 
 /* ---------------------------------------------------------------- distributed x-slab pieces --------------------- */
 /* fill_send_buffers! / recv_from_buffers! (DistributedComputations/communication_buffers.jl:281-313) for Partition(R):
- * west/east buffers of Hx x Py x Pz doubles per field (whole parent extent in y, z: corners ride along), field-major.
+ * west/east buffers of Hx x Py x Pz doubles per field (whole parent extent in y, z: corners ride along; Py, Pz are
+ * each field's own -- Face fields on Bounded dimensions have one more plane), field-major, back to back.
  * The exchange itself (MPI.Isend/Irecv in the reference, halo_communication.jl:300,326) is issued by the host layer
  * over RCCL. */
 int ocn_pack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, double *west_send,
                      double *east_send);
 int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, const double *west_recv,
                        const double *east_recv);
-/* DistributedFFTBasedPoissonSolver for Partition(R,1,1) (distributed_fft_based_poisson_solver.jl:92-188), split at the
- * two transposes (MPI.Alltoallv!, distributed_transpose.jl:185-191) which the host layer runs as RCCL all-to-alls on the
- * send/recv buffers: rhs -> forward_yz -> [all_to_all] -> solve_x -> [all_to_all] -> backward_yz -> phi. */
+/* DistributedFFTBasedPoissonSolver (distributed_fft_based_poisson_solver.jl:92-188; z Periodic) and
+ * DistributedFourierTridiagonalPoissonSolver (distributed_fft_tridiagonal_solver.jl:153-293; z Bounded, regular or
+ * stretched) for Partition(R,1,1), split at the two transposes (MPI.Alltoallv!, distributed_transpose.jl:185-191) which
+ * the host layer runs as RCCL all-to-alls on the send/recv buffers:
+ *   source_term -> forward_yz -> [all_to_all(recv, send)] -> solve_x -> [all_to_all(recv, send)] -> backward_yz -> phi.
+ * The right-hand side is real, so only the y modes 0..Ny/2 travel (half the reference's bytes): send/recv hold
+ * `buffer_size` complex elements = R equal chunks of (Nxl, ceil((Ny/2+1)/R), Nz). */
 typedef struct ocn_dist_poisson_s *ocn_dist_poisson_t;
 int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t local_grid, int R, int rank, double Lx_global);
 int ocn_dist_poisson_destroy(ocn_dist_poisson_t solver);
+int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t solver, size_t *complex_elements);
 int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t solver, double *send_complex, double *recv_complex);
-int ocn_dist_poisson_rhs(ocn_dist_poisson_t solver, double **rhs_complex);   /* solver.storage.zfield, (Nxl, Ny, Nz) */
+/* compute_source_term! (solve_for_pressure.jl:12-84) into the solver's own storage */
+int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w);
 int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver);
 int ocn_dist_poisson_solve_x(ocn_dist_poisson_t solver);
 int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *phi);

@@ -45,7 +45,8 @@ SYMBOLS = {
     "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_destroy": (C.c_int, [_vp]),
     "ocn_dist_poisson_set_buffers": (C.c_int, [_vp, _vp, _vp]),
-    "ocn_dist_poisson_rhs": (C.c_int, [_vp, _pp]),
+    "ocn_dist_poisson_buffer_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "ocn_dist_poisson_source_term": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ocn_dist_poisson_forward_yz": (C.c_int, [_vp]),
     "ocn_dist_poisson_solve_x": (C.c_int, [_vp]),
     "ocn_dist_poisson_backward_yz": (C.c_int, [_vp, _vp]),

@@ -448,13 +448,15 @@ extern "C" int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const do
 // ---------------------------------------------------------------------------------------------------------------------
 // pressure source term / correction
 // ---------------------------------------------------------------------------------------------------------------------
-static int source_term(const DGrid &g, const double *u, const double *v, const double *w, void *rhs, bool weight, bool real_out = false) {
+static int source_term(const DGrid &g, const double *u, const double *v, const double *w, void *rhs, bool weight, bool real_out = false,
+                       long sj = 0, long sk = 0, bool pad = false) {
+    if (sj == 0) { sj = g.Nx; sk = (long)g.Nx * g.Ny; }
     if (real_out)
         hipLaunchKernelGGL(source_term_kernel<true>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, pad);
     else
         hipLaunchKernelGGL(source_term_kernel<false>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight);
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, false);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -854,20 +856,26 @@ extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const dou
 static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east, bool pack) {
     if (n <= 0) return OCN_OK;
     if (n > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
-    int P[3];
-    parent_size(g, locs[0], P);
-    for (int f = 1; f < n; ++f) {
-        int Q[3];
-        parent_size(g, locs[f], Q);
-        if (Q[0] != P[0] || Q[1] != P[1] || Q[2] != P[2]) return fail(OCN_EINVAL, "fields of one exchange must share the parent shape");
-    }
     FieldList fl;
+    SlabList sl;
     fl.n = n;
-    for (int f = 0; f < n; ++f) fl.p[f] = fields[f];
-    const long slab = (long)g.Hx * P[1] * P[2];
-    const int nb = (int)((slab + 255) / 256);
-    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], g.Nx, g.Hx, west, east);
-    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], g.Nx, g.Hx, west, east);
+    int P0 = 0;
+    long off = 0, maxrows = 0;
+    for (int f = 0; f < n; ++f) {
+        int P[3];
+        parent_size(g, locs[f], P);
+        if (f == 0) P0 = P[0];
+        if (P[0] != P0) return fail(OCN_EINVAL, "fields of one exchange must share the parent extent in x");
+        fl.p[f] = fields[f];
+        sl.off[f] = off;
+        sl.rows[f] = (long)P[1] * P[2];
+        off += (long)g.Hx * sl.rows[f];
+        maxrows = std::max(maxrows, sl.rows[f]);
+    }
+    const long threads = (long)g.Hx * maxrows;
+    const int nb = (int)((threads + 255) / 256);
+    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, west, east);
+    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, west, east);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -886,23 +894,33 @@ extern "C" int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const 
     return x_halo_buffers(grid->d, fields, locs, nfields, const_cast<double *>(west_recv), const_cast<double *>(east_recv), false);
 }
 
-// DistributedFFTBasedPoissonSolver for Partition(R, 1, 1) (distributed_fft_based_poisson_solver.jl:92-188)
+// DistributedFFTBasedPoissonSolver (distributed_fft_based_poisson_solver.jl:92-188) and
+// DistributedFourierTridiagonalPoissonSolver (distributed_fft_tridiagonal_solver.jl:153-293) for Partition(R, 1, 1).
+// z is never partitioned on an x-slab decomposition, so both solvers share one pipeline:
+//   local complex transform in (y, z) [z Periodic] or y only [z Bounded] of the PAIRED real columns (see ocn_kernels.h)
+//   -> separate + pack half the y modes -> all-to-all -> x transform -> spectral divide | z-tridiagonal solve
+//   -> inverse x transform -> pack -> all-to-all -> rebuild full spectrum -> inverse local transform -> haloed pressure.
 struct ocn_dist_poisson_s {
     ocn_grid_t grid;            // LOCAL grid (Nxl, Ny, Nz)
-    int R, rank, Nxl, Nxg, Nyl, Ny, Nz;
-    size_t n;                   // local element count Nxl*Ny*Nz == Nxg*Nyl*Nz
-    double2 *zfield = nullptr, *xfield = nullptr;
-    double2 *send = nullptr, *recv = nullptr;   // borrowed (host layer owns them: torch tensors)
+    int R, rank, zmode;         // zmode 0: z Periodic (FFT); 1: z Bounded (tridiagonal solve in the x-local layout)
+    int Nxl, Nxe, Nxh, Nxg, Ny, Nyh, Nyc, Nyp, Nz;
+    size_t nz_c;                // complex elements of the local paired array  Nxh*Ny*Nz
+    size_t nbuf;                // complex elements of xfield / send / recv    Nxl*Nyp*Nz == Nxg*Nyc*Nz
+    double2 *zfield = nullptr;  // (Nxh, Nz, Ny) complex == dense real rhs (Nxe, Nz, Ny)
+    double2 *xfield = nullptr, *xsol = nullptr;   // (Nxg, Nyc, Nz)
+    double2 *send = nullptr, *recv = nullptr;     // borrowed (host layer owns them: torch tensors)
     double *lam[3] = {nullptr, nullptr, nullptr};
-    hipfftHandle plan_yz = 0, plan_x = 0;
-    bool has_yz = false, has_x = false;
+    double *D = nullptr, *lower = nullptr, *t = nullptr;
+    hipfftHandle plan_loc = 0, plan_x = 0;
+    bool has_loc = false, has_x = false;
 };
 
 extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     if (!s) return OCN_OK;
-    if (s->has_yz) hipfftDestroy(s->plan_yz);
+    if (s->has_loc) hipfftDestroy(s->plan_loc);
     if (s->has_x) hipfftDestroy(s->plan_x);
-    hipFree(s->zfield); hipFree(s->xfield);
+    hipFree(s->zfield); hipFree(s->xfield); hipFree(s->xsol);
+    hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
     delete s;
     return OCN_OK;
@@ -913,15 +931,18 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
     if (!solver || !local_grid) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
     if (R < 1 || rank < 0 || rank >= R) return fail(OCN_EINVAL, "invalid rank %d of %d", rank, R);
-    if (g.ty != OCN_PERIODIC || g.tz != OCN_PERIODIC || (R > 1 && g.tx != OCN_CONNECTED) || (R == 1 && g.tx != OCN_PERIODIC))
-        return fail(OCN_ENOTSUP, "the distributed FFT solver is accelerated for (Periodic, Periodic, Periodic) x-slab partitions");
+    if (g.ty != OCN_PERIODIC || (R > 1 && g.tx != OCN_CONNECTED) || (R == 1 && g.tx != OCN_PERIODIC))
+        return fail(OCN_ENOTSUP, "the distributed Poisson solvers are accelerated for (Periodic, Periodic, Periodic | Bounded) x-slab partitions");
     // validate_poisson_solver_distributed_grid (:194-229): Ny must be divisible by Rx
     if (g.Ny % R != 0) return fail(OCN_EINVAL, "Ny = %d must be divisible by the number of ranks %d (transpose y -> x)", g.Ny, R);
-    if (!local_grid->z_regular) return fail(OCN_EINVAL, "DistributedFFTBasedPoissonSolver requires a regular grid");
+    const int zmode = g.tz == OCN_BOUNDED ? 1 : 0;
+    if (zmode == 0 && !local_grid->z_regular) return fail(OCN_EINVAL, "DistributedFFTBasedPoissonSolver requires a regular grid");
     ocn_dist_poisson_s *s = new ocn_dist_poisson_s();
-    s->grid = local_grid; s->R = R; s->rank = rank;
-    s->Nxl = g.Nx; s->Nxg = g.Nx * R; s->Ny = g.Ny; s->Nyl = g.Ny / R; s->Nz = g.Nz;
-    s->n = (size_t)g.Nx * g.Ny * g.Nz;
+    s->grid = local_grid; s->R = R; s->rank = rank; s->zmode = zmode;
+    s->Nxl = g.Nx; s->Nxe = g.Nx + (g.Nx & 1); s->Nxh = s->Nxe / 2; s->Nxg = g.Nx * R;
+    s->Ny = g.Ny; s->Nyh = g.Ny / 2 + 1; s->Nyc = (s->Nyh + R - 1) / R; s->Nyp = s->Nyc * R; s->Nz = g.Nz;
+    s->nz_c = (size_t)s->Nxh * s->Ny * s->Nz;
+    s->nbuf = (size_t)s->Nxg * s->Nyc * s->Nz;
     int rc = OCN_OK;
 #define TRY_OR_FREE(expr)                                                                                  \
     do {                                                                                                   \
@@ -929,29 +950,64 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if (e_ != hipSuccess) { rc = fail((int)e_, "%s: %s", #expr, hipGetErrorString(e_)); goto bad; }   \
     } while (0)
     {
-        TRY_OR_FREE(dev_alloc((void **)&s->zfield, s->n * sizeof(double2)));
-        TRY_OR_FREE(dev_alloc((void **)&s->xfield, s->n * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->zfield, s->nz_c * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->xfield, s->nbuf * sizeof(double2)));
+        TRY_OR_FREE(hipMemset(s->zfield, 0, s->nz_c * sizeof(double2)));
+        TRY_OR_FREE(hipMemset(s->xfield, 0, s->nbuf * sizeof(double2)));
         const int N[3] = {s->Nxg, s->Ny, s->Nz};
         const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
+        std::vector<double> lam[3];
         for (int d = 0; d < 3; ++d) {
-            std::vector<double> lam;
-            poisson_eigenvalues(N[d], L[d], OCN_PERIODIC, lam);
+            poisson_eigenvalues(N[d], L[d], d == 2 ? g.tz : OCN_PERIODIC, lam[d]);
             TRY_OR_FREE(dev_alloc((void **)&s->lam[d], N[d] * sizeof(double)));
-            TRY_OR_FREE(hipMemcpy(s->lam[d], lam.data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
+            TRY_OR_FREE(hipMemcpy(s->lam[d], lam[d].data(), N[d] * sizeof(double), hipMemcpyHostToDevice));
         }
-        // (y, z) transform of the x-fastest local block: element stride Nxl along y, one batch entry per local i
-        int nyz[2] = {s->Nz, s->Ny};
-        int embed[2] = {s->Nz, s->Ny};
-        hipfftResult r = hipfftPlanMany(&s->plan_yz, 2, nyz, embed, s->Nxl, 1, embed, s->Nxl, 1, HIPFFT_Z2Z, s->Nxl);
-        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(yz) failed (%d)", (int)r); goto bad; }
-        s->has_yz = true;
+        if (zmode == 1) {
+            // diagonals as in the serial solver (fourier_tridiagonal_poisson_solver.jl:180-210), on this rank's modes
+            TRY_OR_FREE(dev_alloc((void **)&s->xsol, s->nbuf * sizeof(double2)));
+            TRY_OR_FREE(hipMemset(s->xsol, 0, s->nbuf * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->D, s->nbuf * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->t, s->nbuf * sizeof(double)));
+            TRY_OR_FREE(hipMemset(s->t, 0, s->nbuf * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->lower, std::max(1, g.Nz - 1) * sizeof(double)));
+            const int Nz = g.Nz, Hz = g.Hz;
+            auto dzf = [&](int k) { return local_grid->h_dzf[k - 1 + Hz]; };
+            auto dzc = [&](int k) { return local_grid->h_dzc[k - 1 + Hz]; };
+            std::vector<double> D(s->nbuf), lower(std::max(1, Nz - 1));
+            for (int jl = 0; jl < s->Nyc; ++jl) {
+                const int jg = std::min(rank * s->Nyc + jl, s->Ny - 1);
+                for (int i = 0; i < s->Nxg; ++i) {
+                    double lxy = lam[0][i] + lam[1][jg];
+                    auto at = [&](int k) -> double & { return D[(size_t)i + (size_t)s->Nxg * (jl + (size_t)s->Nyc * (k - 1))]; };
+                    if (Nz == 1) { at(1) = -dzc(1) * lxy; continue; }
+                    at(1) = -1.0 / dzf(2) - dzc(1) * lxy;
+                    at(Nz) = -1.0 / dzf(Nz) - dzc(Nz) * lxy;
+                    for (int k = 2; k <= Nz - 1; ++k) at(k) = -(1.0 / dzf(k + 1) + 1.0 / dzf(k)) - dzc(k) * lxy;
+                }
+            }
+            for (int q = 1; q <= Nz - 1; ++q) lower[q - 1] = 1.0 / dzf(q + 1);
+            TRY_OR_FREE(hipMemcpy(s->D, D.data(), s->nbuf * sizeof(double), hipMemcpyHostToDevice));
+            TRY_OR_FREE(hipMemcpy(s->lower, lower.data(), lower.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+        hipfftResult r;
+        if (zmode == 0) {
+            // (y, z) transform of (Nxh, Nz, Ny): z stride Nxh, y stride Nxh*Nz, one batch entry per column pair
+            int nyz[2] = {s->Ny, s->Nz};
+            r = hipfftPlanMany(&s->plan_loc, 2, nyz, nyz, s->Nxh, 1, nyz, s->Nxh, 1, HIPFFT_Z2Z, s->Nxh);
+        } else {
+            int ny[1] = {s->Ny};
+            r = hipfftPlanMany(&s->plan_loc, 1, ny, ny, s->Nxh * s->Nz, 1, ny, s->Nxh * s->Nz, 1, HIPFFT_Z2Z, s->Nxh * s->Nz);
+        }
+        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(local y/z) failed (%d)", (int)r); goto bad; }
+        s->has_loc = true;
         int nx[1] = {s->Nxg};
-        r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyl * s->Nz);
+        r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyc * s->Nz);
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
         s->has_x = true;
-        if ((rc = plan_set_stream(s->plan_yz)) || (rc = plan_set_stream(s->plan_x))) goto bad;
-        if ((rc = verify_complex_plan(s->plan_yz, s->zfield, (long)s->n, 1.0 / ((double)s->Ny * s->Nz), "distributed (y, z)"))) goto bad;
-        if ((rc = verify_complex_plan(s->plan_x, s->xfield, (long)s->n, 1.0 / (double)s->Nxg, "distributed x"))) goto bad;
+        if ((rc = plan_set_stream(s->plan_loc)) || (rc = plan_set_stream(s->plan_x))) goto bad;
+        const double sc = zmode == 0 ? 1.0 / ((double)s->Ny * s->Nz) : 1.0 / (double)s->Ny;
+        if ((rc = verify_complex_plan(s->plan_loc, s->zfield, (long)s->nz_c, sc, "distributed local (y, z)"))) goto bad;
+        if ((rc = verify_complex_plan(s->plan_x, s->xfield, (long)s->nbuf, 1.0 / (double)s->Nxg, "distributed x"))) goto bad;
     }
     *solver = s;
     return OCN_OK;
@@ -961,39 +1017,50 @@ bad:
 #undef TRY_OR_FREE
 }
 
+extern "C" int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t s, size_t *complex_elements) {
+    if (!s || !complex_elements) return fail(OCN_EINVAL, "NULL argument");
+    *complex_elements = s->nbuf;
+    return OCN_OK;
+}
+
 extern "C" int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t s, double *send_complex, double *recv_complex) {
     if (!s || !send_complex || !recv_complex) return fail(OCN_EINVAL, "NULL argument");
     s->send = (double2 *)send_complex; s->recv = (double2 *)recv_complex;
     return OCN_OK;
 }
 
-extern "C" int ocn_dist_poisson_rhs(ocn_dist_poisson_t s, double **rhs_complex) {
-    if (!s || !rhs_complex) return fail(OCN_EINVAL, "NULL argument");
-    *rhs_complex = (double *)s->zfield;
-    return OCN_OK;
+// compute_source_term! into the solver's paired-column real storage (solve_for_pressure.jl:12-84; weighted by Δzᶜ for the
+// tridiagonal solver)
+extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *u, const double *v, const double *w) {
+    NEED_INIT();
+    if (!s || !u || !v || !w) return fail(OCN_EINVAL, "NULL argument");
+    return source_term(s->grid->d, u, v, w, s->zfield, s->zmode == 1, true, (long)s->Nxe * s->Nz, (long)s->Nxe, s->Nxe != s->Nxl);
 }
 
 static int transpose_stage(ocn_dist_poisson_s *s, int dir, const double2 *src, double2 *dst) {
-    const long total = (long)s->n;
-    hipLaunchKernelGGL(transpose_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, dir, s->R, s->Nxl, s->Nyl,
+    const long total = (long)s->nbuf;
+    hipLaunchKernelGGL(transpose_stage_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, dir, s->R, s->Nxl, s->Nyc,
                        s->Nz, src, dst);
     KERNEL_CHECK();
     return OCN_OK;
 }
 
-// stage 1: forward FFT in z and y on zfield (:148-151), pack for transpose_y_to_x!. Afterwards the host layer runs
-// all_to_all(recv, send).
+// stage 1: local forward transform (:148-151), separate the column pairs and pack for transpose_y_to_x!. Afterwards the
+// host layer runs all_to_all(recv, send).
 extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s) {
     NEED_INIT();
     if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
     int rc;
-    if ((rc = plan_set_stream(s->plan_yz))) return rc;
-    FFT_TRY(hipfftExecZ2Z(s->plan_yz, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
-    return transpose_stage(s, 0, s->zfield, s->send);
+    if ((rc = plan_set_stream(s->plan_loc))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
+    hipLaunchKernelGGL(dist_pack_forward_kernel, grid3(s->Nxh, s->Nyp, s->Nz, BLK), BLK, 0, g_stream, s->zfield, s->send, s->Nxl, s->Nxh,
+                       s->Ny, s->Nyh, s->Nyc, s->Nyp, s->Nz, s->zmode == 0);
+    KERNEL_CHECK();
+    return OCN_OK;
 }
 
-// stage 2: unpack into the x-local layout, forward FFT in x, spectral divide, backward FFT in x (:152-166), pack for
-// transpose_x_to_y!. Afterwards the host layer runs all_to_all(recv, send) again.
+// stage 2: unpack into the x-local layout, forward FFT in x, spectral divide | tridiagonal solve, backward FFT in x
+// (:152-166), pack for transpose_x_to_y!. Afterwards the host layer runs all_to_all(recv, send) again.
 extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s) {
     NEED_INIT();
     if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
@@ -1001,24 +1068,38 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s) {
     if ((rc = transpose_stage(s, 1, s->recv, s->xfield))) return rc;
     if ((rc = plan_set_stream(s->plan_x))) return rc;
     FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)s->xfield, (hipfftDoubleComplex *)s->xfield, HIPFFT_FORWARD));
-    hipLaunchKernelGGL(dist_spectral_divide_kernel, grid3(s->Nxg, s->Nyl, s->Nz, BLK), BLK, 0, g_stream, s->xfield, s->lam[0], s->lam[1],
-                       s->lam[2], s->Nxg, s->Nyl, s->Nz, s->rank * s->Nyl);
-    FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)s->xfield, (hipfftDoubleComplex *)s->xfield, HIPFFT_BACKWARD));
-    return transpose_stage(s, 2, s->xfield, s->send);
+    double2 *sol = s->xfield;
+    if (s->zmode == 0) {
+        const double scale = 1.0 / ((double)s->Nxg * (double)s->Ny * (double)s->Nz);
+        hipLaunchKernelGGL(dist_spectral_divide_kernel, grid3(s->Nxg, s->Nyc, s->Nz, BLK), BLK, 0, g_stream, s->xfield, s->lam[0],
+                           s->lam[1], s->lam[2], s->Nxg, s->Nyc, s->Nz, s->rank * s->Nyc, s->Ny, scale);
+    } else {
+        const double scale = 1.0 / ((double)s->Nxg * (double)s->Ny);
+        hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((s->Nxg + 63) / 64, s->Nyc), dim3(64), 0, g_stream, s->Nxg, s->Nxg, s->Nyc, s->Nz,
+                           s->lower, s->D, s->lower, s->xfield, s->t, s->xsol, scale, true);
+        // the serial solver subtracts the mean (fourier_tridiagonal_poisson_solver.jl:233); the reference's distributed
+        // solver does not -- the difference is a constant in p, which only its gradient uses. Kept identical to the
+        // single-GPU path: the (0, 0) column lives on rank 0.
+        if (s->rank == 0)
+            hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, g_stream, s->xsol, (long)s->Nxg * s->Nyc, s->Nz);
+        sol = s->xsol;
+    }
+    FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)sol, (hipfftDoubleComplex *)sol, HIPFFT_BACKWARD));
+    return transpose_stage(s, 2, sol, s->send);
 }
 
-// stage 3: unpack into zfield, backward FFT in y and z, copy the (normalised) real part into the haloed pressure (:167-178)
+// stage 3: rebuild the paired spectrum, local backward transform, copy into the haloed pressure (:167-178)
 extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
     NEED_INIT();
     if (!s || !s->recv || !phi) return fail(OCN_EINVAL, "solver / buffers not set");
     const DGrid &g = s->grid->d;
     int rc;
-    if ((rc = transpose_stage(s, 3, s->recv, s->zfield))) return rc;
-    if ((rc = plan_set_stream(s->plan_yz))) return rc;
-    FFT_TRY(hipfftExecZ2Z(s->plan_yz, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
-    const double scale = 1.0 / ((double)s->Nxg * (double)s->Ny * (double)s->Nz);
-    hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C), s->zfield, scale, true,
-                       (const double2 *)nullptr);
+    hipLaunchKernelGGL(dist_combine_backward_kernel, grid3(s->Nxh, s->Ny, s->Nz, BLK), BLK, 0, g_stream, s->recv, s->zfield, s->Nxl, s->Nxh,
+                       s->Ny, s->Nyh, s->Nyc, s->Nz, s->zmode == 0);
+    if ((rc = plan_set_stream(s->plan_loc))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
+                       (const double *)s->zfield, s->Nxe);
     KERNEL_CHECK();
     return OCN_OK;
 }

@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 // pressure: source term, correction, scaling (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl)
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool REAL_OUT>
-__global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, void *rhs, bool weight_by_dz) {
+// rhs element (i, j, k) is stored at (i-1) + sj*(j-1) + sk*(k-1); `pad` (real output only): the row has one extra, zero,
+// element after i = Nx (odd local Nx on the distributed solver's paired-column layout)
+__global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, void *rhs, bool weight_by_dz,
+                                                          long sj, long sk, bool pad) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
@@ -200,9 +203,11 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     double dz = az * w.at(i, j, k + 1) - az * w.at(i, j, k);
     double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
     double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
-    const long q = (long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1));
-    if (REAL_OUT) ((double *)rhs)[q] = val;                 // real-to-complex transform path (rhs is real by construction)
-    else ((double2 *)rhs)[q] = make_double2(val, 0.0);      // the reference's complex storage
+    const long q = (long)(i - 1) + sj * (j - 1) + sk * (k - 1);
+    if (REAL_OUT) {                                         // real-transform paths (rhs is real by construction)
+        ((double *)rhs)[q] = val;
+        if (pad && i == g.Nx) ((double *)rhs)[q + 1] = 0.0;
+    } else ((double2 *)rhs)[q] = make_double2(val, 0.0);    // the reference's complex storage
 }
 
 __global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p) {
@@ -396,24 +401,28 @@ __global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsig
 // fill_send_buffers! / recv_from_buffers! for a 1-D x partition (communication_buffers.jl:281-313): the west / east
 // buffers hold Hx x Py x Pz slabs -- the whole parent extent in y and z, so corners ride along (:53,71-76).
 // PACK: west_send <- parent[Hx .. 2Hx), east_send <- parent[Nx .. Nx+Hx);  UNPACK: parent[0 .. Hx) <- west_recv,
-// parent[Nx+Hx .. Nx+2Hx) <- east_recv. Buffers are field-major: field f at offset f * Hx*Py*Pz.
+// parent[Nx+Hx .. Nx+2Hx) <- east_recv. Buffers are field-major; field f (its own Py x Pz: Face fields on Bounded
+// dimensions have one more plane) starts at off[f] and holds rows[f] = Py*Pz rows of Hx values.
+struct SlabList {
+    long off[OCN_MAX_FIELDS];
+    long rows[OCN_MAX_FIELDS];
+};
 template <bool PACK>
-__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, int P0, int P1, int P2, int N, int H,
-                                                            double *west, double *east) {
-    const long slab = (long)H * P1 * P2;
-    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= slab) return;
+__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabList sl, int P0, int N, int H, double *west, double *east) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int h = t % H;
     const long r = t / H;                      // j + P1 * k
     const long row = r * P0;
     for (int f = 0; f < fl.n; ++f) {
+        if (r >= sl.rows[f]) continue;
         double *p = fl.p[f];
+        const long b = sl.off[f] + t;
         if (PACK) {
-            west[f * slab + t] = p[row + H + h];
-            east[f * slab + t] = p[row + N + h];
+            west[b] = p[row + H + h];
+            east[b] = p[row + N + h];
         } else {
-            p[row + h] = west[f * slab + t];
-            p[row + N + H + h] = east[f * slab + t];
+            p[row + h] = west[b];
+            p[row + N + H + h] = east[b];
         }
     }
 }
@@ -442,20 +451,74 @@ __global__ void __launch_bounds__(256) transpose_stage_kernel(int dir, int R, in
 }
 
 // _solve_poisson_in_spectral_space! (distributed_fft_based_poisson_solver.jl:180-188) on the x-local layout
-// (Nxg, Nyl, Nz): ϕ̂ = -b̂ / (λx + λy + λz), λy indexed with the rank's y offset; zeroth mode zeroed on the rank owning it
+// (Nxg, Nyc, Nz): ϕ̂ = -b̂ / (λx + λy + λz), λy indexed with the rank's mode offset; zeroth mode zeroed on the rank owning
+// it. `scale` folds the inverse-transform normalisation. Padding modes (j >= Ny) carry zeros and are clamped.
 __global__ void __launch_bounds__(256) dist_spectral_divide_kernel(double2 *b, const double *lx, const double *ly, const double *lz,
-                                                                   int Nxg, int Nyl, int Nz, int joff) {
+                                                                   int Nxg, int Nyc, int Nz, int joff, int Ny, double scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
     const int k = blockIdx.z;
-    if (i >= Nxg || j >= Nyl || k >= Nz) return;
-    const long q = (long)i + (long)Nxg * (j + (long)Nyl * k);
-    double lam = (lx[i] + ly[joff + j]) + lz[k] - 0.0;
+    if (i >= Nxg || j >= Nyc || k >= Nz) return;
+    const long q = (long)i + (long)Nxg * (j + (long)Nyc * k);
+    const int jg = min(joff + j, Ny - 1);
+    double lam = (lx[i] + ly[jg]) + lz[k] - 0.0;
     double2 val = b[q];
-    val.x = -val.x / lam;
-    val.y = -val.y / lam;
+    val.x = -(val.x * scale) / lam;
+    val.y = -(val.y * scale) / lam;
     if (i == 0 && joff + j == 0 && k == 0) { val.x = 0.0; val.y = 0.0; }
     b[q] = val;
+}
+
+// Distributed real-data transforms without real-to-complex plans: the dense real right-hand side (Nxe, Nz, Ny) -- x fastest,
+// then z, then y -- is read as a complex array Z of (Nxh = Nxe/2, Nz, Ny): column pair (2i', 2i'+1) = (re, im). After the
+// local complex transform in (y, z) [or y only], the transforms A, B of the two real columns are separated with the
+// Hermitian symmetry  A(m) = (Z(m) + conj Z(-m)) / 2,  B(m) = (Z(m) - conj Z(-m)) / 2i,  and only the modes
+// j = 0 .. Ny/2 are kept: HALF the bytes of the reference's complex-to-complex transposes go over xGMI.
+// Pack for transpose_y_to_x! (distributed_transpose.jl:25-95): send chunk q = modes j in [q*Nyc, (q+1)*Nyc), layout
+// (i, jl, k) with i fastest. zmirror: the z direction was transformed too (mirror k -> (Nz-k) % Nz).
+__global__ void __launch_bounds__(256) dist_pack_forward_kernel(const double2 *Z, double2 *send, int Nxl, int Nxh, int Ny, int Nyh,
+                                                                int Nyc, int Nyp, int Nz, bool zmirror) {
+    const int ih = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (ih >= Nxh || j >= Nyp || k >= Nz) return;
+    const int q = j / Nyc, jl = j - q * Nyc;
+    const long base = (((long)q * Nz + k) * Nyc + jl) * Nxl + 2 * ih;
+    double2 A = make_double2(0.0, 0.0), B = A;
+    if (j < Nyh) {
+        const int jm = j == 0 ? 0 : Ny - j, km = (zmirror && k != 0) ? Nz - k : k;
+        const double2 z1 = Z[ih + (long)Nxh * (k + (long)Nz * j)];
+        const double2 z2 = Z[ih + (long)Nxh * (km + (long)Nz * jm)];
+        A = make_double2(0.5 * (z1.x + z2.x), 0.5 * (z1.y - z2.y));
+        B = make_double2(0.5 * (z1.y + z2.y), 0.5 * (z2.x - z1.x));
+    }
+    send[base] = A;
+    if (2 * ih + 1 < Nxl) send[base + 1] = B;
+}
+
+// Unpack after transpose_x_to_y!: rebuild Z = A + iB for ALL modes j (upper half from the conjugate symmetry)
+__global__ void __launch_bounds__(256) dist_combine_backward_kernel(const double2 *recv, double2 *Z, int Nxl, int Nxh, int Ny, int Nyh,
+                                                                    int Nyc, int Nz, bool zmirror) {
+    const int ih = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (ih >= Nxh || j >= Ny || k >= Nz) return;
+    const bool cj = j >= Nyh;
+    const int jj = cj ? Ny - j : j, kk = (cj && zmirror && k != 0) ? Nz - k : k;
+    const int q = jj / Nyc, jl = jj - q * Nyc;
+    const long base = (((long)q * Nz + kk) * Nyc + jl) * Nxl + 2 * ih;
+    const double2 A = recv[base];
+    const double2 B = (2 * ih + 1 < Nxl) ? recv[base + 1] : make_double2(0.0, 0.0);
+    Z[ih + (long)Nxh * (k + (long)Nz * j)] = cj ? make_double2(A.x + B.y, B.x - A.y) : make_double2(A.x - B.y, A.y + B.x);
+}
+
+// real (Nxe, Nz, Ny) -> haloed pressure interior (copy_real_component!, fft_based_poisson_solver.jl:129-137)
+__global__ void __launch_bounds__(256) dist_copy_real_kernel(DGrid g, FView phi, const double *src, int Nxe) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    phi.at(i, j, k) = src[(long)(i - 1) + (long)Nxe * ((k - 1) + (long)g.Nz * (j - 1))];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

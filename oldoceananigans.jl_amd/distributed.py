@@ -174,21 +174,18 @@ class DeviceBackend:
         self.Gm = [Field(l, g) for l in locs]
         self.p = Field((Center,) * 3, g)
         nf = len(locs)
-        Px, Py, Pz = g.total_size((Center,) * 3)
-        slab = g.Hx * Py * Pz
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=ctx.device)   # noqa: E731
-        self.ws, self.es, self.wr, self.er = mk(slab * nf), mk(slab * nf), mk(slab * nf), mk(slab * nf)
-        self.slab = slab
+        total = sum(self._slab(f) for f in self.U)
+        self.ws, self.es, self.wr, self.er = mk(total), mk(total), mk(total), mk(total)
         h = C.c_void_p()
         _lib.check(L.ocn_dist_poisson_create(C.byref(h), g.handle, ctx.world, ctx.rank, grid.Lx_global))
         self.solver = h
-        n = g.Nx * g.Ny * g.Nz
-        self.send = torch.zeros(2 * n, dtype=torch.float64, device=ctx.device)
-        self.recv = torch.zeros(2 * n, dtype=torch.float64, device=ctx.device)
+        n = C.c_size_t()
+        _lib.check(L.ocn_dist_poisson_buffer_size(h, C.byref(n)))
+        self.send = torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
+        # one rank: the "transposes" are the identity -- alias the buffers instead of copying
+        self.recv = self.send if ctx.world == 1 else torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
         _lib.check(L.ocn_dist_poisson_set_buffers(h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
-        rhs = C.c_void_p()
-        _lib.check(L.ocn_dist_poisson_rhs(h, C.byref(rhs)))
-        self.rhs = rhs
         self.profile, self.events, self.n_evals = False, [], 0
 
     # -- halos ---------------------------------------------------------------------------------------------------
@@ -197,8 +194,13 @@ class DeviceBackend:
         _lib.check(L.ocn_fill_halo_regions(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
                                            int(fill_open_bcs)))
 
+    def _slab(self, f):
+        """doubles one field contributes per side: Hx x Py x Pz of ITS parent (Face fields on Bounded dims have one more plane)"""
+        _, Py, Pz = self.grid.local.total_size(f.loc)
+        return self.grid.local.Hx * Py * Pz
+
     def pack_x(self, fields):
-        n = len(fields) * self.slab
+        n = sum(self._slab(f) for f in fields)
         _lib.check(_lib.lib().ocn_pack_x_halos(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
                                                C.c_void_p(self.ws.data_ptr()), C.c_void_p(self.es.data_ptr())))
         return self.ws[:n], self.es[:n], self.wr[:n], self.er[:n]
@@ -239,7 +241,7 @@ class DeviceBackend:
 
     def source_term(self):
         U = self.U
-        _lib.check(_lib.lib().ocn_compute_source_term(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.rhs, 0))
+        _lib.check(_lib.lib().ocn_dist_poisson_source_term(self.solver, U[0].data, U[1].data, U[2].data))
 
     def poisson_forward_yz(self):
         _lib.check(_lib.lib().ocn_dist_poisson_forward_yz(self.solver))
@@ -334,9 +336,11 @@ def solve_for_pressure(model):
     b, ctx = model.backend, model.ctx
     b.source_term()
     b.poisson_forward_yz()
-    ctx.all_to_all(b.recv, b.send)        # transpose_y_to_x!
+    if b.recv is not b.send:
+        ctx.all_to_all(b.recv, b.send)    # transpose_y_to_x!
     b.poisson_solve_x()
-    ctx.all_to_all(b.recv, b.send)        # transpose_x_to_y!
+    if b.recv is not b.send:
+        ctx.all_to_all(b.recv, b.send)    # transpose_x_to_y!
     b.poisson_backward_yz()
 
 

@@ -10,12 +10,20 @@ import numpy as np
 import pytest
 
 from dist_worker import analytic
-from helpers import rel_err
+from helpers import rel_err, tanh_faces
 
 pytestmark = pytest.mark.gpu
 
 
-def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos):
+def _z_and_topology(ocn, zkind, Nz):
+    if zkind == "periodic":
+        return (0.0, 1.0), (ocn.Periodic, ocn.Periodic, ocn.Periodic)
+    if zkind == "bounded":
+        return (-1.0, 0.0), (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+    return tanh_faces(Nz), (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+
+
+def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"):
     import torch
     from oldoceananigans_jl_amd import distributed as dist
     from loopback import LoopbackWorld
@@ -25,7 +33,8 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos):
     def worker(rank):
         try:
             ctx = world.context(rank)
-            grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0))
+            z, topo = _z_and_topology(ocn, zkind, size[2])
+            grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
             model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
             model.async_halos = async_halos
             flds = model.fields()
@@ -51,17 +60,23 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos):
     return results
 
 
-@pytest.mark.parametrize("R,async_halos", [(2, False), (2, True), (4, True)])
-def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_halos):
+@pytest.mark.parametrize("R,async_halos,size,zkind", [
+    (2, False, (32, 16, 8), "periodic"), (2, True, (32, 16, 8), "periodic"), (4, True, (32, 16, 8), "periodic"),
+    (4, True, (36, 12, 10), "periodic"),       # odd local Nx (9): padded column pair; Ny/2+1 = 7 modes over 4 ranks
+    (2, True, (32, 16, 8), "bounded"),         # z Bounded: distributed Fourier-tridiagonal solver
+    (4, True, (28, 8, 12), "stretched"),       # stretched z, odd local Nx (7)
+])
+def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_halos, size, zkind):
     import ctypes as C
     import torch
     from oldoceananigans_jl_amd import _lib
-    size, nsteps = (32, 16, 8), 3
+    nsteps = 3
     # the distributed path runs on torch's current stream
     _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    results = _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos)
+    results = _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind)
     # single-GPU product model on the global grid
-    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0))
+    z, topo = _z_and_topology(ocn, zkind, size[2])
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
     ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
     dt = 0.1 * grid.Δxᶜᵃᵃ / 0.6
@@ -70,12 +85,13 @@ def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_h
     glob = {n: f.parent() for n, f in model.fields().items()}
     glob["p"] = model.pressures.pNHS.parent()
     nxl = size[0] // R
-    # third opinion: the serial oracle (tells which side is wrong if the two product paths ever disagree)
-    from test_distributed_cpu import _serial
-    om = _serial(oracle, size, nsteps)
-    for name, cn in (("u", "u"), ("T", "c0"), ("p", "p")):
-        ref = om.field(cn)
-        assert rel_err(glob[name][3:-3, 3:-3, 3:-3], ref[3:-3, 3:-3, 3:-3]) < 1e-12, ("single-GPU model vs oracle", name)
+    if zkind == "periodic":
+        # third opinion: the serial oracle (tells which side is wrong if the two product paths ever disagree)
+        from test_distributed_cpu import _serial
+        om = _serial(oracle, size, nsteps)
+        for name, cn in (("u", "u"), ("T", "c0"), ("p", "p")):
+            ref = om.field(cn)
+            assert rel_err(glob[name][3:-3, 3:-3, 3:-3], ref[3:-3, 3:-3, 3:-3]) < 1e-12, ("single-GPU model vs oracle", name)
     for r, (out, div, time) in enumerate(results):
         assert div < 5e-8 and time == model.clock.time
         for name, a in out.items():
