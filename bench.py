@@ -153,6 +153,9 @@ def main():
 
     if distributed:
         elapsed = ctx.allreduce_max(elapsed)
+        ctx.barrier()
+        model.backend.close()
+        ctx.dist.destroy_process_group()
     if rank != 0:
         return
     cells = float(N) ** 3 * world
@@ -181,7 +184,7 @@ def main():
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
                      "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only (the bench contract)
         out["cpu_baseline"] = cpu_baseline(N, dt)
     print(json.dumps(out))
 

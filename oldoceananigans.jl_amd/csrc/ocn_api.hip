@@ -518,6 +518,11 @@ struct ocn_poisson_s {
     double2 *hc2 = nullptr;      // kind 1: tridiagonal solution (separate from the rhs like the reference's storage)
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     bool has_r2c = false, has_c2r = false, c2r_strided = false;
+    // grids with Bounded transformed directions: per-direction line transforms (see ocn_kernels.h, line_gather_kernel)
+    bool general = false;
+    hipfftHandle plan_line[3] = {0, 0, 0};
+    bool has_line[3] = {false, false, false};   // owns the handle (directions of equal length share one plan)
+    double2 *buffer = nullptr;
 };
 
 // Solvers/poisson_eigenvalues.jl:8-23
@@ -535,6 +540,9 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
     if (s->has_plan) hipfftDestroy(s->plan);
     if (s->has_r2c) hipfftDestroy(s->plan_r2c);
     if (s->has_c2r) hipfftDestroy(s->plan_c2r);
+    for (int d = 0; d < 3; ++d)
+        if (s->has_line[d]) hipfftDestroy(s->plan_line[d]);
+    hipFree(s->buffer);
     hipFree(s->rrhs); hipFree(s->hc); hipFree(s->hc2);
     hipFree(s->storage); hipFree(s->source); hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     hipFree(s->partial); hipFree(s->mean);
@@ -609,21 +617,48 @@ static int verify_complex_plan(hipfftHandle plan, double2 *buf, long n, double s
     return OCN_OK;
 }
 
+// FFT plans capture a stream at creation; re-point them when the library stream changed (ocn_set_stream)
+static int plan_set_stream(hipfftHandle plan) {
+    FFT_TRY(hipfftSetStream(plan, g_stream));
+    return OCN_OK;
+}
+
 // complex-to-complex resources of the reference's API (solve!(ϕ, solver, b) with a complex b): created on first use so
 // that the model fast path keeps only its two real plans alive
 static int ensure_complex(ocn_poisson_s *s) {
-    if (s->has_plan) return OCN_OK;
+    if (s->has_plan || s->buffer) return OCN_OK;
     const DGrid &g = s->grid->d;
     HIP_TRY(dev_alloc((void **)&s->storage, s->n * sizeof(double2)));
     HIP_TRY(hipMemsetAsync(s->storage, 0, s->n * sizeof(double2), g_stream));
-    hipfftResult r;
-    if (s->kind == 0) {
-        r = hipfftPlan3d(&s->plan, g.Nz, g.Ny, g.Nx, HIPFFT_Z2Z);
-    } else {
+    if (s->kind == 1) {
         HIP_TRY(dev_alloc((void **)&s->source, s->n * sizeof(double2)));
         HIP_TRY(hipMemsetAsync(s->source, 0, s->n * sizeof(double2), g_stream));
         HIP_TRY(dev_alloc((void **)&s->partial, 1024 * sizeof(double2)));
         HIP_TRY(dev_alloc((void **)&s->mean, sizeof(double2)));
+    }
+    if (s->general) {
+        HIP_TRY(dev_alloc((void **)&s->buffer, s->n * sizeof(double2)));
+        const int N[3] = {g.Nx, g.Ny, g.Nz};
+        const int ndims = s->kind == 0 ? 3 : 2;
+        for (int d = 0; d < ndims; ++d) {
+            int shared = -1;
+            for (int e = 0; e < d; ++e)
+                if (N[e] == N[d]) shared = e;
+            if (shared >= 0) { s->plan_line[d] = s->plan_line[shared]; continue; }
+            int nn[1] = {N[d]};
+            hipfftResult r = hipfftPlanMany(&s->plan_line[d], 1, nn, nullptr, 1, N[d], nullptr, 1, N[d], HIPFFT_Z2Z, (int)(s->n / N[d]));
+            if (r != HIPFFT_SUCCESS) return fail(1000 + (int)r, "hipfftPlanMany(line, dim %d) failed (%d)", d, (int)r);
+            s->has_line[d] = true;
+            FFT_TRY(hipfftSetStream(s->plan_line[d], g_stream));
+            int rc = verify_complex_plan(s->plan_line[d], s->buffer, (long)s->n, 1.0 / (double)N[d], "line transform");
+            if (rc) return rc;
+        }
+        return OCN_OK;
+    }
+    hipfftResult r;
+    if (s->kind == 0) {
+        r = hipfftPlan3d(&s->plan, g.Nz, g.Ny, g.Nx, HIPFFT_Z2Z);
+    } else {
         int nfft[2] = {g.Ny, g.Nx};
         r = hipfftPlanMany(&s->plan, 2, nfft, nullptr, 1, g.Nx * g.Ny, nullptr, 1, g.Nx * g.Ny, HIPFFT_Z2Z, g.Nz);
     }
@@ -634,9 +669,37 @@ static int ensure_complex(ocn_poisson_s *s) {
     return verify_complex_plan(s->plan, s->storage, (long)s->n, scale, "complex-to-complex");
 }
 
-// FFT plans capture a stream at creation; re-point them when the library stream changed (ocn_set_stream)
-static int plan_set_stream(hipfftHandle plan) {
-    FFT_TRY(hipfftSetStream(plan, g_stream));
+// one direction of the transform on a grid with Bounded directions (forward: physical -> spectral)
+static int transform_dim(ocn_poisson_s *s, double2 *A, int d, bool forward) {
+    const DGrid &g = s->grid->d;
+    const int T[3] = {g.tx, g.ty, g.tz};
+    const int mode = T[d] == OCN_BOUNDED ? (forward ? 1 : 2) : 0;
+    { int rc_ = plan_set_stream(s->plan_line[d]); if (rc_) return rc_; }
+    const int dir = forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD;
+    if (mode == 0 && d == 0) {          // x lines are contiguous already
+        FFT_TRY(hipfftExecZ2Z(s->plan_line[d], (hipfftDoubleComplex *)A, (hipfftDoubleComplex *)A, dir));
+        return OCN_OK;
+    }
+    hipLaunchKernelGGL(line_gather_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, A, s->buffer, g.Nx, g.Ny, g.Nz, d, mode);
+    FFT_TRY(hipfftExecZ2Z(s->plan_line[d], (hipfftDoubleComplex *)s->buffer, (hipfftDoubleComplex *)s->buffer, dir));
+    hipLaunchKernelGGL(line_scatter_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->buffer, A, g.Nx, g.Ny, g.Nz, d, mode);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// Bounded directions first on the way in, last on the way out (plan_transforms.jl:44-65)
+static int transform_all(ocn_poisson_s *s, double2 *A, bool forward) {
+    const DGrid &g = s->grid->d;
+    const int T[3] = {g.tx, g.ty, g.tz};
+    const int ndims = s->kind == 0 ? 3 : 2;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int d = 0; d < ndims; ++d) {
+            const bool bounded = T[d] == OCN_BOUNDED;
+            if ((pass == 0) == (bounded == forward)) {
+                int rc = transform_dim(s, A, d, forward);
+                if (rc) return rc;
+            }
+        }
     return OCN_OK;
 }
 
@@ -644,11 +707,10 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
     NEED_INIT();
     if (!solver || !grid) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = grid->d;
-    if (g.tx != OCN_PERIODIC || g.ty != OCN_PERIODIC)
-        return fail(OCN_ENOTSUP, "Bounded x / y need the DCT transforms (discrete_transforms.jl:108-169): not accelerated yet");
-    if (kind == -1) kind = (g.tz == OCN_BOUNDED) ? 1 : 0;   // see DESIGN.md: z-Bounded always takes the tridiagonal path
-    if (kind == 0 && g.tz != OCN_PERIODIC)
-        return fail(OCN_ENOTSUP, "FFTBasedPoissonSolver with Bounded z needs a DCT: use kind 1 (Fourier-tridiagonal)");
+    for (int t : {g.tx, g.ty, g.tz})
+        if (t != OCN_PERIODIC && t != OCN_BOUNDED)
+            return fail(OCN_ENOTSUP, "Poisson solvers need Periodic or Bounded directions (a FullyConnected x belongs to ocn_dist_poisson_create)");
+    if (kind == -1) kind = (g.tz == OCN_BOUNDED) ? 1 : 0;   // see DESIGN.md: z-Bounded takes the tridiagonal path by default
     if (kind == 0 && !grid->z_regular) return fail(OCN_EINVAL, "FFTBasedPoissonSolver requires a regular grid");
     if (kind == 1 && g.tz != OCN_BOUNDED)
         return fail(OCN_EINVAL, "`FourierTridiagonalPoissonSolver` can only be used when the stretched direction's topology is `Bounded`.");
@@ -656,6 +718,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
     ocn_poisson_s *s = new ocn_poisson_s();
     s->grid = grid; s->kind = kind;
     s->n = (size_t)g.Nx * g.Ny * g.Nz;
+    s->general = g.tx == OCN_BOUNDED || g.ty == OCN_BOUNDED || (kind == 0 && g.tz == OCN_BOUNDED);
     int rc = OCN_OK;
 #define TRY_OR_FREE(expr)                                                                                  \
     do {                                                                                                   \
@@ -693,6 +756,11 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             TRY_OR_FREE(hipMemcpy(s->lower, lower.data(), lower.size() * sizeof(double), hipMemcpyHostToDevice));
         }
         hipfftResult r;
+        if (s->general) {   // cosine transforms: complex storage + per-direction line transforms, created (and verified) now
+            if ((rc = ensure_complex(s))) goto bad;
+            *solver = s;
+            return OCN_OK;
+        }
         // ---- real-transform path (the complex-to-complex resources of the reference API are created on first use) ----
         s->Nxh = g.Nx / 2 + 1;
         s->nh = (size_t)s->Nxh * g.Ny * g.Nz;
@@ -754,6 +822,31 @@ static int poisson_solve(ocn_poisson_s *s, double *phi) {
     const DGrid &g = s->grid->d;
     { int rc_ = ensure_complex(s); if (rc_) return rc_; }
     FView vphi = make_view(g, phi, LOC_C);
+    if (s->general) {
+        int rc;
+        double2 *sol = s->storage;
+        if (s->kind == 0) {
+            if ((rc = transform_all(s, s->storage, true))) return rc;
+            hipLaunchKernelGGL(spectral_divide_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->storage, s->lam[0],
+                               s->lam[1], s->lam[2], g.Nx, g.Ny, g.Nz, 1.0, false);
+        } else {
+            if ((rc = transform_all(s, s->source, true))) return rc;
+            hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((g.Nx + 63) / 64, g.Ny), dim3(64), 0, g_stream, g.Nx, g.Nx, g.Ny, g.Nz, s->lower,
+                               s->D, s->lower, s->source, s->t, s->storage, 1.0, false);
+        }
+        if ((rc = transform_all(s, sol, false))) return rc;
+        const double scale = s->kind == 0 ? 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz) : 1.0 / ((double)g.Nx * (double)g.Ny);
+        const double2 *mean = nullptr;
+        if (s->kind == 1) {
+            const int nb = 1024;
+            hipLaunchKernelGGL(sum_partial_kernel, dim3(nb), dim3(256), 0, g_stream, s->storage, (long)s->n, s->partial);
+            hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, g_stream, s->partial, nb, 1.0 / (double)s->n, scale, s->mean);
+            mean = s->mean;
+        }
+        hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vphi, s->storage, scale, true, mean);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     { int rc_ = plan_set_stream(s->plan); if (rc_) return rc_; }
     if (s->kind == 0) {
         // fft_based_poisson_solver.jl:95-125
@@ -818,7 +911,7 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
 static int solve_for_pressure(ocn_poisson_s *s, const double *u, const double *v, const double *w, double *p) {
     const DGrid &g = s->grid->d;
     int rc;
-    if (g_real_fft) {
+    if (g_real_fft && !s->general) {
         if ((rc = source_term(g, u, v, w, s->rrhs, s->kind == 1, true))) return rc;
         return poisson_solve_real(s, p);
     }

@@ -334,6 +334,67 @@ __global__ void __launch_bounds__(256) copy_dense_real_kernel(DGrid g, FView phi
     phi.at(i, j, k) = src[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-dimension transforms for grids with Bounded (cosine-transform) directions -- DiscreteTransform on the GPU
+// (Solvers/discrete_transforms.jl:108-175, index_permutations.jl:18-72, plan_transforms.jl:39-136).
+// Each direction d is transformed on its own: GATHER the lines of A (Nx, Ny, Nz) along d into a line-contiguous buffer B
+// (B[m + N*line]), run ONE unit-stride batched complex FFT, SCATTER back. The cosine transforms ride on the same FFT
+// (Makhoul 1980): forward  v = even-odd permutation of x, V = FFT(v), Y[k] = 2 Re(e^{-iπk/2N} V[k])   (= FFTW REDFT10);
+// backward V[k] = e^{iπk/2N} (Y[k] - i Y[N-k]) / 2, v = N * IFFT(V), x = unpermuted v  -- i.e. N x like an unnormalised
+// inverse FFT, so every direction contributes the same 1/N to the normalisation. Bounded directions are transformed FIRST
+// on the way in and LAST on the way out (plan_transforms.jl:44-65) so that their input is real.
+// mode 0: Periodic (plain copy); 1: Bounded forward; 2: Bounded backward.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int line_perm(int n, int N) { return (n & 1) ? N - 1 - (n >> 1) : (n >> 1); }
+
+__global__ void __launch_bounds__(256) line_gather_kernel(const double2 *A, double2 *B, int Nx, int Ny, int Nz, int d, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= Nx || j >= Ny || k >= Nz) return;
+    const long sx = 1, sy = Nx, sz = (long)Nx * Ny;
+    const long q = i * sx + j * sy + k * sz;
+    const int n = d == 0 ? i : (d == 1 ? j : k);
+    const int N = d == 0 ? Nx : (d == 1 ? Ny : Nz);
+    const long sd = d == 0 ? sx : (d == 1 ? sy : sz);
+    const long line = d == 0 ? (j + (long)Ny * k) : (d == 1 ? (i + (long)Nx * k) : (i + (long)Nx * j));
+    double2 val = A[q];
+    int m = n;
+    if (mode == 1) {
+        m = line_perm(n, N);
+        val.y = 0.0;
+    } else if (mode == 2) {
+        const double yk = val.x;
+        const double ynk = n == 0 ? 0.0 : A[q + (long)(N - 2 * n) * sd].x;     // Y[N - n], Y[N] := 0
+        double sn, cs;
+        sincospi((double)n / (2.0 * (double)N), &sn, &cs);
+        // e^{iπn/2N} (yk - i ynk) / 2
+        val = make_double2(0.5 * (cs * yk + sn * ynk), 0.5 * (sn * yk - cs * ynk));
+    }
+    B[m + (long)N * line] = val;
+}
+
+__global__ void __launch_bounds__(256) line_scatter_kernel(const double2 *B, double2 *A, int Nx, int Ny, int Nz, int d, int mode) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= Nx || j >= Ny || k >= Nz) return;
+    const long q = i + (long)Nx * (j + (long)Ny * k);
+    const int n = d == 0 ? i : (d == 1 ? j : k);
+    const int N = d == 0 ? Nx : (d == 1 ? Ny : Nz);
+    const long line = d == 0 ? (j + (long)Ny * k) : (d == 1 ? (i + (long)Nx * k) : (i + (long)Nx * j));
+    if (mode == 0) {
+        A[q] = B[n + (long)N * line];
+    } else if (mode == 1) {
+        const double2 V = B[n + (long)N * line];
+        double sn, cs;
+        sincospi((double)n / (2.0 * (double)N), &sn, &cs);
+        A[q] = make_double2(2.0 * (cs * V.x + sn * V.y), 0.0);                   // 2 Re(e^{-iπn/2N} V)
+    } else {
+        A[q] = make_double2(B[line_perm(n, N) + (long)N * line].x, 0.0);
+    }
+}
+
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
 __global__ void __launch_bounds__(256) sum_partial_kernel(const double2 *x, long n, double2 *partial) {
     __shared__ double sx[256], sy[256];

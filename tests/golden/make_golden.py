@@ -25,6 +25,7 @@ from helpers import smooth_state, tanh_faces  # noqa: E402
 CASES = {
     "ppp_16": dict(size=(16, 16, 16), topology=(0, 0, 0), z=(0.0, 1.0), nsteps=3),
     "ppb_stretched_16x16x12": dict(size=(16, 16, 12), topology=(0, 0, 1), z="tanh", nsteps=3),
+    "bbb_12x10x8": dict(size=(12, 10, 8), topology=(1, 1, 1), z=(-1.0, 0.0), nsteps=3),      # cosine-transform pressure solve
 }
 
 

@@ -11,10 +11,14 @@ from helpers import field_pairs, make_pair, rel_err, set_both, tanh_faces
 pytestmark = pytest.mark.gpu
 
 TOPOS = [("Periodic", "Periodic", "Periodic"), ("Periodic", "Periodic", "Bounded")]
+# topologies with Bounded x / y: cosine transforms in the pressure solver, wall fallbacks of the advection scheme in x / y
+# (the reference's list, test/test_poisson_solvers.jl:58-98)
+TOPOS_XY = [("Periodic", "Bounded", "Bounded"), ("Bounded", "Bounded", "Bounded"), ("Bounded", "Periodic", "Periodic"),
+            ("Periodic", "Bounded", "Periodic"), ("Bounded", "Periodic", "Bounded")]
 
 
 @pytest.mark.parametrize("size", [(8, 8, 8), (16, 9, 5), (3, 3, 3)])
-@pytest.mark.parametrize("topology", TOPOS)
+@pytest.mark.parametrize("topology", TOPOS + TOPOS_XY)
 def test_halo_fill_bit_exact(ocn, oracle, arch, size, topology):
     g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology)
     rng = np.random.default_rng(7)
@@ -29,7 +33,7 @@ def test_halo_fill_bit_exact(ocn, oracle, arch, size, topology):
             assert np.array_equal(f.parent(), b), (name, fill_open)
 
 
-@pytest.mark.parametrize("topology", TOPOS)
+@pytest.mark.parametrize("topology", TOPOS + TOPOS_XY)
 def test_tendencies_match_oracle(ocn, oracle, arch, topology):
     size = (16, 12, 10)
     z = tanh_faces(size[2]) if topology[2] == "Bounded" else None
@@ -47,7 +51,9 @@ def test_tendencies_match_oracle(ocn, oracle, arch, topology):
             assert np.array_equal(G_gpu, G_cpu), (impl, n, np.abs(G_gpu - G_cpu).max())
 
 
-@pytest.mark.parametrize("topology,stretched", [(TOPOS[0], False), (TOPOS[1], True), (TOPOS[1], False)])
+@pytest.mark.parametrize("topology,stretched", [(TOPOS[0], False), (TOPOS[1], True), (TOPOS[1], False),
+                                                (TOPOS_XY[0], False), (TOPOS_XY[1], False), (TOPOS_XY[1], True),
+                                                (TOPOS_XY[2], False), (TOPOS_XY[3], False), (TOPOS_XY[4], True)])
 def test_time_step_parity_10_steps(ocn, oracle, arch, topology, stretched):
     size = (16, 16, 16)
     z = tanh_faces(size[2]) if stretched else None
@@ -92,6 +98,37 @@ def test_poisson_fft_solver_residual(ocn, oracle, arch):
         p_cpu = g_cpu.zeros(oracle.LOC["c"])
         s_cpu.solve(p_cpu)
         assert rel_err(c, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-12
+
+
+@pytest.mark.parametrize("topology", TOPOS + TOPOS_XY)
+@pytest.mark.parametrize("kind", ["fft", "tridiagonal"])
+def test_poisson_solvers_all_topologies(ocn, oracle, arch, topology, kind):
+    """∇²ϕ = ∇·U-like random source, every topology of test/test_poisson_solvers.jl:58-98 (cosine transforms on Bounded
+    directions, discrete_transforms.jl:108-175), FFT-based and Fourier-tridiagonal, against the oracle's direct DCT/FFT"""
+    if kind == "tridiagonal" and topology[2] != "Bounded":
+        pytest.skip("FourierTridiagonalPoissonSolver needs a Bounded z")
+    rng = np.random.default_rng(17)
+    for size in [(16, 16, 16), (11, 16, 7), (8, 13, 27)]:
+        topo_cls = tuple(getattr(ocn, t) for t in topology)
+        z = tanh_faces(size[2]) if kind == "tridiagonal" else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo_cls)
+        solver = ocn.FFTBasedPoissonSolver(grid) if kind == "fft" else ocn.FourierTridiagonalPoissonSolver(grid)
+        R = rng.standard_normal(size)
+        R -= R.mean()
+        g_cpu = oracle.Grid(size, topology=tuple(1 if t == "Bounded" else 0 for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+        s_cpu = oracle.PoissonSolver(g_cpu, 0 if kind == "fft" else 1)
+        if kind == "tridiagonal":       # both sides take the Δzᶜ-weighted source (solve_for_pressure.jl:36-42); compatible: Σ = 0
+            R = R * np.diff(np.asarray(z))[None, None, :]
+            R -= R.mean()
+        solver.set_source_term(R)
+        s_cpu.rhs[...] = R
+        phi = ocn.CenterField(grid)
+        ocn.solve(phi, solver)
+        p_cpu = g_cpu.zeros(oracle.LOC["c"])
+        s_cpu.solve(p_cpu)
+        got = phi.parent()[3:-3, 3:-3, 3:-3]
+        assert rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-11, (size, rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]))
+        solver.close()
 
 
 def test_batched_tridiagonal_vs_dense(ocn, arch):
