@@ -78,6 +78,24 @@ int ocn_grid_parent_size(ocn_grid_t grid, const int loc[3], int P[3]);    /* tot
  * fill_open_bcs == 0). nfields fields of identical location are filled by ONE launch. */
 int ocn_fill_halo_regions(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int fill_open_bcs);
 
+/* Non-default boundary conditions with constant values on Bounded sides (BoundaryCondition{<:Flux|Value|Gradient|Open},
+ * boundary_condition.jl / boundary_condition_classifications.jl). Sides are ordered west, east, south, north, bottom, top.
+ * Value / Gradient fill ONE halo cell by linear extrapolation through the boundary face
+ * (fill_halo_regions_value_gradient.jl:7-119), Flux fills like no-flux (fill_halo_regions_flux.jl:9-27) and contributes
+ * through ocn_compute_flux_bcs, Open sets the wall-normal component on the boundary face (fill_halo_regions_open.jl:2-7).
+ * OCN_BC_DEFAULT = what field_boundary_conditions.jl:15-25 assigns. bcs[f][side]; bcs == NULL: all default. */
+#define OCN_BC_DEFAULT 0
+#define OCN_BC_FLUX 1
+#define OCN_BC_VALUE 2
+#define OCN_BC_GRADIENT 3
+#define OCN_BC_OPEN 4
+typedef struct { int kind; double value; } ocn_bc_t;
+int ocn_fill_halo_regions_bcs(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields,
+                              const ocn_bc_t (*bcs)[6], int fill_open_bcs);
+/* compute_x_bcs! / compute_y_bcs! / compute_z_bcs! (BoundaryConditions/compute_flux_bcs.jl:12-163), called by
+ * compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184): G[1] += flux A / V, G[N] -= flux A / V */
+int ocn_compute_flux_bcs(ocn_grid_t grid, double *G, const int loc[3], const ocn_bc_t bcs[6]);
+
 /* ---------------------------------------------------------------- tendencies ------------------------------------ */
 /* compute_Gu!/Gv!/Gw!/Gc! (Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:138-163) for
  * advection = WENO(order=5), every other term `nothing`. range = {i0,i1,j0,j1,k0,k1} inclusive 1-based
@@ -183,6 +201,10 @@ int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, co
  * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "profile" 1 = record HIP
  * events around every tendency evaluation on the launch stream */
 int ocn_model_set_option(ocn_model_t model, const char *key, int value);
+/* boundary_conditions = (name = FieldBoundaryConditions(side = BoundaryCondition(kind, value)),) of the model
+ * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0"..; side 0..5 = west .. top. OCN_EINVAL mirrors
+ * the reference's validation: Bounded sides only; Flux/Value/Gradient on Center-located, Open on Face-located fields */
+int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
 /* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
  * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */
 int ocn_set_option(const char *key, int value);

@@ -27,6 +27,12 @@ def build(force=False):
 # every symbol include/ocn_mi355x.h declares: name -> (restype, argtypes)
 _vp, _dp, _ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)
 _pp = C.POINTER(C.c_void_p)
+
+
+class BC(C.Structure):
+    """ocn_bc_t"""
+    _fields_ = [("kind", C.c_int), ("value", C.c_double)]
+
 SYMBOLS = {
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_sync": (C.c_int, []),
@@ -42,6 +48,9 @@ SYMBOLS = {
     "ocn_set_stream": (C.c_int, [_vp]),
     "ocn_pack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
+    "ocn_fill_halo_regions_bcs": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
+    "ocn_compute_flux_bcs": (C.c_int, [_vp, _vp, _ip, _vp]),
+    "ocn_model_set_boundary_condition": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_destroy": (C.c_int, [_vp]),
     "ocn_dist_poisson_set_buffers": (C.c_int, [_vp, _vp, _vp]),

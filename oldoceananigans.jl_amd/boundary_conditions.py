@@ -1,0 +1,76 @@
+"""Boundary conditions with constant values (reference: src/BoundaryConditions/boundary_condition.jl,
+boundary_condition_classifications.jl, field_boundary_conditions.jl). Function- and field-valued conditions are outside the
+accelerated path."""
+import ctypes as C
+
+from . import _lib
+
+SIDES = ("west", "east", "south", "north", "bottom", "top")
+KINDS = {"Default": 0, "Flux": 1, "Value": 2, "Gradient": 3, "Open": 4}
+
+
+class BoundaryCondition:
+    """BoundaryCondition(classification, condition::Number)"""
+
+    def __init__(self, classification, condition=0.0):
+        if classification not in KINDS:
+            raise ValueError(f"unknown boundary condition classification {classification}")
+        if callable(condition) or not isinstance(condition, (int, float)):
+            raise NotImplementedError("only constant (Number) boundary conditions are on the accelerated path")
+        self.classification, self.condition = classification, float(condition)
+
+    def __repr__(self):
+        return f"{self.classification}BoundaryCondition: {self.condition}"
+
+
+def FluxBoundaryCondition(value):
+    return BoundaryCondition("Flux", value)
+
+
+def ValueBoundaryCondition(value):
+    return BoundaryCondition("Value", value)
+
+
+def GradientBoundaryCondition(value):
+    return BoundaryCondition("Gradient", value)
+
+
+def OpenBoundaryCondition(value):
+    return BoundaryCondition("Open", value)
+
+
+class FieldBoundaryConditions:
+    """FieldBoundaryConditions(; west, east, south, north, bottom, top): unspecified sides keep the defaults of
+    field_boundary_conditions.jl:15-25 (Periodic -> periodic, Bounded + Center -> no flux, Bounded + Face -> impenetrable)"""
+
+    def __init__(self, **sides):
+        for s, bc in sides.items():
+            if s not in SIDES:
+                raise ValueError(f"unknown side {s}; expected one of {SIDES}")
+            if bc is not None and not isinstance(bc, BoundaryCondition):
+                raise TypeError(f"{s} must be a BoundaryCondition")
+        self.sides = {s: bc for s, bc in sides.items() if bc is not None}
+
+    def c_array(self):
+        arr = (_lib.BC * 6)()
+        for s, bc in self.sides.items():
+            arr[SIDES.index(s)].kind = KINDS[bc.classification]
+            arr[SIDES.index(s)].value = bc.condition
+        return arr
+
+
+def bc_table(fields_bcs):
+    """list of FieldBoundaryConditions | None, one per field -> ocn_bc_t[n][6]"""
+    table = ((_lib.BC * 6) * len(fields_bcs))()
+    for f, fb in enumerate(fields_bcs):
+        if fb is not None:
+            row = fb.c_array()
+            for s in range(6):
+                table[f][s].kind, table[f][s].value = row[s].kind, row[s].value
+    return table
+
+
+def compute_flux_bcs(G, bcs):
+    """compute_x_bcs! / compute_y_bcs! / compute_z_bcs! (compute_flux_bcs.jl:12-163) on the tendency field G"""
+    loc = (C.c_int * 3)(*[1 if l.__name__ == "Face" else 0 for l in G.loc])
+    _lib.check(_lib.lib().ocn_compute_flux_bcs(G.grid.handle, G.data, loc, bcs.c_array()))

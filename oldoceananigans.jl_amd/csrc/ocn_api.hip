@@ -256,8 +256,10 @@ static int check_range(const DGrid &g, const int *range, Range6 *out, const int 
 // ---------------------------------------------------------------------------------------------------------------------
 // halo fills
 // ---------------------------------------------------------------------------------------------------------------------
-static int fill_halo_group(const DGrid &g, double *const *fields, int n, const int loc[3], bool fill_open) {
+static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n, const int loc[3], bool fill_open,
+                           const ocn_bc_t (*bcs)[6]) {
     if (n <= 0) return OCN_OK;
+    const DGrid &g = grid->d;
     FieldList fl;
     fl.n = n;
     for (int f = 0; f < n; ++f) fl.p[f] = fields[f];
@@ -271,12 +273,21 @@ static int fill_halo_group(const DGrid &g, double *const *fields, int n, const i
         if (T[d] != OCN_BOUNDED) continue;
         const bool face = loc[d] == OCN_FACE;
         if (face && !fill_open) continue;
+        BcSides bc;
+        for (int f = 0; f < n; ++f)
+            for (int sd = 0; sd < 2; ++sd) {
+                bc.kind[f][sd] = bcs ? bcs[f][2 * d + sd].kind : OCN_BC_DEFAULT;
+                bc.value[f][sd] = bcs ? bcs[f][2 * d + sd].value : 0.0;
+            }
+        // Δ at the boundary faces (flip(Center) = Face): Δxᶠ = Δx, Δyᶠ = Δy, Δzᶠ[1], Δzᶠ[N+1]
+        bc.dlo = d == 0 ? g.dx : (d == 1 ? g.dy : grid->h_dzf[g.Hz]);
+        bc.dhi = d == 0 ? g.dx : (d == 1 ? g.dy : grid->h_dzf[g.Nz + g.Hz]);
         const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
         const long total = (long)Na * Nb;
         const int nb = (int)((total + 255) / 256);
-        if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[0], face, fill_open);
-        if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[1], face, fill_open);
-        if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, view, Na, Nb, N[2], face, fill_open);
+        if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open);
+        if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open);
+        if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open);
     }
     for (int d = 2; d >= 0; --d) {
         if (T[d] != OCN_PERIODIC) continue;
@@ -291,13 +302,30 @@ static int fill_halo_group(const DGrid &g, double *const *fields, int n, const i
     return OCN_OK;
 }
 
+// FieldBoundaryConditions validation: Bounded sides only; Flux / Value / Gradient on fields at Center along the boundary
+// direction, Open on the wall-normal (Face) component
+static int validate_bc(const DGrid &g, const int loc[3], int side, int kind) {
+    const int T[3] = {g.tx, g.ty, g.tz};
+    if (side < 0 || side > 5) return fail(OCN_EINVAL, "side %d out of range (0..5 = west, east, south, north, bottom, top)", side);
+    if (kind < OCN_BC_DEFAULT || kind > OCN_BC_OPEN) return fail(OCN_EINVAL, "unknown boundary condition kind %d", kind);
+    if (kind == OCN_BC_DEFAULT) return OCN_OK;
+    const int d = side / 2;
+    if (T[d] != OCN_BOUNDED) return fail(OCN_EINVAL, "a non-default boundary condition needs a Bounded topology in dimension %d", d);
+    if (kind == OCN_BC_OPEN ? loc[d] != OCN_FACE : loc[d] != OCN_CENTER)
+        return fail(OCN_EINVAL, "Flux/Value/Gradient conditions apply to fields at Center, Open to fields at Face along the boundary direction");
+    return OCN_OK;
+}
+
 // groups fields by identical location (identical parent shape) -> one set of launches per group
-static int fill_halo_regions(const DGrid &g, double *const *fields, const int (*locs)[3], int nfields, bool fill_open) {
+static int fill_halo_regions(const ocn_grid_s *grid, double *const *fields, const int (*locs)[3], int nfields, bool fill_open,
+                             const ocn_bc_t (*bcs)[6] = nullptr) {
+    const DGrid &g = grid->d;
     if (nfields > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
     bool done[OCN_MAX_FIELDS] = {false};
     for (int f = 0; f < nfields; ++f) {
         if (done[f]) continue;
         double *grp[OCN_MAX_FIELDS];
+        ocn_bc_t gbc[OCN_MAX_FIELDS][6];
         int n = 0;
         int P0[3], P1[3];
         parent_size(g, locs[f], P0);
@@ -309,9 +337,13 @@ static int fill_halo_regions(const DGrid &g, double *const *fields, const int (*
                 const int T[3] = {g.tx, g.ty, g.tz};
                 if (T[d] == OCN_BOUNDED && locs[h][d] != locs[f][d]) same = false;
             }
-            if (same) { grp[n++] = fields[h]; done[h] = true; }
+            if (same) {
+                if (bcs) memcpy(gbc[n], bcs[h], sizeof(ocn_bc_t) * 6);
+                grp[n++] = fields[h];
+                done[h] = true;
+            }
         }
-        int rc = fill_halo_group(g, grp, n, locs[f], fill_open);
+        int rc = fill_halo_group(grid, grp, n, locs[f], fill_open, bcs ? gbc : nullptr);
         if (rc) return rc;
     }
     return OCN_OK;
@@ -320,7 +352,48 @@ static int fill_halo_regions(const DGrid &g, double *const *fields, const int (*
 extern "C" int ocn_fill_halo_regions(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int fill_open_bcs) {
     NEED_INIT();
     if (!grid || !fields || !locs || nfields < 0) return fail(OCN_EINVAL, "invalid argument");
-    return fill_halo_regions(grid->d, fields, locs, nfields, fill_open_bcs != 0);
+    return fill_halo_regions(grid, fields, locs, nfields, fill_open_bcs != 0);
+}
+
+extern "C" int ocn_fill_halo_regions_bcs(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields,
+                                         const ocn_bc_t (*bcs)[6], int fill_open_bcs) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || nfields < 0) return fail(OCN_EINVAL, "invalid argument");
+    if (bcs)
+        for (int f = 0; f < nfields; ++f)
+            for (int sd = 0; sd < 6; ++sd) {
+                int rc = validate_bc(grid->d, locs[f], sd, bcs[f][sd].kind);
+                if (rc) return rc;
+            }
+    return fill_halo_regions(grid, fields, locs, nfields, fill_open_bcs != 0, bcs);
+}
+
+static int compute_flux_bcs(const DGrid &g, double *G, const int loc[3], const ocn_bc_t bcs[6]) {
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
+    FView view = make_view(g, G, loc);
+    for (int d = 0; d < 3; ++d) {
+        if (T[d] != OCN_BOUNDED) continue;
+        const bool lo = bcs[2 * d].kind == OCN_BC_FLUX, hi = bcs[2 * d + 1].kind == OCN_BC_FLUX;
+        if (!lo && !hi) continue;
+        const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
+        const int nb = (int)(((long)Na * Nb + 255) / 256);
+        const double flo = bcs[2 * d].value, fhi = bcs[2 * d + 1].value;
+        if (d == 0) hipLaunchKernelGGL(flux_bc_kernel<0>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[0], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
+        if (d == 1) hipLaunchKernelGGL(flux_bc_kernel<1>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[1], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
+        if (d == 2) hipLaunchKernelGGL(flux_bc_kernel<2>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[2], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
+    }
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_flux_bcs(ocn_grid_t grid, double *G, const int loc[3], const ocn_bc_t bcs[6]) {
+    NEED_INIT();
+    if (!grid || !G || !loc || !bcs) return fail(OCN_EINVAL, "NULL argument");
+    for (int sd = 0; sd < 6; ++sd) {
+        int rc = validate_bc(grid->d, loc, sd, bcs[sd].kind);
+        if (rc) return rc;
+    }
+    return compute_flux_bcs(grid->d, G, loc, bcs);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1205,6 +1278,8 @@ struct ocn_model_s {
     int ntr, nf;
     double *U[OCN_MAX_FIELDS], *Gn[OCN_MAX_FIELDS], *Gm[OCN_MAX_FIELDS];
     int loc[OCN_MAX_FIELDS][3];
+    ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
+    bool any_bc = false, any_flux_bc = false;
     double *p;
     ocn_poisson_t solver;
     double *blockmax;
@@ -1319,7 +1394,7 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
 // update_state! (update_nonhydrostatic_model_state.jl:20-56), closure / buoyancy / forcing = nothing
 static int update_state(ocn_model_s *m, bool compute_tend) {
     const DGrid &g = m->grid->d;
-    int rc = fill_halo_regions(g, m->U, m->loc, m->nf, /*fill_open_bcs=*/false);
+    int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, /*fill_open_bcs=*/false, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
     if (compute_tend) {
         std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
@@ -1336,6 +1411,9 @@ static int update_state(ocn_model_s *m, bool compute_tend) {
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
+        // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)
+        if (m->any_flux_bc)
+            for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
     }
     return rc;
 }
@@ -1343,12 +1421,13 @@ static int update_state(ocn_model_s *m, bool compute_tend) {
 // compute_pressure_correction! (pressure_correction.jl:8-20)
 static int compute_pressure_correction(ocn_model_s *m) {
     const DGrid &g = m->grid->d;
-    int rc = fill_halo_regions(g, m->U, m->loc, 3, true);
+    int rc = fill_halo_regions(m->grid, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
     if ((rc = solve_for_pressure(m->solver, m->U[0], m->U[1], m->U[2], m->p))) return rc;
     double *pp[1] = {m->p};
     const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
-    return fill_halo_regions(g, pp, pl, 1, true);
+    (void)g;
+    return fill_halo_regions(m->grid, pp, pl, 1, true);
 }
 
 // make_pressure_correction! (pressure_correction.jl:40-53)
@@ -1358,6 +1437,27 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
     if (rc) return rc;
     double dtp = std::fmax(2.220446049250313e-16, dt);
     return divide_interior(g, m->p, dtp);
+}
+
+extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name, int side, int kind, double value) {
+    if (!m || !name) return fail(OCN_EINVAL, "NULL argument");
+    int f = -1;
+    if (!strcmp(name, "u")) f = 0;
+    else if (!strcmp(name, "v")) f = 1;
+    else if (!strcmp(name, "w")) f = 2;
+    else if (name[0] == 'c' && name[1] >= '0' && name[1] <= '9' && !name[2] && name[1] - '0' < m->ntr) f = 3 + (name[1] - '0');
+    if (f < 0) return fail(OCN_EINVAL, "boundary conditions can be set on u, v, w and the tracers c0..c%d; got '%s'", m->ntr - 1, name);
+    int rc = validate_bc(m->grid->d, m->loc[f], side, kind);
+    if (rc) return rc;
+    m->bcs[f][side].kind = kind;
+    m->bcs[f][side].value = value;
+    m->any_bc = m->any_flux_bc = false;
+    for (int q = 0; q < m->nf; ++q)
+        for (int sd = 0; sd < 6; ++sd) {
+            if (m->bcs[q][sd].kind != OCN_BC_DEFAULT) m->any_bc = true;
+            if (m->bcs[q][sd].kind == OCN_BC_FLUX && m->bcs[q][sd].value != 0.0) m->any_flux_bc = true;
+        }
+    return OCN_OK;
 }
 
 extern "C" int ocn_model_update_state(ocn_model_t m, int compute_tendencies_flag) {
@@ -1370,7 +1470,8 @@ extern "C" int ocn_model_set_finalize(ocn_model_t m, int enforce_incompressibili
     NEED_INIT();
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = m->grid->d;
-    int rc = fill_halo_regions(g, m->U, m->loc, m->nf, true);     // set!(ϕ, value); fill_halo_regions!(ϕ) per field
+    (void)g;
+    int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, true, m->any_bc ? m->bcs : nullptr);     // set!(ϕ, value); fill_halo_regions!(ϕ) per field
     if (rc) return rc;
     if ((rc = update_state(m, false))) return rc;
     if (enforce_incompressibility) {

@@ -127,11 +127,18 @@ __global__ void __launch_bounds__(256) fill_periodic_kernel(FieldList fl, int P0
     for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
 }
 
-// Bounded directions: _fill_flux_*_halo! (fill_halo_regions_flux.jl:9-27) one-cell mirror for Center fields,
-// open/impenetrable wall value (fill_halo_regions_open.jl:2-7) for Face fields. Launched over the INTERIOR extent
-// (grid N) of the two other dims.
+// Bounded directions, ONE halo cell (fill_halo_kernels.jl:69-70), launched over the INTERIOR extent (grid N) of the two
+// other dims. Center fields: Flux / default -> mirror (fill_halo_regions_flux.jl:9-27); Value / Gradient -> linear
+// extrapolation through the boundary face (fill_halo_regions_value_gradient.jl:7-119). Face fields: Open wall value
+// (fill_halo_regions_open.jl:2-7; impenetrable = 0), skipped when fill_open_bcs = false.
+struct BcSides {
+    int kind[OCN_MAX_FIELDS][2];      // [field][lo | hi], OCN_BC_*
+    double value[OCN_MAX_FIELDS][2];
+    double dlo, dhi;                  // spacing at the boundary faces (Δ between the first interior and the first halo point)
+};
+
 template <int D>
-__global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, FView view, int Na, int Nb, int N, bool face,
+__global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides bc, FView view, int Na, int Nb, int N, bool face,
                                                            bool fill_open) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)Na * Nb) return;
@@ -142,9 +149,45 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, FView v
     else { lo = view.lin(a, b, face ? 1 : 0); ilo = view.lin(a, b, 1); hi = view.lin(a, b, N + 1); ihi = view.lin(a, b, N); }
     for (int f = 0; f < fl.n; ++f) {
         double *p = fl.p[f];
-        if (!face) { p[lo] = p[ilo]; p[hi] = p[ihi]; }
-        else if (fill_open) { p[lo] = 0.0; p[hi] = 0.0; }
+        if (!face) {
+            const double c1 = p[ilo], cN = p[ihi];
+            const int kl = bc.kind[f][0], kh = bc.kind[f][1];
+            double h0 = c1, h1 = cN;
+            if (kl == OCN_BC_VALUE) h0 = c1 + ((c1 - bc.value[f][0]) / (bc.dlo / 2)) * (-bc.dlo);
+            else if (kl == OCN_BC_GRADIENT) h0 = c1 + bc.value[f][0] * (-bc.dlo);
+            if (kh == OCN_BC_VALUE) h1 = cN + ((bc.value[f][1] - cN) / (bc.dhi / 2)) * bc.dhi;
+            else if (kh == OCN_BC_GRADIENT) h1 = cN + bc.value[f][1] * bc.dhi;
+            p[lo] = h0;
+            p[hi] = h1;
+        } else if (fill_open) {
+            p[lo] = bc.kind[f][0] == OCN_BC_OPEN ? bc.value[f][0] : 0.0;
+            p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.value[f][1] : 0.0;
+        }
     }
+}
+
+// compute_x/y/z_bcs! (compute_flux_bcs.jl:57-163): G[1] += flux * A / V, G[N] -= flux * A / V over the interior extent of
+// the two other dims. area / volume evaluated per cell by the caller-provided metric look-ups.
+template <int D>
+__global__ void __launch_bounds__(256) flux_bc_kernel(DGrid g, FView G, int Na, int Nb, int N, int lx, int ly, int lz, bool has_lo,
+                                                      double flo, bool has_hi, double fhi) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)Na * Nb) return;
+    const int a = 1 + t % Na, b = 1 + t / Na;
+    for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !has_lo : !has_hi) continue;
+        const int n = side ? N : 1;
+        const int i = D == 0 ? n : a, j = D == 1 ? n : (D == 0 ? a : b), k = D == 2 ? n : b;
+        const double dx = g.dx, dy = g.dy;          // regular in x, y at every location
+        const double dz = lz == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
+        const double vol = (dx * dy) * dz;          // volume = Az * Δz
+        const double area = D == 0 ? dy * dz : (D == 1 ? dx * dz : dx * dy);
+        const double flux = side ? fhi : flo;
+        double &Gq = G.at(i, j, k);
+        if (side) Gq -= flux * area / vol;
+        else      Gq += flux * area / vol;
+    }
+    (void)lx; (void)ly;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -189,10 +189,28 @@ class DeviceBackend:
         self.profile, self.events, self.n_evals = False, [], 0
 
     # -- halos ---------------------------------------------------------------------------------------------------
+    def set_boundary_conditions(self, bcs_by_index):
+        """{index into U: FieldBoundaryConditions}: constant Flux / Value / Gradient / Open conditions on y / z sides"""
+        self.bcs = dict(bcs_by_index)
+        for fb in self.bcs.values():
+            if any(s in fb.sides for s in ("west", "east")):
+                raise NotImplementedError("the partitioned x direction is Periodic: no west / east conditions")
+
     def fill_local_halos(self, fields, fill_open_bcs):
-        L = _lib.lib()
-        _lib.check(L.ocn_fill_halo_regions(self.grid.local.handle, _ptr_array(fields), _loc_array(fields), len(fields),
-                                           int(fill_open_bcs)))
+        from .fields import fill_halo_regions as fill
+        bcs = getattr(self, "bcs", None)
+        if not bcs:
+            fill(fields, fill_open_bcs)
+            return
+        index = {id(f): n for n, f in enumerate(self.U)}
+        fill(fields, fill_open_bcs, boundary_conditions=[bcs.get(index.get(id(f), -1)) for f in fields])
+
+    def flux_bc_tendencies(self):
+        """compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)"""
+        from .boundary_conditions import compute_flux_bcs
+        for n, fb in getattr(self, "bcs", {}).items():
+            if any(bc.classification == "Flux" and bc.condition != 0.0 for bc in fb.sides.values()):
+                compute_flux_bcs(self.Gn[n], fb)
 
     def _slab(self, f):
         """doubles one field contributes per side: Hx x Py x Pz of ITS parent (Face fields on Bounded dims have one more plane)"""
@@ -285,7 +303,8 @@ class DeviceBackend:
 class DistributedNonhydrostaticModel:
     """NonhydrostaticModel on a Distributed architecture (x-slabs): WENO(order=5), RK3, DistributedFFTBasedPoissonSolver."""
 
-    def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None):
+    def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None,
+                 boundary_conditions=None):
         if advection is not None and not isinstance(advection, WENO):
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
         self.grid, self.ctx = grid, grid.ctx
@@ -294,6 +313,9 @@ class DistributedNonhydrostaticModel:
         self.time, self.iteration, self.stage = 0.0, 0, 1
         self.last_Δt = self.last_stage_Δt = float("inf")
         self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
+        if boundary_conditions:
+            names = ["u", "v", "w"] + list(self.tracer_names)
+            self.backend.set_boundary_conditions({names.index(n): fb for n, fb in boundary_conditions.items()})
 
     # field access ---------------------------------------------------------------------------------------------
     def fields(self):
@@ -355,6 +377,8 @@ def update_state(model, compute_tendencies=True):
         fill_halo_regions(model, b.U, fill_open_bcs=False)
         if compute_tendencies:
             b.compute_tendencies(None)
+            if hasattr(b, "flux_bc_tendencies"):
+                b.flux_bc_tendencies()
         return
     # async: start the exchange, compute the interior that does not depend on x halos, finish, compute the two strips
     b.fill_local_halos(b.U, False)
@@ -366,6 +390,8 @@ def update_state(model, compute_tendencies=True):
     b.unpack_x(b.U)                                                   # complete_communication_and_compute_buffer! (:9-20)
     b.compute_tendencies((1, Hx, 1, Ny, 1, Nz))                       # compute_buffer_tendencies! west strip
     b.compute_tendencies((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))             # east strip
+    if hasattr(b, "flux_bc_tendencies"):
+        b.flux_bc_tendencies()
 
 
 def compute_pressure_correction(model):

@@ -113,14 +113,24 @@ def _loc_array(fields):
     return arr
 
 
-def fill_halo_regions(fields, fill_open_bcs=True):
-    """fill_halo_regions!(field | tuple of fields; fill_open_bcs) with the default boundary conditions
-    (BoundaryConditions/fill_halo_regions.jl:25-36, field_boundary_conditions.jl:15-25)."""
+def fill_halo_regions(fields, fill_open_bcs=True, boundary_conditions=None):
+    """fill_halo_regions!(field | tuple of fields; fill_open_bcs) (BoundaryConditions/fill_halo_regions.jl:25-36) with the
+    default boundary conditions (field_boundary_conditions.jl:15-25) or, per field, a FieldBoundaryConditions of constant
+    Flux / Value / Gradient / Open conditions (`boundary_conditions`: one entry or None per field)."""
     if isinstance(fields, Field):
         fields = [fields]
+        if boundary_conditions is not None and not isinstance(boundary_conditions, (list, tuple)):
+            boundary_conditions = [boundary_conditions]
     fields = list(fields)
     if not fields:
         return
     grid = fields[0].grid
-    _lib.check(_lib.lib().ocn_fill_halo_regions(grid.handle, _ptr_array(fields), _loc_array(fields), len(fields),
-                                                int(fill_open_bcs)))
+    if boundary_conditions is None:
+        _lib.check(_lib.lib().ocn_fill_halo_regions(grid.handle, _ptr_array(fields), _loc_array(fields), len(fields),
+                                                    int(fill_open_bcs)))
+        return
+    from .boundary_conditions import bc_table
+    if len(boundary_conditions) != len(fields):
+        raise ValueError("one FieldBoundaryConditions (or None) per field")
+    _lib.check(_lib.lib().ocn_fill_halo_regions_bcs(grid.handle, _ptr_array(fields), _loc_array(fields), len(fields),
+                                                    bc_table(list(boundary_conditions)), int(fill_open_bcs)))

@@ -39,7 +39,7 @@ class NonhydrostaticModel:
     coriolis / buoyancy / closure / forcing = nothing -- the configuration BASELINE.json benchmarks."""
 
     def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", buoyancy=None, coriolis=None,
-                 closure=None, forcing=None):
+                 closure=None, forcing=None, boundary_conditions=None):
         if advection is None:
             advection = WENO()
         if not isinstance(advection, WENO):
@@ -61,6 +61,16 @@ class NonhydrostaticModel:
         self.tracers = T(*[self._field("c%d" % n) for n in range(len(self.tracer_names))])
         P = namedtuple("Pressures", "pNHS")
         self.pressures = P(self._field("p"))
+        # boundary_conditions = (u = FieldBoundaryConditions(top = FluxBoundaryCondition(Q)), ...) (nonhydrostatic_model.jl:
+        # 163-190): constant Flux / Value / Gradient / Open conditions on Bounded sides
+        self.boundary_conditions = dict(boundary_conditions or {})
+        from .boundary_conditions import KINDS, SIDES
+        for name, fbcs in self.boundary_conditions.items():
+            if name not in ("u", "v", "w") + self.tracer_names:
+                raise ValueError(f"boundary conditions given for {name}, which is not a velocity or tracer of the model")
+            for side, bc in fbcs.sides.items():
+                _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, self._cname(name).encode(), SIDES.index(side),
+                                                                       KINDS[bc.classification], bc.condition))
 
     @property
     def architecture(self):

@@ -97,23 +97,33 @@ static void fill_periodic(const oro_grid *g, double *c, const int loc[3], int d)
 /* fill_halo_regions_flux.jl:9-27 (no-flux mirror, ONE halo cell) and fill_halo_regions_open.jl:2-7 (impenetrable wall
  * value on Face fields), launched over the interior extent of the other two dims (`:xy` etc., fill_halo_kernels.jl:69-70,
  * Utils/kernel_launching.jl:211-221). */
-static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, int fill_open_bcs) {
+static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, int fill_open_bcs, const oro_bc *bcs) {
     fld f = mkfld(g, c, loc);
     const int N = g->N[d];
     int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    const oro_bc lo_bc = bcs ? bcs[2 * d] : (oro_bc){ORO_BC_DEFAULT, 0.0};
+    const oro_bc hi_bc = bcs ? bcs[2 * d + 1] : (oro_bc){ORO_BC_DEFAULT, 0.0};
     for (int b = 1; b <= g->N[d2]; ++b)
         for (int a = 1; a <= g->N[d1]; ++a) {
             int lo[3], hi[3], ilo[3], ihi[3];
             lo[d1] = hi[d1] = ilo[d1] = ihi[d1] = a;
             lo[d2] = hi[d2] = ilo[d2] = ihi[d2] = b;
-            if (loc[d] == ORO_CENTER) {             /* c[0] = c[1]; c[N+1] = c[N] */
+            if (loc[d] == ORO_CENTER) {
                 lo[d] = 0; ilo[d] = 1; hi[d] = N + 1; ihi[d] = N;
-                AT(f, lo[0], lo[1], lo[2]) = AT(f, ilo[0], ilo[1], ilo[2]);
-                AT(f, hi[0], hi[1], hi[2]) = AT(f, ihi[0], ihi[1], ihi[2]);
-            } else if (fill_open_bcs) {             /* c[1] = 0; c[N+1] = 0 (ImpenetrableBoundaryCondition) */
+                double *h0 = &AT(f, lo[0], lo[1], lo[2]), *h1 = &AT(f, hi[0], hi[1], hi[2]);
+                const double c1 = AT(f, ilo[0], ilo[1], ilo[2]), cN = AT(f, ihi[0], ihi[1], ihi[2]);
+                /* Δ between the first interior and the first halo point = spacing at the boundary FACE (flip(L)) */
+                const double dlo = DF(g, d, 1), dhi = DF(g, d, N + 1);
+                if (lo_bc.kind == ORO_BC_VALUE)         *h0 = c1 + ((c1 - lo_bc.value) / (dlo / 2)) * (-dlo);   /* :12,41-54 */
+                else if (lo_bc.kind == ORO_BC_GRADIENT) *h0 = c1 + lo_bc.value * (-dlo);
+                else                                    *h0 = c1;             /* Flux / default: c[0] = c[1] */
+                if (hi_bc.kind == ORO_BC_VALUE)         *h1 = cN + ((hi_bc.value - cN) / (dhi / 2)) * dhi;       /* :13,56-69 */
+                else if (hi_bc.kind == ORO_BC_GRADIENT) *h1 = cN + hi_bc.value * dhi;
+                else                                    *h1 = cN;
+            } else if (fill_open_bcs) {             /* c[1] = value; c[N+1] = value (Open; impenetrable = 0) */
                 lo[d] = 1; hi[d] = N + 1;
-                AT(f, lo[0], lo[1], lo[2]) = 0.0;
-                AT(f, hi[0], hi[1], hi[2]) = 0.0;
+                AT(f, lo[0], lo[1], lo[2]) = lo_bc.kind == ORO_BC_OPEN ? lo_bc.value : 0.0;
+                AT(f, hi[0], hi[1], hi[2]) = hi_bc.kind == ORO_BC_OPEN ? hi_bc.value : 0.0;
             }
         }
 }
@@ -122,11 +132,50 @@ static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, 
  * then periodic (which also fill corners because they span the whole parent). `sortperm(bcs_array, lt=fill_first)`
  * (:42) runs an insertion sort with an `lt` that is true for every same-class pair, which REVERSES same-class
  * entries of [west_and_east, south_and_north, bottom_and_top]: the order within a class is z, y, x. */
-void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs) {
+void oro_fill_halo_regions_bcs(const oro_grid *g, double *c, const int loc[3], const oro_bc bcs[6], int fill_open_bcs) {
     for (int d = 2; d >= 0; --d)
-        if (g->topo[d] == ORO_BOUNDED) fill_bounded(g, c, loc, d, fill_open_bcs);
+        if (g->topo[d] == ORO_BOUNDED) fill_bounded(g, c, loc, d, fill_open_bcs, bcs);
     for (int d = 2; d >= 0; --d)
         if (g->topo[d] == ORO_PERIODIC) fill_periodic(g, c, loc, d);
+}
+
+void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs) {
+    oro_fill_halo_regions_bcs(g, c, loc, NULL, fill_open_bcs);
+}
+
+/* compute_flux_bcs.jl:57-163: Gc[1] += flux * A / V on the left side, Gc[N] -= flux * A / V on the right side; A is the
+ * area of the boundary face (location flipped along the boundary direction), V the volume of the boundary-adjacent cell;
+ * launched over the interior extent of the two other dimensions (:xy etc.) */
+static inline double spacing(const oro_grid *g, int d, int face, int idx) { return face ? DF(g, d, idx) : DC(g, d, idx); }
+void oro_compute_flux_bcs(const oro_grid *g, double *Gc, const int loc[3], const oro_bc bcs[6]) {
+    fld G = mkfld(g, Gc, loc);
+    for (int d = 0; d < 3; ++d) {            /* compute_x_bcs!, compute_y_bcs!, compute_z_bcs! */
+        if (g->topo[d] != ORO_BOUNDED) continue;
+        const oro_bc lo = bcs[2 * d], hi = bcs[2 * d + 1];
+        if (lo.kind != ORO_BC_FLUX && hi.kind != ORO_BC_FLUX) continue;
+        const int N = g->N[d];
+        int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+        for (int b = 1; b <= g->N[d2]; ++b)
+            for (int a = 1; a <= g->N[d1]; ++a) {
+                int q[3];
+                q[d1] = a; q[d2] = b;
+                for (int side = 0; side < 2; ++side) {
+                    const oro_bc bc = side ? hi : lo;
+                    if (bc.kind != ORO_BC_FLUX) continue;
+                    q[d] = side ? N : 1;
+                    const int fidx = side ? N + 1 : 1;       /* boundary face index along d */
+                    /* volume(i,j,k,LX,LY,LZ) = Az * Δz (spacings_and_areas_and_volumes.jl:376), Az = Δx Δy */
+                    const double vol = (spacing(g, 0, loc[0], q[0]) * spacing(g, 1, loc[1], q[1])) * spacing(g, 2, loc[2], q[2]);
+                    double area;
+                    if (d == 0)      area = spacing(g, 1, loc[1], q[1]) * spacing(g, 2, loc[2], q[2]);                 /* Ax = Δy Δz */
+                    else if (d == 1) area = spacing(g, 0, loc[0], q[0]) * spacing(g, 2, loc[2], q[2]);                 /* Ay = Δx Δz */
+                    else             area = spacing(g, 0, loc[0], q[0]) * spacing(g, 1, loc[1], q[1]);                 /* Az = Δx Δy */
+                    (void)fidx;      /* x / y spacings are uniform and Az does not depend on k: the flipped index only matters on curvilinear grids */
+                    if (side) AT(G, q[0], q[1], q[2]) -= bc.value * area / vol;
+                    else      AT(G, q[0], q[1], q[2]) += bc.value * area / vol;
+                }
+            }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -764,6 +813,8 @@ struct oro_model {
     double *Gn[3 + ORO_MAXTR];
     double *Gm[3 + ORO_MAXTR];
     int loc[3 + ORO_MAXTR][3];
+    oro_bc bcs[3 + ORO_MAXTR][6];
+    int any_flux_bc;
     double *p;
     oro_poisson *solver;
     double time, last_dt, last_stage_dt;
@@ -838,15 +889,37 @@ void oro_model_field_loc(oro_model *m, const char *name, int loc[3]) {
     memcpy(loc, m->loc[f], sizeof(int) * 3);
 }
 
+/* FieldBoundaryConditions validation (field_boundary_conditions.jl, boundary_condition.jl): Flux / Value / Gradient on
+ * fields at Center along the boundary direction, Open on the wall-normal (Face) component, Bounded sides only */
+int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value) {
+    char k;
+    int f = field_index(m, name, &k);
+    if (f < 0 || k != 'U' || side < 0 || side > 5) return -1;
+    const int d = side / 2;
+    if (m->g->topo[d] != ORO_BOUNDED) return -1;
+    if (kind == ORO_BC_OPEN ? m->loc[f][d] != ORO_FACE : (kind != ORO_BC_DEFAULT && m->loc[f][d] != ORO_CENTER)) return -1;
+    if (kind < ORO_BC_DEFAULT || kind > ORO_BC_OPEN) return -1;
+    m->bcs[f][side].kind = kind;
+    m->bcs[f][side].value = value;
+    m->any_flux_bc = 0;
+    for (int q = 0; q < 3 + m->ntr; ++q)
+        for (int sd = 0; sd < 6; ++sd)
+            if (m->bcs[q][sd].kind == ORO_BC_FLUX && m->bcs[q][sd].value != 0.0) m->any_flux_bc = 1;
+    return 0;
+}
+
 /* update_nonhydrostatic_model_state.jl:20-56 with closure/buoyancy = nothing */
 void oro_model_update_state(oro_model *m, int compute_tendencies) {
     const oro_grid *g = m->g;
-    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions(g, m->U[f], m->loc[f], /*fill_open_bcs=*/0);
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions_bcs(g, m->U[f], m->loc[f], m->bcs[f], /*fill_open_bcs=*/0);
     if (compute_tendencies) {
         oro_compute_Gu(g, m->U[0], m->U[1], m->U[2], m->Gn[0], NULL);
         oro_compute_Gv(g, m->U[0], m->U[1], m->U[2], m->Gn[1], NULL);
         oro_compute_Gw(g, m->U[0], m->U[1], m->U[2], m->Gn[2], NULL);
         for (int t = 0; t < m->ntr; ++t) oro_compute_Gc(g, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->Gn[3 + t], NULL);
+        /* compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) */
+        if (m->any_flux_bc)
+            for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
     }
 }
 
@@ -854,7 +927,7 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
 static void compute_pressure_correction(oro_model *m, double dt) {
     (void)dt;
     const oro_grid *g = m->g;
-    for (int f = 0; f < 3; ++f) oro_fill_halo_regions(g, m->U[f], m->loc[f], 1);
+    for (int f = 0; f < 3; ++f) oro_fill_halo_regions_bcs(g, m->U[f], m->loc[f], m->bcs[f], 1);
     oro_compute_source_term(g, m->U[0], m->U[1], m->U[2], oro_poisson_rhs(m->solver), m->solver->kind == 1);
     oro_poisson_solve(m->solver, m->p);
     oro_fill_halo_regions(g, m->p, LOC_C, 1);
@@ -869,7 +942,7 @@ static void make_pressure_correction(oro_model *m, double dt) {
 
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility) {
     /* set_nonhydrostatic_model.jl:33-60: per-field fill_halo_regions! after set!, then update_state!, projection */
-    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions(m->g, m->U[f], m->loc[f], 1);
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions_bcs(m->g, m->U[f], m->loc[f], m->bcs[f], 1);
     oro_model_update_state(m, 0);
     if (enforce_incompressibility) {
         compute_pressure_correction(m, 1.0);

@@ -49,6 +49,15 @@ void oro_parent_size(const oro_grid *g, const int loc[3], int P[3]);
  * -> no-flux mirror (one cell); Bounded+Face -> impenetrable (wall value 0), skipped when fill_open_bcs == 0 */
 void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int fill_open_bcs);
 
+/* non-default boundary conditions with constant values on Bounded sides (boundary_condition_classifications.jl,
+ * fill_halo_regions_value_gradient.jl:7-119, fill_halo_regions_flux.jl:9-27, fill_halo_regions_open.jl:2-7,
+ * compute_flux_bcs.jl:57-163). Sides are ordered west, east, south, north, bottom, top. */
+enum { ORO_BC_DEFAULT = 0, ORO_BC_FLUX = 1, ORO_BC_VALUE = 2, ORO_BC_GRADIENT = 3, ORO_BC_OPEN = 4 };
+typedef struct { int kind; double value; } oro_bc;
+void oro_fill_halo_regions_bcs(const oro_grid *g, double *c, const int loc[3], const oro_bc bcs[6], int fill_open_bcs);
+/* compute_x/y/z_bcs!: adds the flux divergence of Flux boundary conditions to the tendency G of a field at loc */
+void oro_compute_flux_bcs(const oro_grid *g, double *G, const int loc[3], const oro_bc bcs[6]);
+
 /* ---- tendencies (src/Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:49-163) ---- */
 /* range = {i0, i1, j0, j1, k0, k1} inclusive (KernelParameters); NULL -> :xyz with exclude_periphery as the
  * reference launches it. */
@@ -92,6 +101,8 @@ oro_model *oro_model_create(const oro_grid *g, int ntracers);
 void oro_model_destroy(oro_model *m);
 double *oro_model_field(oro_model *m, const char *name); /* "u","v","w","c0".., "p", "Gu","Gv","Gw","Gc0".., "Mu".. */
 void oro_model_field_loc(oro_model *m, const char *name, int loc[3]);
+/* side 0..5 = west, east, south, north, bottom, top; returns 0, or -1 for an invalid combination */
+int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value);
 void oro_model_update_state(oro_model *m, int compute_tendencies);
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
 void oro_model_time_step(oro_model *m, double dt);

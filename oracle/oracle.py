@@ -65,6 +65,9 @@ def lib():
         L.oro_grid_destroy.argtypes = [vp]
         L.oro_parent_size.argtypes = [vp, ip, ip]
         L.oro_fill_halo_regions.argtypes = [vp, dp, ip, C.c_int]
+        L.oro_fill_halo_regions_bcs.argtypes = [vp, dp, ip, C.POINTER(BC), C.c_int]
+        L.oro_compute_flux_bcs.argtypes = [vp, dp, ip, C.POINTER(BC)]
+        L.oro_model_set_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_double]
         for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
             getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
         L.oro_compute_Gc.argtypes = [vp, dp, dp, dp, dp, dp, ip]
@@ -104,6 +107,24 @@ def lib():
         L.oro_model_max_abs_divergence.argtypes = [vp]
         L.oro_set_num_threads.argtypes = [C.c_int]
     return _LIB
+
+
+class BC(C.Structure):
+    """oro_bc: constant-valued boundary condition on one side"""
+    _fields_ = [("kind", C.c_int), ("value", C.c_double)]
+
+
+BC_KINDS = {"default": 0, "flux": 1, "value": 2, "gradient": 3, "open": 4}
+SIDES = {"west": 0, "east": 1, "south": 2, "north": 3, "bottom": 4, "top": 5}
+
+
+def _bcs(bcs):
+    """dict side -> (kind, value)  ->  oro_bc[6]"""
+    arr = (BC * 6)()
+    for side, (kind, value) in (bcs or {}).items():
+        arr[SIDES[side]].kind = BC_KINDS[kind]
+        arr[SIDES[side]].value = float(value)
+    return arr
 
 
 def _dp(a):
@@ -214,8 +235,14 @@ class Grid:
         return a[tuple(slice(self.H[d], self.H[d] + self.N[d]) for d in range(3))]
 
     # ---- kernels ----
-    def fill_halo_regions(self, a, loc, fill_open_bcs=True):
-        lib().oro_fill_halo_regions(self.handle, _dp(a), _i3(loc), int(fill_open_bcs))
+    def fill_halo_regions(self, a, loc, fill_open_bcs=True, bcs=None):
+        if bcs is None:
+            lib().oro_fill_halo_regions(self.handle, _dp(a), _i3(loc), int(fill_open_bcs))
+        else:
+            lib().oro_fill_halo_regions_bcs(self.handle, _dp(a), _i3(loc), _bcs(bcs), int(fill_open_bcs))
+
+    def compute_flux_bcs(self, G, loc, bcs):
+        lib().oro_compute_flux_bcs(self.handle, _dp(G), _i3(loc), _bcs(bcs))
 
     def compute_G(self, which, u, v, w, G, c=None, rng=None):
         r = (C.c_int * 6)(*rng) if rng is not None else None
@@ -279,6 +306,11 @@ class Model:
         loc = (C.c_int * 3)()
         lib().oro_model_field_loc(self.handle, name.encode(), loc)
         return tuple(loc)
+
+    def set_bc(self, name, side, kind, value=0.0):
+        """field boundary condition with a constant value: kind in flux | value | gradient | open | default"""
+        if lib().oro_model_set_bc(self.handle, name.encode(), SIDES[side], BC_KINDS[kind], float(value)) != 0:
+            raise ValueError(f"invalid boundary condition {kind} on the {side} side of {name}")
 
     def set(self, enforce_incompressibility=True, **fields):
         for name, val in fields.items():

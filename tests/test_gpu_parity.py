@@ -144,3 +144,90 @@ def test_batched_tridiagonal_vs_dense(ocn, arch):
         for j in range(Ny):
             M = np.diag(b[i, j]) + np.diag(a, -1) + np.diag(c, 1)
             assert np.allclose(phi[i, j], np.linalg.solve(M, f[i, j]), rtol=1e-12, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# boundary conditions with constant values (fill_halo_regions_value_gradient.jl, fill_halo_regions_open.jl, compute_flux_bcs.jl)
+# ---------------------------------------------------------------------------------------------------------------------
+BC_SETS = {
+    "c": dict(west=("Value", 1.5), east=("Gradient", -0.7), south=("Gradient", 0.3), north=("Value", -2.0),
+              bottom=("Value", 0.25), top=("Flux", 4.0)),
+    "u": dict(south=("Value", 0.0), north=("Gradient", 0.1), bottom=("Value", 0.0), top=("Flux", -1e-3), west=("Open", 0.2)),
+    "w": dict(west=("Gradient", 0.5), north=("Value", 1.0), top=("Open", 0.125), bottom=("Open", -0.25)),
+}
+
+
+def _fbcs(ocn, spec):
+    return ocn.FieldBoundaryConditions(**{s: ocn.BoundaryCondition(k, v) for s, (k, v) in spec.items()})
+
+
+def _oracle_bcs(spec):
+    return {s: (k.lower(), v) for s, (k, v) in spec.items()}
+
+
+@pytest.mark.parametrize("stretched", [False, True])
+def test_bc_halo_fills_and_flux_tendencies_bit_exact(ocn, oracle, arch, stretched):
+    size = (9, 7, 6)
+    topology = ("Bounded", "Bounded", "Bounded")
+    z = tanh_faces(size[2]) if stretched else None
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=z)
+    rng = np.random.default_rng(21)
+    flds = m_gpu.fields()
+    for name, key in (("T", "c"), ("u", "u"), ("w", "w")):
+        f = flds[name]
+        a = rng.standard_normal(f.shape)
+        f.set_parent(a)
+        b = np.asfortranarray(a.copy())
+        loc = tuple(1 if l is ocn.Face else 0 for l in f.loc)
+        for fill_open in (False, True):
+            ocn.fill_halo_regions(f, fill_open_bcs=fill_open, boundary_conditions=_fbcs(ocn, BC_SETS[key]))
+            g_cpu.fill_halo_regions(b, loc, fill_open, bcs=_oracle_bcs(BC_SETS[key]))
+            assert np.array_equal(f.parent(), b), (name, fill_open)
+        # flux divergence of the Flux conditions on a tendency field at the same location
+        if key != "w":
+            G = m_gpu.tendency(name)
+            ga = rng.standard_normal(G.shape)
+            G.set_parent(ga)
+            gb = np.asfortranarray(ga.copy())
+            ocn.compute_flux_bcs(G, _fbcs(ocn, BC_SETS[key]))
+            g_cpu.compute_flux_bcs(gb, loc, _oracle_bcs(BC_SETS[key]))
+            assert np.array_equal(G.parent(), gb), name
+    # validation mirrors the reference's: no Value condition on a wall-normal component, nothing on Periodic sides
+    with pytest.raises(ocn.OcnError):
+        ocn.fill_halo_regions(flds["w"], boundary_conditions=ocn.FieldBoundaryConditions(top=ocn.ValueBoundaryCondition(1.0)))
+
+
+def test_model_with_boundary_conditions_matches_oracle(ocn, oracle, arch):
+    """the configuration-5 style set-up: wind-stress Flux on u at the top, surface Flux + bottom Gradient on T,
+    Value on S, on a stretched (Periodic, Periodic, Bounded) grid; 10 RK3 steps against the oracle"""
+    size = (16, 16, 12)
+    topology = ("Periodic", "Periodic", "Bounded")
+    spec = {"u": dict(top=("Flux", -2e-3), bottom=("Value", 0.0)), "v": dict(bottom=("Value", 0.0)),
+            "T": dict(top=("Flux", 5e-3), bottom=("Gradient", 0.4)), "S": dict(top=("Value", 35.1))}
+    topo_cls = tuple(getattr(ocn, t) for t in topology)
+    z = tanh_faces(size[2])
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo_cls)
+    g_cpu = oracle.Grid(size, topology=(0, 0, 1), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, advection=ocn.WENO(), tracers=("T", "S"),
+                                    boundary_conditions={n: _fbcs(ocn, s) for n, s in spec.items()})
+    m_cpu = oracle.Model(g_cpu, 2)
+    cname = {"u": "u", "v": "v", "w": "w", "T": "c0", "S": "c1"}
+    for n, s in spec.items():
+        for side, (k, v) in s.items():
+            m_cpu.set_bc(cname[n], side, k.lower(), v)
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.1 * g_gpu.Δxᶜᵃᵃ / 0.6
+    T0 = m_gpu.fields()["T"].parent()[3:-3, 3:-3, 3:-3].copy()
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        ia, ib = a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]
+        assert rel_err(ia, ib) < 1e-12, (name, rel_err(ia, ib))
+    # the surface flux really acts: volume-integrated T changes by -(Q_top - 0) * area * t (bottom condition is a Gradient: no flux term)
+    dz = np.diff(z)[None, None, :]
+    T1 = m_gpu.fields()["T"].parent()[3:-3, 3:-3, 3:-3]
+    change = ((T1 - T0) * dz).sum() / (size[0] * size[1])
+    assert abs(change - (-5e-3 * 10 * dt)) < 1e-12
+    with pytest.raises(ocn.OcnError):
+        ocn.NonhydrostaticModel(grid=g_gpu, boundary_conditions={"T": _fbcs(ocn, dict(west=("Flux", 1.0)))})

@@ -105,6 +105,76 @@ def test_impenetrable_walls_and_fill_open_bcs_flag(oracle):
     assert np.all(w[:, :, 3] == 0.0) and np.all(w[:, :, 3 + 4] == 0.0)      # wall faces k = 1 and k = Nz+1, x/y halos included
 
 
+def test_value_gradient_and_open_halo_fills(oracle):
+    """fill_halo_regions_value_gradient.jl:7-119: ONE halo cell by linear extrapolation through the boundary face, so that
+    the face average equals a Value condition and the face difference a Gradient condition; fill_halo_regions_open.jl:2-7
+    puts an Open condition on the wall-normal component (test/test_boundary_conditions_integration.jl exercises the same
+    kernels through models)"""
+    N = (6, 5, 4)
+    zf = tanh_faces(N[2])
+    g = oracle.Grid(N, topology=(B, B, B), z=zf)
+    rng = np.random.default_rng(3)
+    loc = oracle.LOC["c"]
+    c = np.asfortranarray(rng.standard_normal(g.parent_size(loc)))
+    before = c.copy()
+    bcs = {"west": ("value", 1.5), "east": ("gradient", -0.7), "south": ("gradient", 0.3), "north": ("value", -2.0),
+           "bottom": ("value", 0.25), "top": ("gradient", 4.0)}
+    g.fill_halo_regions(c, loc, True, bcs=bcs)
+    I = (slice(3, 3 + N[0]), slice(3, 3 + N[1]), slice(3, 3 + N[2]))
+    dx, dy = 1.0 / N[0], 1.0 / N[1]
+    dzf_bot, dzf_top = g.df[2][3], g.df[2][3 + N[2]]            # Δzᶠ at k = 1 and k = Nz + 1
+    assert np.allclose((c[2, I[1], I[2]] + c[3, I[1], I[2]]) / 2, 1.5, rtol=0, atol=1e-14)
+    assert np.allclose((c[3 + N[0], I[1], I[2]] - c[2 + N[0], I[1], I[2]]) / dx, -0.7, rtol=0, atol=1e-13)
+    assert np.allclose((c[I[0], 3, I[2]] - c[I[0], 2, I[2]]) / dy, 0.3, rtol=0, atol=1e-13)
+    assert np.allclose((c[I[0], 3 + N[1], I[2]] + c[I[0], 2 + N[1], I[2]]) / 2, -2.0, rtol=0, atol=1e-14)
+    assert np.allclose((c[I[0], I[1], 2] + c[I[0], I[1], 3]) / 2, 0.25, rtol=0, atol=1e-14)
+    assert np.allclose((c[I[0], I[1], 3 + N[2]] - c[I[0], I[1], 2 + N[2]]) / dzf_top, 4.0, rtol=0, atol=1e-12)
+    assert dzf_bot > 0
+    # only ONE halo cell per side is written, and only over the interior extent of the other two dimensions
+    assert np.array_equal(c[:2], before[:2]) and np.array_equal(c[I], before[I]) and np.array_equal(c[2, :3], before[2, :3])
+    # Open condition on w: wall-normal component takes the prescribed value when fill_open_bcs, untouched otherwise
+    w = g.zeros(oracle.LOC["w"])
+    w[...] = 1.0
+    g.fill_halo_regions(w, oracle.LOC["w"], False, bcs={"top": ("open", 0.125)})
+    assert np.all(w[3:-3, 3:-3, 3 + N[2]] == 1.0)
+    g.fill_halo_regions(w, oracle.LOC["w"], True, bcs={"top": ("open", 0.125)})
+    assert np.all(w[3:-3, 3:-3, 3 + N[2]] == 0.125) and np.all(w[3:-3, 3:-3, 3] == 0.0)
+
+
+@pytest.mark.parametrize("topo,names,sides", [
+    ((P, B, B), ("u", "c0"), ("north", "south", "top", "bottom")),
+    ((B, P, B), ("v", "c0"), ("east", "west", "top", "bottom")),
+    ((B, B, P), ("w", "c0"), ("east", "west", "north", "south")),
+])
+def test_flux_boundary_condition_budget(oracle, topo, names, sides):
+    """test_nonhydrostatic_flux_budget (test/test_boundary_conditions_integration.jl:28-52,309-358): a Flux condition of
+    ±π on one side of a field that starts at 0 gives mean(ϕ) = flux * t / L after one RK3 step with Δt = 1"""
+    Lx, Ly, Lz = 0.3, 0.4, 0.5
+    L = {"east": Lx, "west": Lx, "north": Ly, "south": Ly, "top": Lz, "bottom": Lz}
+    for name in names:
+        for side in sides:
+            g = oracle.Grid((4, 4, 4), topology=topo, x=(0.0, Lx), y=(0.0, Ly), z=(0.0, Lz))
+            m = oracle.Model(g, 1)
+            direction = 1 if side in ("west", "south", "bottom") else -1
+            m.set_bc(name, side, "flux", np.pi * direction)
+            m.set(**{n: 0.0 for n in m.names()})
+            m.time_step(1.0)
+            mean = g.interior(m.field(name), m.loc(name)).mean()
+            assert abs(mean - np.pi * m.time / L[side]) < 1e-12 * np.pi / L[side], (name, side, mean)
+
+
+def test_boundary_condition_validation(oracle):
+    g = oracle.Grid((4, 4, 4), topology=(P, P, B))
+    m = oracle.Model(g, 1)
+    with pytest.raises(ValueError):
+        m.set_bc("c0", "west", "flux", 1.0)        # Periodic side
+    with pytest.raises(ValueError):
+        m.set_bc("w", "top", "value", 1.0)         # wall-normal component takes Open conditions only
+    with pytest.raises(ValueError):
+        m.set_bc("u", "top", "open", 1.0)
+    m.set_bc("u", "top", "flux", 1.0)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Poisson solvers (test/test_poisson_solvers.jl:58-108, dependencies_for_poisson_solvers.jl:111-173,195-220)
 # ---------------------------------------------------------------------------------------------------------------------
