@@ -28,6 +28,10 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 TENDENCY_BYTES_PER_CELL = 80.0    # (5 fields read + 5 tendencies written) x 8 B
+# When the RK3 substep of stages 2 and 3 is fused into the tendency launch that precedes it, that launch also reads the 5
+# previous tendencies and writes the 5 updated fields: 80 + 80 B/cell (SURVEY.md 8(d) prices the separate substep at 160:
+# the fused form saves re-reading U and Gn). Two of the three launches per time-step are of this kind.
+FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL = 80.0
 V100_PUBLISHED_CELL_UPDATES = 256 ** 3 / 56.444e-3   # 256^3 F64 WENO 56.444 ms on a V100 (v0.58.8)
 
 
@@ -162,7 +166,9 @@ def main():
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
-    achieved = TENDENCY_BYTES_PER_CELL * float(N) ** 3 / t_launch / 1e9 if tend_n else None
+    fused_substep = (not distributed) and model.get_option("fuse_substep_active") == 1
+    bytes_per_cell = TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * fused_substep
+    achieved = bytes_per_cell * float(N) ** 3 / t_launch / 1e9 if tend_n else None
     out = {
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
@@ -174,13 +180,17 @@ def main():
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
                                        "benchmarks.md:128); older version without RK3/2 tracers -- context only"},
-        "roofline": {"kernel": "fused WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS)" if args.tendency_impl == 1
+        "roofline": {"kernel": "fused WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS) [+ RK3 substep of the next stage on 2 of 3 launches]"
+                     if args.tendency_impl == 1
                      else "per-field WENO-5 tendency kernels (5 launches)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": measured_traffic(args.tendency_impl, N) if world == 1 else None,
                      "traffic_source": "profiles/r01_tendency_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                     "algorithmic_bytes_per_launch": TENDENCY_BYTES_PER_CELL * float(N) ** 3,
+                     "algorithmic_bytes_per_launch": bytes_per_cell * float(N) ** 3,
+                     "algorithmic_bytes_note": ("average over the 3 launches of a time-step: 80 B/cell (tendencies) + 80 B/cell on the 2 "
+                                                "launches that carry the fused RK3 substep of the next stage") if fused_substep
+                     else "80 B/cell: 5 fields read + 5 tendencies written",
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
                      "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},
     }

@@ -198,9 +198,15 @@ int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *st
 int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
 int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value);
 /* options: "tendency_impl" 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel;
- * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "profile" 1 = record HIP
+ * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "fuse_substep" 1 = fuse the
+ * substeps of RK3 stages 2 and 3 into the preceding tendency evaluation (second set of prognostic arrays, swapped twice per
+ * time-step); "profile" 1 = record HIP
  * events around every tendency evaluation on the launch stream */
 int ocn_model_set_option(ocn_model_t model, const char *key, int value);
+/* reads an option back; additionally "fused_tendency_active" (1 when the fused flux-sharing kernel runs for this grid) and
+ * "fuse_substep_active" (1 when the rk3_substep! of stages 2 and 3 is fused into the preceding tendency evaluation:
+ * option "fuse_substep" = 1 (default), fused kernel, tendencies cached by pointer swap, no Flux boundary condition) */
+int ocn_model_get_option(ocn_model_t model, const char *key, int *value);
 /* boundary_conditions = (name = FieldBoundaryConditions(side = BoundaryCondition(kind, value)),) of the model
  * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0"..; side 0..5 = west .. top. OCN_EINVAL mirrors
  * the reference's validation: Bounded sides only; Flux/Value/Gradient on Center-located, Open on Face-located fields */

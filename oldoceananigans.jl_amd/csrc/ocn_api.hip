@@ -74,6 +74,8 @@ extern "C" int ocn_init(int device_id) {
     g_stream_owned = true;
     g_device = device_id;
     g_initialized = true;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) g_num_cus = cus;
     return OCN_OK;
 }
 
@@ -437,12 +439,18 @@ extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v,
     return launch_tendency<F_C>(grid->d, u, v, w, c, Gc, range);
 }
 
+static bool fused_path(const DGrid &g, const int *range, int ntr, int impl) {
+    return impl == 1 && fused_tendency_supported(g, range) && ntr <= 3;
+}
+
 static int compute_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr,
-                              int ntr, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range, int impl) {
-    if (impl == 1 && fused_tendency_supported(g, range) && ntr <= 3) {
+                              int ntr, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range, int impl,
+                              const FusedSubstep *sub = nullptr) {
+    if (sub && !fused_path(g, range, ntr, impl)) return fail(OCN_ESTATE, "fused substep requested on the per-field tendency path");
+    if (fused_path(g, range, ntr, impl)) {
         int rc = check_range(g, range, nullptr);
         if (rc) return rc;
-        rc = launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range);
+        rc = launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub);
         if (rc) return fail(rc, "fused tendency launch failed");
         KERNEL_CHECK();
         return OCN_OK;
@@ -1277,6 +1285,11 @@ struct ocn_model_s {
     ocn_grid_t grid;
     int ntr, nf;
     double *U[OCN_MAX_FIELDS], *Gn[OCN_MAX_FIELDS], *Gm[OCN_MAX_FIELDS];
+    // second set of prognostic arrays: the substeps of stages 2 and 3 are fused into the preceding tendency evaluation and
+    // write here (other workgroups still read U), then the two sets swap roles. Two swaps per time-step: the pointers
+    // handed out by ocn_model_field are the live ones again at every time-step boundary.
+    double *U2[OCN_MAX_FIELDS];
+    int fuse_substep = 1;
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
     bool any_bc = false, any_flux_bc = false;
@@ -1299,7 +1312,7 @@ struct ocn_model_s {
 extern "C" int ocn_model_destroy(ocn_model_t m) {
     if (!m) return OCN_OK;
     for (auto &e : m->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-    for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
+    for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->U2[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
     hipFree(m->p); hipFree(m->blockmax);
     ocn_poisson_destroy(m->solver);
     delete m;
@@ -1312,7 +1325,7 @@ extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracer
     if (ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3) return fail(OCN_EINVAL, "ntracers must be in 0..%d", OCN_MAX_FIELDS - 3);
     ocn_model_s *m = new ocn_model_s();
     m->grid = grid; m->ntr = ntracers; m->nf = 3 + ntracers;
-    for (int f = 0; f < OCN_MAX_FIELDS; ++f) m->U[f] = m->Gn[f] = m->Gm[f] = nullptr;
+    for (int f = 0; f < OCN_MAX_FIELDS; ++f) m->U[f] = m->U2[f] = m->Gn[f] = m->Gm[f] = nullptr;
     m->p = nullptr; m->solver = nullptr; m->blockmax = nullptr;
     const int *locs[3] = {LOC_U, LOC_V, LOC_W};
     int rc = OCN_OK;
@@ -1330,6 +1343,7 @@ extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracer
         const int *l = f < 3 ? locs[f] : LOC_C;
         memcpy(m->loc[f], l, sizeof(int) * 3);
         if (!rc) rc = alloc(&m->U[f], l);
+        if (!rc) rc = alloc(&m->U2[f], l);
         if (!rc) rc = alloc(&m->Gn[f], l);
         if (!rc) rc = alloc(&m->Gm[f], l);
     }
@@ -1379,7 +1393,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
-    if (!strcmp(key, "fused_kchunk")) { if (value < 1) return fail(OCN_EINVAL, "fused_kchunk must be >= 1"); g_fused_kchunk = value; return OCN_OK; }
+    if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }
 
@@ -1387,12 +1401,27 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
     if (!strcmp(key, "tendency_impl")) { m->tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "swap_tendencies")) { m->swap_tendencies = value; return OCN_OK; }
+    if (!strcmp(key, "fuse_substep")) { m->fuse_substep = value; return OCN_OK; }
     if (!strcmp(key, "profile")) { m->profile = value; m->events_used = 0; return OCN_OK; }
     return ocn_set_option(key, value);
 }
 
+static bool can_fuse_substep(const ocn_model_s *m) {
+    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
+}
+
+extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) {
+    if (!m || !key || !value) return fail(OCN_EINVAL, "NULL argument");
+    if (!strcmp(key, "tendency_impl")) { *value = m->tendency_impl; return OCN_OK; }
+    if (!strcmp(key, "swap_tendencies")) { *value = m->swap_tendencies; return OCN_OK; }
+    if (!strcmp(key, "fuse_substep")) { *value = m->fuse_substep; return OCN_OK; }
+    if (!strcmp(key, "fuse_substep_active")) { *value = can_fuse_substep(m) ? 1 : 0; return OCN_OK; }
+    if (!strcmp(key, "fused_tendency_active")) { *value = fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl) ? 1 : 0; return OCN_OK; }
+    return fail(OCN_EINVAL, "unknown model option '%s'", key);
+}
+
 // update_state! (update_nonhydrostatic_model_state.jl:20-56), closure / buoyancy / forcing = nothing
-static int update_state(ocn_model_s *m, bool compute_tend) {
+static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub = nullptr) {
     const DGrid &g = m->grid->d;
     int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, /*fill_open_bcs=*/false, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
@@ -1409,7 +1438,7 @@ static int update_state(ocn_model_s *m, bool compute_tend) {
             HIP_TRY(hipEventRecord(ev->first, g_stream));
         }
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
-                                m->tendency_impl);
+                                m->tendency_impl, sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
         // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)
         if (m->any_flux_bc)
@@ -1516,9 +1545,14 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
     const double dt1 = dt * g1, dt2 = dt * (g2 + z2), dt3 = dt * (g3 + z3);
     const double tn1 = m->time + dt;
     const double gam[3] = {g1, g2, g3}, zet[3] = {0.0, z2, z3}, sdt[3] = {dt1, dt2, dt3};
+    // stages 2 and 3: rk3_substep! fused into the tendency evaluation that precedes it (the cell's new tendency and its
+    // previous one are at hand when the cell is closed) -- possible when the fused kernel runs, tendencies are cached by
+    // pointer swap and no Flux boundary condition is added to G after the kernel
+    const bool can_fuse = can_fuse_substep(m);
+    bool substep_done = false;
     for (int stage = 0; stage < 3; ++stage) {
-        // compute_flux_bc_tendencies!: no value-carrying Flux BCs in scope (compute_flux_bcs.jl:24-28)
-        if ((rc = rk3_substep(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, gam[stage], zet[stage], stage > 0))) return rc;
+        if (!substep_done && (rc = rk3_substep(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, gam[stage], zet[stage], stage > 0))) return rc;
+        substep_done = false;
         if (stage < 2) tick(m, sdt[stage], true);
         else {
             double corrected = tn1 - m->time;
@@ -1529,7 +1563,12 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
         if ((rc = compute_pressure_correction(m))) return rc;
         if ((rc = make_pressure_correction(m, sdt[stage]))) return rc;
         if (stage < 2 && (rc = cache_previous_tendencies(m))) return rc;
-        if ((rc = update_state(m, true))) return rc;
+        if (stage < 2 && can_fuse) {
+            FusedSubstep sub{m->U2, m->Gm, dt, gam[stage + 1], zet[stage + 1], 1};
+            if ((rc = update_state(m, true, &sub))) return rc;
+            for (int f = 0; f < m->nf; ++f) std::swap(m->U[f], m->U2[f]);
+            substep_done = true;
+        } else if ((rc = update_state(m, true))) return rc;
     }
     return OCN_OK;
 }

@@ -33,6 +33,12 @@ struct FusedArgs {
     Range6 r;          // cell range of the launch
     Range6 ru, rv, rw, rc;  // per-field store masks (exclude_periphery)
     int kchunk;        // levels per workgroup along z
+    // optional fused RK3 substep of the NEXT stage (runge_kutta_3.jl:212-226): Un = U + dt (gamma Gn + zeta Gm), written to a
+    // second set of prognostic arrays (other workgroups still read U). substep = 0: tendencies only.
+    int substep, has_zeta;
+    double dt, gamma, zeta;
+    double *Un[3 + OCN_FUSED_MAXTR];
+    const double *Gm[3 + OCN_FUSED_MAXTR];
 };
 
 // window loaders ----------------------------------------------------------------------------------------------------
@@ -187,6 +193,13 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
         if (flux_ij) {
             const unsigned o = col + s2 * (unsigned)pk;
             const double *pu = a.u, *pv = a.v, *pw = a.w;
+            // previous-stage tendencies of the cell closed in this iteration: issued first, consumed after the z-fluxes
+            double gm[NF];
+            const bool close_cell = k > kc0 && cell_ij;
+            if (a.substep && a.has_zeta && close_cell) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) gm[f] = ld8(a.Gm[f], o - s2);
+            }
             // ---- z-fluxes of plane k, then close cell k-1 ----
             double fz[NF];
             if (ZWIN) {
@@ -210,7 +223,7 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                 z_fluxes<NTR>(g, i, j, k, load_win(pw, o, sx), load_win(pw, o, s1), load_win(pw, o, s2), load_win(pu, o, s2),
                               load_win(pv, o, s2), cz, fz);
             }
-            if (k > kc0 && cell_ij) {
+            if (close_cell) {
                 const int pb = buf ^ 1;
                 const long pkm = pk - 1;
                 const double vc = g.vinv_c[pkm], vf = g.vinv_f[pkm];
@@ -224,12 +237,28 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
                     const double div = (f == 2 ? vf : vc) * ((dx + dy) + (fz[f] - fz_prev[f]));
                     Gn_[f] = -div + 0.0;
                 }
-                if (in_range(a.ru, i, j, km)) st8(a.Gu, q, Gn_[0]);
-                if (in_range(a.rv, i, j, km)) st8(a.Gv, q, Gn_[1]);
-                if (in_range(a.rw, i, j, km)) st8(a.Gw, q, Gn_[2]);
+                const bool mu = in_range(a.ru, i, j, km), mv = in_range(a.rv, i, j, km), mw = in_range(a.rw, i, j, km),
+                           mc = in_range(a.rc, i, j, km);
+                if (mu) st8(a.Gu, q, Gn_[0]);
+                if (mv) st8(a.Gv, q, Gn_[1]);
+                if (mw) st8(a.Gw, q, Gn_[2]);
 #pragma unroll
                 for (int t = 0; t < NTR; ++t)
-                    if (in_range(a.rc, i, j, km)) st8(a.Gc[t], q, Gn_[3 + t]);
+                    if (mc) st8(a.Gc[t], q, Gn_[3 + t]);
+                if (a.substep) {
+                    // rk3_substep_field! of the next stage on the cell just closed: same operation order as rk3_substep_kernel
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const bool msk = f == 0 ? mu : (f == 1 ? mv : (f == 2 ? mw : mc));
+                        if (!msk) continue;
+                        const double *Uf = f == 0 ? a.u : (f == 1 ? a.v : (f == 2 ? a.w : a.c[f >= 3 ? f - 3 : 0]));
+                        double Uv = ZWIN ? (f == 0 ? uz.s[2] : (f == 1 ? vz.s[2] : (f == 2 ? wz.s[2] : czw[f >= 3 ? f - 3 : 0].s[2])))
+                                         : ld8(Uf, q);
+                        if (a.has_zeta) Uv += a.dt * (a.gamma * Gn_[f] + a.zeta * gm[f]);
+                        else            Uv += a.dt * a.gamma * Gn_[f];
+                        st8(a.Un[f], q, Uv);
+                    }
+                }
             }
 #pragma unroll
             for (int f = 0; f < NF; ++f) fz_prev[f] = fz[f];
@@ -291,24 +320,37 @@ static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
            bytes < 4294967296.0;         // 32-bit byte offsets inside a parent array
 }
 
-// tuned on MI355X at 256^3 (tools/tune_fused.py): 64 x 7 tiles, register z-windows, 2 waves/SIMD (no spills), 32 levels per workgroup
-static int g_fused_ty = 7, g_fused_kchunk = 32, g_fused_minw = 2, g_fused_zwin = 1;
+// tuned on MI355X at 256^3 (tools/tune_fused.py): 64 x 7 tiles, register z-windows, 2 waves/SIMD (no spills);
+// kchunk = 0: levels per workgroup chosen per launch so that the grid fills whole rounds of the chip (see pick_kchunk)
+static int g_fused_ty = 7, g_fused_kchunk = 0, g_fused_minw = 2, g_fused_zwin = 1;
+static int g_num_cus = 256;
+
+// Each workgroup primes 3 planes before its first cell closes, and the grid runs in rounds of one workgroup per CU (2 waves
+// per SIMD): cost ~ rounds x (kchunk + 3). Pick the cheapest kchunk in [12, 64].
+static inline int pick_kchunk(int tiles_xy, int nz) {
+    int best = 32;
+    long best_cost = -1;
+    for (int kc = 12; kc <= 64; ++kc) {
+        const long blocks = (long)tiles_xy * ((nz + kc - 1) / kc);
+        const long rounds = (blocks + g_num_cus - 1) / g_num_cus;
+        const long cost = rounds * (std::min(kc, nz) + 3);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kc; }
+    }
+    return best;
+}
 
 template <int NTR, int TY>
-static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a) {
+static int launch_fused_t(const DGrid &g, hipStream_t stream, FusedArgs &a) {
     const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
     if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    if (a.kchunk <= 0) a.kchunk = pick_kchunk(((nx + 63) / 64) * ((ny + TY - 1) / TY), nz);
     dim3 grid((nx + 63) / 64, (ny + TY - 1) / TY, (nz + a.kchunk - 1) / a.kchunk);
     const dim3 blk(64 * (TY + 1));
 #define OCN_LAUNCH_FUSED(BZV, MWV, ZWV) hipLaunchKernelGGL((fused_tendency_kernel<NTR, TY, BZV, MWV, ZWV>), grid, blk, 0, stream, g, a)
-    // waves per SIMD the register allocator must allow: two (TY+1)-wave workgroups per CU
+    // waves per SIMD the register allocator must allow without the register z-windows: two (TY+1)-wave workgroups per CU
     constexpr int MW2 = (2 * (TY + 1) + 3) / 4;
-    if (g_fused_zwin && g_fused_minw == 2) {
+    if (g_fused_zwin) {
         if (g.tz != 0) OCN_LAUNCH_FUSED(true, 2, true); else OCN_LAUNCH_FUSED(false, 2, true);
-    } else if (g_fused_zwin) {
-        if (g.tz != 0) OCN_LAUNCH_FUSED(true, MW2, true); else OCN_LAUNCH_FUSED(false, MW2, true);
-    } else if (g_fused_minw == 2) {
-        if (g.tz != 0) OCN_LAUNCH_FUSED(true, 2, false); else OCN_LAUNCH_FUSED(false, 2, false);
     } else {
         if (g.tz != 0) OCN_LAUNCH_FUSED(true, MW2, false); else OCN_LAUNCH_FUSED(false, MW2, false);
     }
@@ -316,14 +358,24 @@ static int launch_fused_t(const DGrid &g, hipStream_t stream, const FusedArgs &a
     return 0;
 }
 
-
+// optional fused substep: next-stage prognostic arrays, previous tendencies and RK3 coefficients
+struct FusedSubstep {
+    double *const *Un;           // u, v, w, tracers (3 + ntr)
+    const double *const *Gm;
+    double dt, gamma, zeta;
+    int has_zeta;
+};
 
 static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,
                                         const double *const *tr, int ntr, double *Gu, double *Gv, double *Gw,
-                                        double *const *Gc, const int *range) {
+                                        double *const *Gc, const int *range, const FusedSubstep *sub = nullptr) {
     FusedArgs a;
     a.u = u; a.v = v; a.w = w; a.Gu = Gu; a.Gv = Gv; a.Gw = Gw;
     for (int t = 0; t < ntr; ++t) { a.c[t] = tr[t]; a.Gc[t] = Gc[t]; }
+    a.substep = sub ? 1 : 0;
+    a.has_zeta = sub ? sub->has_zeta : 0;
+    a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
+    for (int f = 0; f < 3 + ntr; ++f) { a.Un[f] = sub ? sub->Un[f] : nullptr; a.Gm[f] = sub ? sub->Gm[f] : nullptr; }
     const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;
     a.s1 = Px;
     a.s2u = (long)Px * Py;
@@ -342,9 +394,6 @@ static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, cons
 #define OCN_FUSED_CASE(NTR)                                                          \
     case NTR:                                                                        \
         if (g_fused_ty == 3) return launch_fused_t<NTR, 3>(g, stream, a);            \
-        if (g_fused_ty == 5) return launch_fused_t<NTR, 5>(g, stream, a);            \
-        if (g_fused_ty == 4) return launch_fused_t<NTR, 4>(g, stream, a);            \
-        if (g_fused_ty == 8) return launch_fused_t<NTR, 8>(g, stream, a);            \
         return launch_fused_t<NTR, 7>(g, stream, a);
     switch (ntr) {
         OCN_FUSED_CASE(0)

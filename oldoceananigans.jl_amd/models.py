@@ -100,6 +100,11 @@ class NonhydrostaticModel:
     def set_option(self, key, value):
         _lib.check(_lib.lib().ocn_model_set_option(self.handle, key.encode(), int(value)))
 
+    def get_option(self, key):
+        v = C.c_int()
+        _lib.check(_lib.lib().ocn_model_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
+
     def profile_read(self):
         """(total ms, count) of the event-timed tendency evaluations since the last read"""
         ms, n = C.c_double(), C.c_int()

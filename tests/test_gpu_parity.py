@@ -231,3 +231,27 @@ def test_model_with_boundary_conditions_matches_oracle(ocn, oracle, arch):
     assert abs(change - (-5e-3 * 10 * dt)) < 1e-12
     with pytest.raises(ocn.OcnError):
         ocn.NonhydrostaticModel(grid=g_gpu, boundary_conditions={"T": _fbcs(ocn, dict(west=("Flux", 1.0)))})
+
+
+@pytest.mark.parametrize("topology", TOPOS)
+def test_fused_substep_is_bit_identical_to_separate_kernels(ocn, arch, topology):
+    """RK3 substeps of stages 2 and 3 fused into the preceding tendency evaluation (second set of prognostic arrays, swapped
+    twice per step) against rk3_substep! as its own launch: same IEEE operation order => identical bits, stable pointers"""
+    size = (64, 20, 18)
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else (0.0, 1.0)
+    out = []
+    for fuse in (1, 0):
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+        model.set_option("fuse_substep", fuse)
+        assert model.get_option("fuse_substep_active") == fuse and model.get_option("fused_tendency_active") == 1
+        from helpers import smooth_state
+        ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=5))
+        views = dict(model.fields())                      # Field views created BEFORE stepping must stay valid
+        for _ in range(3):
+            ocn.time_step(model, 0.1 * grid.Δxᶜᵃᵃ / 0.6)
+        out.append({n: f.parent() for n, f in views.items()} | {"p": model.pressures.pNHS.parent(),
+                                                               "Gu": model.tendency("u").parent()})
+        model.close()
+    for n in out[0]:
+        assert np.array_equal(out[0][n], out[1][n]), n

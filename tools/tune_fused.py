@@ -13,7 +13,7 @@ flds = model.fields()
 vals = smooth_state({n: grid.nodes(f.loc) for n, f in flds.items()}, 1234)
 ocn.set_model(model, **vals)
 ref = None
-variants = [(0, 8, 16, 4, 0), (1, 7, 16, 4, 0)] + [(1, ty, kc, 2, 1) for ty in (3, 4, 5, 7) for kc in (16, 32)]
+variants = [(0, 8, 16, 4, 0)] + [(1, 7, kc, 2, 1) for kc in (32, 22, 26, 37, 43, 52)]
 for impl, ty, kc, mw, zw in variants:
     model.set_option("tendency_impl", impl); model.set_option("fused_ty", ty); model.set_option("fused_kchunk", kc); model.set_option("fused_minw", mw); model.set_option("fused_zwin", zw)
     ocn.update_state(model, True); ocn.synchronize()
