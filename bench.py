@@ -47,6 +47,22 @@ def measured_traffic(tendency_impl, N):
         return None
 
 
+def measured_valu(tendency_impl, N, t_launch):
+    """FP64 issue-side roofline of the same kernel (its binding roof): VALU wave-instructions per launch from the
+    committed SQ_INSTS_VALU pass over the live launch time, against 256 CUs x 4 SIMDs x one wave64 FP64 instruction per
+    4 cycles x 2.4 GHz"""
+    path = os.path.join(ROOT, "profiles", "r01_tendency_valu.json")
+    if tendency_impl != 1 or N != 256 or not os.path.exists(path) or not t_launch:
+        return None
+    try:
+        n = float(json.load(open(path))["counters_per_launch"]["SQ_INSTS_VALU"])
+    except (OSError, ValueError, KeyError):
+        return None
+    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+    return {"wave_instructions_per_launch": n, "achieved": n / t_launch / 1e9, "peak": peak, "unit": "G wave-instr/s",
+            "frac": n / t_launch / 1e9 / peak, "source": "profiles/r01_tendency_valu.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+
+
 def initial_state(ocn, model, seed=1234):
     from helpers import smooth_state
     g = model.grid
@@ -126,6 +142,7 @@ def main():
         arch = ctx.arch
         grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
         model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+        model.fuse_substep = os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"
         step = lambda dt: dist.time_step(model, dt)          # noqa: E731
         barrier = ctx.barrier
         vals = dist.local_initial_state(model, initial_state)
@@ -191,6 +208,7 @@ def main():
                      "algorithmic_bytes_note": ("average over the 3 launches of a time-step: 80 B/cell (tendencies) + 80 B/cell on the 2 "
                                                 "launches that carry the fused RK3 substep of the next stage") if fused_substep
                      else "80 B/cell: 5 fields read + 5 tendencies written",
+                     "valu": measured_valu(args.tendency_impl, N, t_launch) if world == 1 else None,
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
                      "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},
     }

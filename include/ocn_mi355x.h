@@ -111,6 +111,13 @@ int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v, const doub
 int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
                            const double *const *tracers, int ntracers,
                            double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range);
+/* the same pass with the rk3_substep! of the NEXT stage (runge_kutta_3.jl:179-226) fused in: when a cell's tendency is
+ * complete, U_next = U + dt (gamma Gn + zeta Gm) is written to a SECOND set of prognostic arrays (U itself is still read by
+ * neighbouring workgroups); the caller then swaps the two sets. fields / next / Gn / Gm are ordered u, v, w, tracers
+ * (3 + ntracers). OCN_ENOTSUP when the fused kernel cannot run on this grid (Bounded x / y). */
+int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fields, int ntracers, double *const *Gn,
+                                       const int *range, double *const *next, const double *const *Gm, double dt,
+                                       double gamma, double zeta, int has_zeta);
 
 /* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
 /* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage

@@ -50,6 +50,8 @@ SYMBOLS = {
     "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_fill_halo_regions_bcs": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "ocn_compute_flux_bcs": (C.c_int, [_vp, _vp, _ip, _vp]),
+    "ocn_compute_tendencies_and_substep": (C.c_int, [_vp, _vp, C.c_int, _vp, _ip, _vp, _vp, C.c_double, C.c_double, C.c_double,
+                                                     C.c_int]),
     "ocn_model_get_option": (C.c_int, [_vp, C.c_char_p, _ip]),
     "ocn_model_set_boundary_condition": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),

@@ -477,6 +477,19 @@ extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const do
     return OCN_OK;
 }
 
+extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fields, int ntracers, double *const *Gn,
+                                                  const int *range, double *const *next, const double *const *Gm, double dt,
+                                                  double gamma, double zeta, int has_zeta) {
+    NEED_INIT();
+    if (!grid || !fields || !Gn || !next || ntracers < 0 || ntracers > 3 || (has_zeta && !Gm)) return fail(OCN_EINVAL, "invalid argument");
+    for (int f = 0; f < 3 + ntracers; ++f)
+        if (!fields[f] || !Gn[f] || !next[f] || (has_zeta && !Gm[f])) return fail(OCN_EINVAL, "NULL field pointer");
+    if (!fused_path(grid->d, range, ntracers, 1))
+        return fail(OCN_ENOTSUP, "the fused tendency + substep pass needs Periodic / FullyConnected x and y");
+    const FusedSubstep sub{next, has_zeta ? Gm : Gn, dt, gamma, zeta, has_zeta ? 1 : 0};
+    return compute_tendencies(grid->d, fields[0], fields[1], fields[2], fields + 3, ntracers, Gn[0], Gn[1], Gn[2], Gn + 3, range, 1, &sub);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // RK3 substep, tendency caching
 // ---------------------------------------------------------------------------------------------------------------------

@@ -170,6 +170,8 @@ class DeviceBackend:
         L = _lib.lib()
         locs = [(Face, Center, Center), (Center, Face, Center), (Center, Center, Face)] + [(Center,) * 3] * ntracers
         self.U = [Field(l, g) for l in locs]
+        self.U2 = [Field(l, g) for l in locs]      # target of the fused substeps (see time_step); swaps with U twice per step
+        self.fused_substep = None                  # (Δt, γ, ζ) of the next stage while a fused evaluation is in flight
         self.Gn = [Field(l, g) for l in locs]
         self.Gm = [Field(l, g) for l in locs]
         self.p = Field((Center,) * 3, g)
@@ -235,6 +237,17 @@ class DeviceBackend:
     def swap_tendencies(self):
         self.Gn, self.Gm = self.Gm, self.Gn
 
+    def can_fuse_substep(self):
+        g = self.grid.local
+        no_flux = not any(bc.classification == "Flux" and bc.condition != 0.0
+                          for fb in getattr(self, "bcs", {}).values() for bc in fb.sides.values())
+        return no_flux and g.topology[1] is not Bounded and self.ntracers <= 3
+
+    def swap_prognostic(self):
+        """after a fused evaluation: the updated fields become the live ones (list contents swap, Field objects stay)"""
+        for a, b in zip(self.U, self.U2):
+            a.data, b.data = b.data, a.data
+
     def compute_tendencies(self, rng=None):
         from . import kernels
         U = self.U
@@ -243,8 +256,12 @@ class DeviceBackend:
             torch = self.ctx.torch
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        kernels.compute_tendencies(self.grid.local, U[0], U[1], U[2], U[3:], self.Gn[0], self.Gn[1], self.Gn[2], self.Gn[3:],
-                                   kernel_parameters=rng)
+        if self.fused_substep is None:
+            kernels.compute_tendencies(self.grid.local, U[0], U[1], U[2], U[3:], self.Gn[0], self.Gn[1], self.Gn[2], self.Gn[3:],
+                                       kernel_parameters=rng)
+        else:
+            Δt, γ, ζ = self.fused_substep
+            kernels.compute_tendencies_and_substep(self.grid.local, U, self.Gn, self.U2, self.Gm, Δt, γ, ζ, kernel_parameters=rng)
         if ev:
             ev[1].record()
             self.events.append(ev)
@@ -444,8 +461,13 @@ def time_step(model, Δt):
     ζ = (None, RK3["ζ2"], RK3["ζ3"])
     stage_dt = (Δt * γ[0], Δt * (γ[1] + ζ[1]), Δt * (γ[2] + ζ[2]))
     tn1 = model.time + Δt
+    # stages 2 and 3: rk3_substep! is fused into the tendency evaluation that precedes it (backend permitting)
+    fuse = getattr(model, "fuse_substep", True) and hasattr(b, "can_fuse_substep") and b.can_fuse_substep()
+    substep_done = False
     for s in range(3):
-        b.rk3_substep(Δt, γ[s], ζ[s])
+        if not substep_done:
+            b.rk3_substep(Δt, γ[s], ζ[s])
+        substep_done = False
         if s < 2:
             _tick(model, stage_dt[s], True)
         else:
@@ -456,7 +478,14 @@ def time_step(model, Δt):
         make_pressure_correction(model, stage_dt[s])
         if s < 2:
             b.swap_tendencies()           # cache_previous_tendencies! as a pointer swap (see ocn_api.hip)
-        update_state(model, True)
+        if s < 2 and fuse:
+            b.fused_substep = (Δt, γ[s + 1], ζ[s + 1])
+            update_state(model, True)
+            b.fused_substep = None
+            b.swap_prognostic()
+            substep_done = True
+        else:
+            update_state(model, True)
 
 
 def local_initial_state(model, fn):

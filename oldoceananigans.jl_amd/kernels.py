@@ -34,6 +34,13 @@ def compute_tendencies(grid, u, v, w, tracers, Gu, Gv, Gw, Gc, kernel_parameters
                                                  Gw.data, gc, _range(kernel_parameters)))
 
 
+def compute_tendencies_and_substep(grid, fields, Gn, next_fields, Gm, Δt, γ, ζ, kernel_parameters=None):
+    """tendencies of all prognostic fields (u, v, w, tracers...) + the rk3_substep! of the next stage into `next_fields`"""
+    _lib.check(_lib.lib().ocn_compute_tendencies_and_substep(
+        grid.handle, _ptr_array(fields), len(fields) - 3, _ptr_array(Gn), _range(kernel_parameters), _ptr_array(next_fields),
+        _ptr_array(Gm), float(Δt), float(γ), 0.0 if ζ is None else float(ζ), 0 if ζ is None else 1))
+
+
 def rk3_substep(grid, fields, Gn, Gm, Δt, γ, ζ):
     """rk3_substep_field! over a tuple of fields (ζ = None -> first stage)"""
     _lib.check(_lib.lib().ocn_rk3_substep(grid.handle, _ptr_array(fields), _ptr_array(Gn), _ptr_array(Gm),
