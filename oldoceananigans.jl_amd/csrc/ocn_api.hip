@@ -4,6 +4,7 @@
 #include "../../include/ocn_mi355x.h"
 #include "ocn_kernels.h"
 #include "ocn_tendency_fused.h"
+#include "ocn_tendency_lds.h"
 #include <hipfft/hipfft.h>
 #include <cmath>
 #include <cstdarg>
@@ -1406,6 +1407,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
+    if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

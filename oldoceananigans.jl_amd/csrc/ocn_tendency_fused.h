@@ -323,6 +323,7 @@ static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
 // tuned on MI355X at 256^3 (tools/tune_fused.py): 64 x 7 tiles, register z-windows, 2 waves/SIMD (no spills);
 // kchunk = 0: levels per workgroup chosen per launch so that the grid fills whole rounds of the chip (see pick_kchunk)
 static int g_fused_ty = 7, g_fused_kchunk = 0, g_fused_minw = 2, g_fused_zwin = 1;
+static int g_fused_lds = 0;     // 1: x / y windows from an LDS tile copy (ocn_tendency_lds.h), ntracers <= 2
 static int g_num_cus = 256;
 
 // Each workgroup primes 3 planes before its first cell closes, and the grid runs in rounds of one workgroup per CU (2 waves
@@ -338,6 +339,8 @@ static inline int pick_kchunk(int tiles_xy, int nz) {
     }
     return best;
 }
+
+template <int NTR, int TY> static int launch_fused_lds_t(const DGrid &g, hipStream_t stream, FusedArgs &a);   // ocn_tendency_lds.h
 
 template <int NTR, int TY>
 static int launch_fused_t(const DGrid &g, hipStream_t stream, FusedArgs &a) {
@@ -395,6 +398,11 @@ static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, cons
     case NTR:                                                                        \
         if (g_fused_ty == 3) return launch_fused_t<NTR, 3>(g, stream, a);            \
         return launch_fused_t<NTR, 7>(g, stream, a);
+    if (g_fused_lds && g.Hx >= 3 && g.Hy >= 3) {
+        if (ntr == 0) return launch_fused_lds_t<0, 7>(g, stream, a);
+        if (ntr == 1) return launch_fused_lds_t<1, 7>(g, stream, a);
+        if (ntr == 2) return launch_fused_lds_t<2, 7>(g, stream, a);
+    }
     switch (ntr) {
         OCN_FUSED_CASE(0)
         OCN_FUSED_CASE(1)

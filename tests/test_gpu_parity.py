@@ -42,13 +42,18 @@ def test_tendencies_match_oracle(ocn, oracle, arch, topology):
     set_both(ocn, m_gpu, m_cpu, seed=11, enforce_incompressibility=False)
     ocn.update_state(m_gpu, True)
     m_cpu.update_state(True)
-    for impl in (0, 1):
+    # per-field kernels (the reference's launch structure), fused register-window kernel, fused LDS-tile kernel
+    for impl, lds in ((0, 0), (1, 0), (1, 1)):
         m_gpu.set_option("tendency_impl", impl)
+        m_gpu.set_option("fused_lds", lds)
+        for n in m_gpu.fields():
+            m_gpu.tendency(n).set_parent(np.zeros(m_gpu.tendency(n).shape))
         ocn.update_state(m_gpu, True)
         for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
             G_gpu = m_gpu.tendency(n).parent()
             G_cpu = m_cpu.field("G" + cn)
-            assert np.array_equal(G_gpu, G_cpu), (impl, n, np.abs(G_gpu - G_cpu).max())
+            assert np.array_equal(G_gpu, G_cpu), (impl, lds, n, np.abs(G_gpu - G_cpu).max())
+    m_gpu.set_option("fused_lds", 0)
 
 
 @pytest.mark.parametrize("topology,stretched", [(TOPOS[0], False), (TOPOS[1], True), (TOPOS[1], False),
