@@ -228,6 +228,10 @@ int ocn_model_profile_read(ocn_model_t model, double *tendency_ms, int *count);
 /* test hook: counts the Float32 significands (of 2^23, binade 2^exponent) for which the fast correctly-rounded
  * reciprocal used inside newton_div (Utils/newton_div.jl:8-20) differs from the IEEE divide; must return 0 */
 int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatches);
+/* sampled check of the Float64 reciprocal used for the WENO weight normalisation against the compiler's IEEE divide:
+ * nsamples pseudo-random significands with exponents exp_lo..exp_hi; returns the number of differing results */
+int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, int exp_hi, unsigned long long seed,
+                          unsigned long long *mismatches);
 
 #ifdef __cplusplus
 }

@@ -1632,6 +1632,21 @@ extern "C" int ocn_debug_rcp_check(int variant, int exponent, unsigned long long
     return OCN_OK;
 }
 
+extern "C" int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, int exp_hi, unsigned long long seed,
+                                     unsigned long long *mismatches) {
+    NEED_INIT();
+    if (!mismatches || exp_lo < -1000 || exp_hi > 1000 || exp_lo > exp_hi || nsamples == 0 || nsamples > (1ull << 36))
+        return fail(OCN_EINVAL, "invalid argument");
+    unsigned long long *d;
+    HIP_TRY(dev_alloc((void **)&d, 8));
+    HIP_TRY(hipMemsetAsync(d, 0, 8, g_stream));
+    hipLaunchKernelGGL(rcp64_check_kernel, dim3((unsigned)((nsamples + 255) / 256)), dim3(256), 0, g_stream, nsamples, exp_lo, exp_hi, seed, d);
+    HIP_TRY(hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipFree(d));
+    return OCN_OK;
+}
+
 extern "C" int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !value) return fail(OCN_EINVAL, "NULL argument");

@@ -65,6 +65,25 @@ template <int VARIANT> __device__ __forceinline__ float rcp_rn_f32(float x) {
     return r;
 }
 
+// Correctly rounded Float64 reciprocal for the WENO weight normalisation `1 / sum(α)` (weno_interpolants.jl:336): the compiler's
+// IEEE divide expands to v_div_scale x2, v_rcp_f64, 2 Newton steps, v_mul, v_fma, v_div_fmas, v_div_fixup (11 VALU). For a
+// numerator of 1 and a denominator far from the exponent limits the scale factors are 1, v_div_fmas is a plain fma and
+// v_div_fixup passes its argument through, so the SAME operation sequence without them (7 VALU) returns the same bits.
+// sum(α) >= C★-sum = 1 and <= ~1e45 here. Checked against `1.0 / x` on sampled inputs by ocn_debug_rcp64_check.
+#ifndef OCN_RCP64_VARIANT
+#define OCN_RCP64_VARIANT 1
+#endif
+__device__ __forceinline__ double rcp_rn_f64(double d) {
+    if (OCN_RCP64_VARIANT == 0) return 1.0 / d;
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);          // n - d*q with q = n*r = r
+    return __builtin_fma(e, r, r);
+}
+
 __device__ __forceinline__ double newton_div_f32(double a, double b) {
     float b_low = (float)b;
     float inv_b = rcp_rn_f32<OCN_RCP_VARIANT>(b_low);
@@ -101,7 +120,7 @@ __device__ __forceinline__ double weno5_biased(double s0, double s1, double s2, 
     double al0 = OCN_W3C0 * (1.0 + r0 * r0);
     double al1 = OCN_W3C1 * (1.0 + r1 * r1);
     double al2 = OCN_W3C2 * (1.0 + r2 * r2);
-    double sinv = 1.0 / ((al0 + al1) + al2);
+    double sinv = rcp_rn_f64((al0 + al1) + al2);
     double w0 = al0 * sinv, w1 = al1 * sinv, w2 = al2 * sinv;
     double q0 = (OCN_W3P00 * a0 + OCN_W3P01 * a1) + OCN_W3P02 * a2;
     double q1 = (OCN_W3P10 * b0 + OCN_W3P11 * b1) + OCN_W3P12 * b2;
@@ -120,7 +139,7 @@ __device__ __forceinline__ double weno3_biased(double s0, double s1, double s2, 
     double r1 = newton_div_f32(tau, be1 + OCN_WENO_EPS);
     double al0 = OCN_W2C0 * (1.0 + r0 * r0);
     double al1 = OCN_W2C1 * (1.0 + r1 * r1);
-    double sinv = 1.0 / (al0 + al1);
+    double sinv = rcp_rn_f64(al0 + al1);
     double w0 = al0 * sinv, w1 = al1 * sinv;
     double q0 = OCN_W2P00 * a0 + OCN_W2P01 * a1;
     double q1 = OCN_W2P10 * b0 + OCN_W2P11 * b1;

@@ -499,6 +499,20 @@ __global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsig
     if (__float_as_uint(a) != __float_as_uint(b)) atomicAdd(mismatches, 1ULL);
 }
 
+// sampled check of rcp_rn_f64 against the compiler's IEEE divide: pseudo-random significands, exponents exp_lo..exp_hi
+__global__ void __launch_bounds__(256) rcp64_check_kernel(unsigned long long n, int exp_lo, int exp_hi, unsigned long long seed,
+                                                          unsigned long long *mismatches) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    unsigned long long h = (t + seed) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 31; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+    const unsigned long long mant = h & ((1ull << 52) - 1);
+    const int e = exp_lo + (int)((h >> 52) % (unsigned long long)(exp_hi - exp_lo + 1));
+    const double x = __longlong_as_double((long long)(((unsigned long long)(e + 1023) << 52) | mant));
+    const double a = rcp_rn_f64(x), b = 1.0 / x;
+    if (__double_as_longlong(a) != __double_as_longlong(b)) atomicAdd(mismatches, 1ULL);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // distributed x-slab support (src/DistributedComputations)
 // ---------------------------------------------------------------------------------------------------------------------

@@ -260,3 +260,22 @@ def test_fused_substep_is_bit_identical_to_separate_kernels(ocn, arch, topology)
         model.close()
     for n in out[0]:
         assert np.array_equal(out[0][n], out[1][n]), n
+
+
+def test_fast_reciprocals_are_correctly_rounded(ocn, arch):
+    """the Float32 reciprocal inside newton_div (v_rcp_f32 + one Markstein step) is compared EXHAUSTIVELY -- all 2^23
+    significands of a binade, binades spanning the range the WENO argument beta + eps can take -- with the compiler's correctly
+    rounded divide; the Float64 reciprocal of the weight normalisation (the IEEE divide sequence without its scale / fixup
+    instructions) on 2^28 sampled inputs over the exponents sum(alpha) can take. Zero mismatches = same bits as the reference's
+    `1f0 / x` and `1 / x`."""
+    import ctypes as C
+    from oldoceananigans_jl_amd import _lib
+    L = _lib.lib()
+    bad = C.c_ulonglong()
+    for exponent in (-27, -20, -8, -1, 0, 1, 7, 23, 40, 63):          # beta + eps in [1e-8, ~1e19]
+        _lib.check(L.ocn_debug_rcp_check(1, exponent, C.byref(bad)))
+        assert bad.value == 0, (exponent, bad.value)
+    _lib.check(L.ocn_debug_rcp64_check(1 << 28, 0, 160, 12345, C.byref(bad)))
+    assert bad.value == 0, bad.value
+    _lib.check(L.ocn_debug_rcp64_check(1 << 24, -60, 0, 99, C.byref(bad)))       # below the range in use: still exact
+    assert bad.value == 0, bad.value
