@@ -592,6 +592,7 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 // Poisson solvers
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_real_fft = 1, g_c2r_strided = 1;
+static int g_fused_zfft = 1;    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
 
 struct ocn_poisson_s {
     ocn_grid_t grid;
@@ -613,6 +614,9 @@ struct ocn_poisson_s {
     double2 *hc2 = nullptr;      // kind 1: tridiagonal solution (separate from the rhs like the reference's storage)
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     bool has_r2c = false, has_c2r = false, c2r_strided = false;
+    bool zfused = false;         // kind 0: 2-D (x, y) plans + zline_solve_kernel instead of 3-D plans + divide kernel
+    int logn_z = 0;
+    double2 *ztw = nullptr;      // exp(-2πi m / Nz), m < Nz/2
     // grids with Bounded transformed directions: per-direction line transforms (see ocn_kernels.h, line_gather_kernel)
     bool general = false;
     hipfftHandle plan_line[3] = {0, 0, 0};
@@ -638,6 +642,7 @@ extern "C" int ocn_poisson_destroy(ocn_poisson_t s) {
     for (int d = 0; d < 3; ++d)
         if (s->has_line[d]) hipfftDestroy(s->plan_line[d]);
     hipFree(s->buffer);
+    hipFree(s->ztw);
     hipFree(s->rrhs); hipFree(s->hc); hipFree(s->hc2);
     hipFree(s->storage); hipFree(s->source); hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     hipFree(s->partial); hipFree(s->mean);
@@ -670,7 +675,7 @@ static int verify_real_plans(ocn_poisson_s *s) {
     HIP_TRY(dev_alloc((void **)&bm, nb * sizeof(double)));
     hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, s->rrhs, n);
     hipfftResult r = hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)s->hc);
-    const double scale = s->kind == 0 ? 1.0 / ((double)g.Nx * g.Ny * g.Nz) : 1.0 / ((double)g.Nx * g.Ny);
+    const double scale = (s->kind == 0 && !s->zfused) ? 1.0 / ((double)g.Nx * g.Ny * g.Nz) : 1.0 / ((double)g.Nx * g.Ny);
     if (r == HIPFFT_SUCCESS) {
         if (s->c2r_strided) {
             hipError_t e = dev_alloc((void **)&tmp, (size_t)Px * Py * Pz * sizeof(double));
@@ -866,7 +871,18 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             TRY_OR_FREE(hipMemset(s->hc2, 0, s->nh * sizeof(double2)));
         }
         const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
-        if (kind == 0) {
+        if (kind == 0 && g_fused_zfft && g.Nz >= 8 && g.Nz <= 512 && (g.Nz & (g.Nz - 1)) == 0) {
+            s->zfused = true;
+            while ((1 << s->logn_z) < g.Nz) ++s->logn_z;
+            std::vector<double2> tw(g.Nz / 2);
+            for (int m = 0; m < g.Nz / 2; ++m) {
+                const double a = -2.0 * M_PI * (double)m / (double)g.Nz;
+                tw[m] = make_double2(cos(a), sin(a));
+            }
+            TRY_OR_FREE(dev_alloc((void **)&s->ztw, tw.size() * sizeof(double2)));
+            TRY_OR_FREE(hipMemcpy(s->ztw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
+        }
+        if (kind == 0 && !s->zfused) {
             int n3[3] = {g.Nz, g.Ny, g.Nx};
             r = hipfftPlanMany(&s->plan_r2c, 3, n3, nullptr, 1, 0, nullptr, 1, 0, HIPFFT_D2Z, 1);
             if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(D2Z 3-D) failed (%d)", (int)r); goto bad; }
@@ -980,7 +996,11 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
     { int rc_; if ((rc_ = plan_set_stream(s->plan_r2c)) || (rc_ = plan_set_stream(s->plan_c2r))) return rc_; }
     FFT_TRY(hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)s->hc));
     double2 *sol = s->hc;
-    if (s->kind == 0) {
+    if (s->kind == 0 && s->zfused) {
+        const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
+        hipLaunchKernelGGL(zline_solve_kernel, dim3((s->Nxh + OCN_ZL - 1) / OCN_ZL, g.Ny), dim3(256), (size_t)g.Nz * OCN_ZL * sizeof(double2),
+                           g_stream, s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale);
+    } else if (s->kind == 0) {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
         hipLaunchKernelGGL(spectral_divide_kernel, grid3(s->Nxh, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->hc, s->lam[0], s->lam[1],
                            s->lam[2], s->Nxh, g.Ny, g.Nz, scale, true);
@@ -1408,6 +1428,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
     if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
+    if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

@@ -438,6 +438,105 @@ __global__ void __launch_bounds__(256) line_scatter_kernel(const double2 *B, dou
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused z pass of the FFT-based Poisson solve on the Hermitian half spectrum (Nxs, Ny, Nz), z Periodic, Nz a power of two:
+// forward FFT along z, ϕ̂ = -b̂ / (λx + λy + λz) (fft_based_poisson_solver.jl:108-118), inverse FFT along z -- ONE pass over the
+// array instead of three (rocFFT column transform, divide kernel, rocFFT column transform). A workgroup holds ZL z-lines
+// (consecutive in x: 128-B rows) in LDS. Forward = radix-2 decimation in frequency (natural -> bit-reversed order), the divide
+// runs in bit-reversed order, inverse = radix-2 decimation in time (bit-reversed -> natural): in place, no reordering pass.
+// tw[m] = exp(-2πi m / Nz), m < Nz/2 (host-computed). `scale` folds the normalisation of the whole 3-D inverse transform.
+// ---------------------------------------------------------------------------------------------------------------------
+#define OCN_ZL 8
+__global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const double2 *tw, const double *lx, const double *ly,
+                                                          const double *lz, int Nxs, int Ny, int Nz, int logn, double scale) {
+    extern __shared__ double2 zbuf[];                 // [Nz][OCN_ZL]
+    const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;       // 32 k-rows per pass
+    const int i0 = blockIdx.x * OCN_ZL, j = blockIdx.y;
+    const int i = i0 + il;
+    const bool live = i < Nxs;
+    const long plane = (long)Nxs * Ny, base = (long)i + (long)Nxs * j;
+    for (int k = kq; k < Nz; k += 256 / OCN_ZL) zbuf[k * OCN_ZL + il] = live ? hc[base + plane * k] : make_double2(0.0, 0.0);
+    __syncthreads();
+    const int half = Nz >> 1, quarter = Nz >> 2, KQ = 256 / OCN_ZL;
+#define ZB(n) zbuf[(n) * OCN_ZL + il]
+#define CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)        /* (ar + i ai) * w       */
+#define CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)       /* v * conj(w)           */
+    // forward, decimation in frequency (natural -> bit-reversed): spans Nz/2, Nz/4, ..., 1; two radix-2 stages are fused in
+    // registers (radix-4 butterflies: half the LDS traffic and barriers), preceded by one radix-2 stage when log2 Nz is odd
+    int h = half, st = 1;
+    if (logn & 1) {
+        for (int q = kq; q < half; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), xb = ZB(b), w = tw[jj * st];
+            ZB(a) = make_double2(xa.x + xb.x, xa.y + xb.y);
+            ZB(b) = CMUL(xa.x - xb.x, xa.y - xb.y, w);
+        }
+        __syncthreads();
+        h >>= 1; st <<= 1;
+    }
+    for (; h >= 2; h >>= 2, st <<= 2) {
+        const int h2 = h >> 1;
+        for (int q = kq; q < quarter; q += KQ) {
+            const int jj = q & (h2 - 1), a = ((q - jj) << 2) + jj;             // blocks of 2h elements, jj < h/2
+            const double2 x0 = ZB(a), x1 = ZB(a + h2), x2 = ZB(a + h), x3 = ZB(a + h + h2);
+            const double2 wa = tw[jj * st], wb = tw[(jj + h2) * st], wc = tw[jj * 2 * st];
+            const double2 y0 = make_double2(x0.x + x2.x, x0.y + x2.y), y2 = CMUL(x0.x - x2.x, x0.y - x2.y, wa);
+            const double2 y1 = make_double2(x1.x + x3.x, x1.y + x3.y), y3 = CMUL(x1.x - x3.x, x1.y - x3.y, wb);
+            ZB(a) = make_double2(y0.x + y1.x, y0.y + y1.y);
+            ZB(a + h2) = CMUL(y0.x - y1.x, y0.y - y1.y, wc);
+            ZB(a + h) = make_double2(y2.x + y3.x, y2.y + y3.y);
+            ZB(a + h + h2) = CMUL(y2.x - y3.x, y2.y - y3.y, wc);
+        }
+        __syncthreads();
+    }
+    // spectral divide in bit-reversed order
+    if (live) {
+        const double lxy = lx[i] + ly[j];
+        for (int p = kq; p < Nz; p += KQ) {
+            const int k = (int)(__brev((unsigned)p) >> (32 - logn));
+            double2 v = ZB(p);
+            const double lam = lxy + lz[k] - 0.0;
+            v.x = -(v.x * scale) / lam;
+            v.y = -(v.y * scale) / lam;
+            if (i == 0 && j == 0 && k == 0) v = make_double2(0.0, 0.0);
+            ZB(p) = v;
+        }
+    }
+    __syncthreads();
+    // inverse, decimation in time (bit-reversed -> natural): spans 1, 2, ..., Nz/2, conjugate twiddles, fused in pairs
+    h = 1; st = half;
+    for (; (h << 1) <= half; h <<= 2, st >>= 2) {
+        for (int q = kq; q < quarter; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 2) + jj;              // blocks of 4h elements, jj < h
+            const double2 x0 = ZB(a), x1 = ZB(a + h), x2 = ZB(a + 2 * h), x3 = ZB(a + 3 * h);
+            const double2 wa = tw[jj * st], wb = tw[jj * (st >> 1)], wc = tw[(jj + h) * (st >> 1)];
+            const double2 t1 = CMULC(x1, wa), t3 = CMULC(x3, wa);
+            const double2 y0 = make_double2(x0.x + t1.x, x0.y + t1.y), y1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+            const double2 y2 = make_double2(x2.x + t3.x, x2.y + t3.y), y3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+            const double2 u2 = CMULC(y2, wb), u3 = CMULC(y3, wc);
+            ZB(a) = make_double2(y0.x + u2.x, y0.y + u2.y);
+            ZB(a + 2 * h) = make_double2(y0.x - u2.x, y0.y - u2.y);
+            ZB(a + h) = make_double2(y1.x + u3.x, y1.y + u3.y);
+            ZB(a + 3 * h) = make_double2(y1.x - u3.x, y1.y - u3.y);
+        }
+        __syncthreads();
+    }
+    if (h <= half) {                          // one radix-2 stage left when log2 Nz is odd (h == half here)
+        for (int q = kq; q < half; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), t = CMULC(ZB(b), tw[jj * st]);
+            ZB(a) = make_double2(xa.x + t.x, xa.y + t.y);
+            ZB(b) = make_double2(xa.x - t.x, xa.y - t.y);
+        }
+        __syncthreads();
+    }
+#undef ZB
+#undef CMUL
+#undef CMULC
+    if (live)
+        for (int k = kq; k < Nz; k += 256 / OCN_ZL) hc[base + plane * k] = zbuf[k * OCN_ZL + il];
+}
+
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
 __global__ void __launch_bounds__(256) sum_partial_kernel(const double2 *x, long n, double2 *partial) {
     __shared__ double sx[256], sy[256];

@@ -105,6 +105,34 @@ def test_poisson_fft_solver_residual(ocn, oracle, arch):
         assert rel_err(c, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-12
 
 
+@pytest.mark.parametrize("size", [(8, 8, 8), (16, 16, 16), (12, 10, 32), (4, 6, 64), (6, 5, 128), (4, 4, 512), (10, 6, 7), (8, 8, 1024)])
+def test_solve_for_pressure_real_transform_path(ocn, oracle, arch, size):
+    """solve_for_pressure! as the model runs it (real-to-complex transforms; for Nz = 2^m in 8..512 the z transform, the spectral
+    divide and the inverse z transform are one fused pass, zline_solve_kernel -- even and odd m; other Nz: rocFFT 3-D plans)
+    against the oracle's source term + complex FFT solve"""
+    rng = np.random.default_rng(size[2])
+    grid = ocn.RectilinearGrid(arch, size=size, extent=(1, 1, 1))
+    solver = ocn.FFTBasedPoissonSolver(grid)
+    g_cpu = oracle.Grid(size)
+    U, A = [], []
+    for F, loc in ((ocn.XFaceField, "u"), (ocn.YFaceField, "v"), (ocn.ZFaceField, "w")):
+        f = F(grid)
+        a = np.asfortranarray(rng.standard_normal(f.shape))
+        f.set_parent(a)
+        ocn.fill_halo_regions(f)
+        g_cpu.fill_halo_regions(a, oracle.LOC[loc])
+        U.append(f)
+        A.append(a)
+    p = ocn.CenterField(grid)
+    ocn.solve_for_pressure(p, solver, U)
+    s_cpu = oracle.PoissonSolver(g_cpu, 0)
+    s_cpu.rhs[...] = g_cpu.source_term(*A)
+    p_cpu = g_cpu.zeros(oracle.LOC["c"])
+    s_cpu.solve(p_cpu)
+    assert rel_err(p.parent()[3:-3, 3:-3, 3:-3], p_cpu[3:-3, 3:-3, 3:-3]) < 1e-12
+    solver.close()
+
+
 @pytest.mark.parametrize("topology", TOPOS + TOPOS_XY)
 @pytest.mark.parametrize("kind", ["fft", "tridiagonal"])
 def test_poisson_solvers_all_topologies(ocn, oracle, arch, topology, kind):
