@@ -1121,13 +1121,17 @@ struct ocn_dist_poisson_s {
     double *D = nullptr, *lower = nullptr, *t = nullptr;
     hipfftHandle plan_loc = 0, plan_x = 0;
     bool has_loc = false, has_x = false;
+    // zmode 0, Nxg = 2^m <= 4096: the x stage (unpack, FFT, divide, inverse FFT, pack) is one LDS pass (xline_solve_kernel)
+    bool xfused = false;
+    int logn_x = 0, xlines = 1;
+    double2 *xtw = nullptr;
 };
 
 extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     if (!s) return OCN_OK;
     if (s->has_loc) hipfftDestroy(s->plan_loc);
     if (s->has_x) hipfftDestroy(s->plan_x);
-    hipFree(s->zfield); hipFree(s->xfield); hipFree(s->xsol);
+    hipFree(s->zfield); hipFree(s->xfield); hipFree(s->xsol); hipFree(s->xtw);
     hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
     delete s;
@@ -1208,14 +1212,29 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         }
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(local y/z) failed (%d)", (int)r); goto bad; }
         s->has_loc = true;
-        int nx[1] = {s->Nxg};
-        r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyc * s->Nz);
-        if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
-        s->has_x = true;
-        if ((rc = plan_set_stream(s->plan_loc)) || (rc = plan_set_stream(s->plan_x))) goto bad;
+        if (zmode == 0 && g_fused_zfft && s->Nxg >= 8 && s->Nxg <= 4096 && (s->Nxg & (s->Nxg - 1)) == 0) {
+            s->xfused = true;
+            while ((1 << s->logn_x) < s->Nxg) ++s->logn_x;
+            s->xlines = std::max(1, 4096 / s->Nxg);           // 64 KB of LDS per workgroup
+            std::vector<double2> tw(s->Nxg / 2);
+            for (int m = 0; m < s->Nxg / 2; ++m) {
+                const double a = -2.0 * M_PI * (double)m / (double)s->Nxg;
+                tw[m] = make_double2(cos(a), sin(a));
+            }
+            TRY_OR_FREE(dev_alloc((void **)&s->xtw, tw.size() * sizeof(double2)));
+            TRY_OR_FREE(hipMemcpy(s->xtw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
+        }
+        if ((rc = plan_set_stream(s->plan_loc))) goto bad;
         const double sc = zmode == 0 ? 1.0 / ((double)s->Ny * s->Nz) : 1.0 / (double)s->Ny;
         if ((rc = verify_complex_plan(s->plan_loc, s->zfield, (long)s->nz_c, sc, "distributed local (y, z)"))) goto bad;
-        if ((rc = verify_complex_plan(s->plan_x, s->xfield, (long)s->nbuf, 1.0 / (double)s->Nxg, "distributed x"))) goto bad;
+        if (!s->xfused) {
+            int nx[1] = {s->Nxg};
+            r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyc * s->Nz);
+            if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
+            s->has_x = true;
+            if ((rc = plan_set_stream(s->plan_x))) goto bad;
+            if ((rc = verify_complex_plan(s->plan_x, s->xfield, (long)s->nbuf, 1.0 / (double)s->Nxg, "distributed x"))) goto bad;
+        }
     }
     *solver = s;
     return OCN_OK;
@@ -1273,6 +1292,17 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s) {
     NEED_INIT();
     if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
     int rc;
+    if (s->xfused) {
+        // send may alias recv (one rank): a workgroup reads all of its lines before it writes them back
+        const double scale = 1.0 / ((double)s->Nxg * (double)s->Ny * (double)s->Nz);
+        const long nlines = (long)s->Nyc * s->Nz;
+        const unsigned nb = (unsigned)((nlines + s->xlines - 1) / s->xlines);
+        hipLaunchKernelGGL(xline_solve_kernel, dim3(nb), dim3(256), (size_t)s->xlines * s->Nxg * sizeof(double2), g_stream, s->recv, s->send,
+                           s->xtw, s->lam[0], s->lam[1], s->lam[2], s->R, s->Nxl, s->Nyc, s->Nz, s->logn_x, s->xlines, s->rank * s->Nyc,
+                           s->Ny, scale);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     if ((rc = transpose_stage(s, 1, s->recv, s->xfield))) return rc;
     if ((rc = plan_set_stream(s->plan_x))) return rc;
     FFT_TRY(hipfftExecZ2Z(s->plan_x, (hipfftDoubleComplex *)s->xfield, (hipfftDoubleComplex *)s->xfield, HIPFFT_FORWARD));

@@ -537,6 +537,113 @@ __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const dou
         for (int k = kq; k < Nz; k += 256 / OCN_ZL) hc[base + plane * k] = zbuf[k * OCN_ZL + il];
 }
 
+// The x stage of the distributed FFT solve in ONE pass (distributed_fft_based_poisson_solver.jl:152-166 with the transposes'
+// unpack / pack folded in): a workgroup gathers L whole x-lines (length Nxg = R * Nxl, a power of two) from the all-to-all
+// receive buffer -- chunk p holds columns [p*Nxl, (p+1)*Nxl) of every line (il fastest) --, transforms them forward (radix-4
+// DIF), divides by the eigenvalues in bit-reversed order, transforms back (DIT) and scatters them into the send buffer in
+// the same chunk layout. Replaces unpack + rocFFT + divide + rocFFT + pack (5 passes). LDS: L * Nxg complex.
+__global__ void __launch_bounds__(256) xline_solve_kernel(const double2 *recv, double2 *send, const double2 *tw, const double *lx,
+                                                          const double *ly, const double *lz, int R, int Nxl, int Nyc, int Nz,
+                                                          int logn, int L, int joff, int Ny, double scale) {
+    extern __shared__ double2 zbuf[];                 // [L][Nxg]
+    const int N = R * Nxl;
+    const long nlines = (long)Nyc * Nz, line0 = (long)blockIdx.x * L;
+    const long chunk = (long)Nxl * nlines;
+    const int total = L * N;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int ln = e >> logn, n = e & (N - 1);
+        const long line = line0 + ln;
+        const int pch = n / Nxl, il = n - pch * Nxl;
+        zbuf[e] = line < nlines ? recv[pch * chunk + il + (long)Nxl * line] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const int half = N >> 1, quarter = N >> 2;
+#define ZB(n) zbuf[lo + (n)]
+#define CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)
+#define CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)
+    int h = half, st = 1;
+    if (logn & 1) {
+        for (int e = threadIdx.x; e < L * half; e += 256) {
+            const int ln = e >> (logn - 1), q = e & (half - 1), lo = ln << logn;
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), xb = ZB(b), w = tw[jj * st];
+            ZB(a) = make_double2(xa.x + xb.x, xa.y + xb.y);
+            ZB(b) = CMUL(xa.x - xb.x, xa.y - xb.y, w);
+        }
+        __syncthreads();
+        h >>= 1; st <<= 1;
+    }
+    for (; h >= 2; h >>= 2, st <<= 2) {
+        const int h2 = h >> 1;
+        for (int e = threadIdx.x; e < L * quarter; e += 256) {
+            const int ln = e >> (logn - 2), q = e & (quarter - 1), lo = ln << logn;
+            const int jj = q & (h2 - 1), a = ((q - jj) << 2) + jj;
+            const double2 x0 = ZB(a), x1 = ZB(a + h2), x2 = ZB(a + h), x3 = ZB(a + h + h2);
+            const double2 wa = tw[jj * st], wb = tw[(jj + h2) * st], wc = tw[jj * 2 * st];
+            const double2 y0 = make_double2(x0.x + x2.x, x0.y + x2.y), y2 = CMUL(x0.x - x2.x, x0.y - x2.y, wa);
+            const double2 y1 = make_double2(x1.x + x3.x, x1.y + x3.y), y3 = CMUL(x1.x - x3.x, x1.y - x3.y, wb);
+            ZB(a) = make_double2(y0.x + y1.x, y0.y + y1.y);
+            ZB(a + h2) = CMUL(y0.x - y1.x, y0.y - y1.y, wc);
+            ZB(a + h) = make_double2(y2.x + y3.x, y2.y + y3.y);
+            ZB(a + h + h2) = CMUL(y2.x - y3.x, y2.y - y3.y, wc);
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int ln = e >> logn, pz = e & (N - 1);
+        const long line = line0 + ln;
+        if (line >= nlines) continue;
+        const int jl = (int)(line % Nyc), k = (int)(line / Nyc);
+        const int i = (int)(__brev((unsigned)pz) >> (32 - logn));
+        const int jg = min(joff + jl, Ny - 1);
+        double2 v = zbuf[e];
+        const double lam = (lx[i] + ly[jg]) + lz[k] - 0.0;
+        v.x = -(v.x * scale) / lam;
+        v.y = -(v.y * scale) / lam;
+        if (i == 0 && joff + jl == 0 && k == 0) v = make_double2(0.0, 0.0);
+        zbuf[e] = v;
+    }
+    __syncthreads();
+    h = 1; st = half;
+    for (; (h << 1) <= half; h <<= 2, st >>= 2) {
+        for (int e = threadIdx.x; e < L * quarter; e += 256) {
+            const int ln = e >> (logn - 2), q = e & (quarter - 1), lo = ln << logn;
+            const int jj = q & (h - 1), a = ((q - jj) << 2) + jj;
+            const double2 x0 = ZB(a), x1 = ZB(a + h), x2 = ZB(a + 2 * h), x3 = ZB(a + 3 * h);
+            const double2 wa = tw[jj * st], wb = tw[jj * (st >> 1)], wc = tw[(jj + h) * (st >> 1)];
+            const double2 t1 = CMULC(x1, wa), t3 = CMULC(x3, wa);
+            const double2 y0 = make_double2(x0.x + t1.x, x0.y + t1.y), y1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+            const double2 y2 = make_double2(x2.x + t3.x, x2.y + t3.y), y3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+            const double2 u2 = CMULC(y2, wb), u3 = CMULC(y3, wc);
+            ZB(a) = make_double2(y0.x + u2.x, y0.y + u2.y);
+            ZB(a + 2 * h) = make_double2(y0.x - u2.x, y0.y - u2.y);
+            ZB(a + h) = make_double2(y1.x + u3.x, y1.y + u3.y);
+            ZB(a + 3 * h) = make_double2(y1.x - u3.x, y1.y - u3.y);
+        }
+        __syncthreads();
+    }
+    if (h <= half) {
+        for (int e = threadIdx.x; e < L * half; e += 256) {
+            const int ln = e >> (logn - 1), q = e & (half - 1), lo = ln << logn;
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), t = CMULC(ZB(b), tw[jj * st]);
+            ZB(a) = make_double2(xa.x + t.x, xa.y + t.y);
+            ZB(b) = make_double2(xa.x - t.x, xa.y - t.y);
+        }
+        __syncthreads();
+    }
+#undef ZB
+#undef CMUL
+#undef CMULC
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int ln = e >> logn, n = e & (N - 1);
+        const long line = line0 + ln;
+        if (line >= nlines) continue;
+        const int pch = n / Nxl, il = n - pch * Nxl;
+        send[pch * chunk + il + (long)Nxl * line] = zbuf[e];
+    }
+}
+
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
 __global__ void __launch_bounds__(256) sum_partial_kernel(const double2 *x, long n, double2 *partial) {
     __shared__ double sx[256], sy[256];
