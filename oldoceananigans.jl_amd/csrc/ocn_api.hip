@@ -259,6 +259,8 @@ static int check_range(const DGrid &g, const int *range, Range6 *out, const int 
 // ---------------------------------------------------------------------------------------------------------------------
 // halo fills
 // ---------------------------------------------------------------------------------------------------------------------
+static int g_fused_halo = 1;     // triply periodic grids: the three directional periodic fills as one launch
+
 static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n, const int loc[3], bool fill_open,
                            const ocn_bc_t (*bcs)[6]) {
     if (n <= 0) return OCN_OK;
@@ -291,6 +293,14 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open);
         if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open);
         if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open);
+    }
+    // triply periodic with N >= H everywhere: one launch writes every halo cell from its wrapped interior source
+    if (g_fused_halo && T[0] == OCN_PERIODIC && T[1] == OCN_PERIODIC && T[2] == OCN_PERIODIC && N[0] >= H[0] && N[1] >= H[1] && N[2] >= H[2]) {
+        const long total = (long)P[0] * P[1] * (2 * H[2]) + (long)P[0] * (2 * H[1]) * N[2] + (long)(2 * H[0]) * N[1] * N[2];
+        hipLaunchKernelGGL(fill_periodic_xyz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], N[0],
+                           N[1], N[2], H[0], H[1], H[2]);
+        KERNEL_CHECK();
+        return OCN_OK;
     }
     for (int d = 2; d >= 0; --d) {
         if (T[d] != OCN_PERIODIC) continue;
@@ -1459,6 +1469,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
     if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
     if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
+    if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

@@ -127,6 +127,38 @@ __global__ void __launch_bounds__(256) fill_periodic_kernel(FieldList fl, int P0
     for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
 }
 
+// Triply periodic grids: the three directional fills in ONE launch. Filling z, then y, then x over the whole parent extent
+// (the reference's order) leaves every halo cell -- edges and corners included -- equal to the interior cell at the wrapped
+// index in each direction, so each halo cell can be written directly from that interior cell: same bits, a third of the
+// launches, and the x halos are no longer a separate uncoalesced pass. Thread -> one halo cell of the (P0, P1, P2) parent.
+__global__ void __launch_bounds__(256) fill_periodic_xyz_kernel(FieldList fl, int P0, int P1, int P2, int N0, int N1, int N2, int H0,
+                                                                int H1, int H2) {
+    // halo cells are enumerated as three slabs: all (i, j) of the 2*H2 halo planes; then, for interior k, the 2*H1 halo rows;
+    // then, for interior (j, k), the 2*H0 halo columns
+    const long nz = (long)P0 * P1 * (2 * H2), ny = (long)P0 * (2 * H1) * N2, nx = (long)(2 * H0) * N1 * N2;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int i, j, k;
+    if (t < nz) {
+        i = t % P0; const long r = t / P0; j = r % P1; const int hz = r / P1;
+        k = hz < H2 ? hz : N2 + hz;
+    } else if ((t -= nz) < ny) {
+        i = t % P0; const long r = t / P0; const int hy = r % (2 * H1);
+        j = hy < H1 ? hy : N1 + hy;
+        k = H2 + (int)(r / (2 * H1));
+    } else if ((t -= ny) < nx) {
+        const int hx = t % (2 * H0); const long r = t / (2 * H0);
+        i = hx < H0 ? hx : N0 + hx;
+        j = H1 + (int)(r % N1);
+        k = H2 + (int)(r / N1);
+    } else return;
+    // wrapped interior source (0-based parent indices; interior is [H, H + N))
+    const int si = i < H0 ? i + N0 : (i >= H0 + N0 ? i - N0 : i);
+    const int sj = j < H1 ? j + N1 : (j >= H1 + N1 ? j - N1 : j);
+    const int sk = k < H2 ? k + N2 : (k >= H2 + N2 ? k - N2 : k);
+    const long od = i + (long)P0 * (j + (long)P1 * k), os = si + (long)P0 * (sj + (long)P1 * sk);
+    for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
+}
+
 // Bounded directions, ONE halo cell (fill_halo_kernels.jl:69-70), launched over the INTERIOR extent (grid N) of the two
 // other dims. Center fields: Flux / default -> mirror (fill_halo_regions_flux.jl:9-27); Value / Gradient -> linear
 // extrapolation through the boundary face (fill_halo_regions_value_gradient.jl:7-119). Face fields: Open wall value
