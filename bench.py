@@ -123,6 +123,9 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="cells per side per GPU")
     ap.add_argument("--tendency-impl", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched"],
+                    help="ppp: BASELINE.json configs[1] (the metric's configuration, default); ppb_stretched: configs[2], "
+                         "256x256x128 (Periodic, Periodic, Bounded) with tanh-stretched z (Fourier-tridiagonal solver), single GPU")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,7 +152,12 @@ def main():
         dist.set_model(model, **vals)
     else:
         arch = ocn.GPU(local_rank)
-        grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
+        if args.workload == "ppb_stretched":
+            from helpers import tanh_faces
+            grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
+                                       topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        else:
+            grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
         model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
         step = lambda dt: ocn.time_step(model, dt)            # noqa: E731
         barrier = lambda: None                                # noqa: E731
@@ -199,20 +207,24 @@ def main():
         ctx.dist.destroy_process_group()
     if rank != 0:
         return
-    cells = float(N) ** 3 * world
+    cells = float(N) ** 3 * world * (0.5 if args.workload == "ppb_stretched" else 1.0)
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
     fused_substep = (not distributed) and model.get_option("fuse_substep_active") == 1
     bytes_per_cell = TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * fused_substep
-    achieved = bytes_per_cell * float(N) ** 3 / t_launch / 1e9 if tend_n else None
+    cells_per_gpu = cells / world
+    achieved = bytes_per_cell * cells_per_gpu / t_launch / 1e9 if tend_n else None
     out = {
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 else None,
+        "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" else None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{N * world}x{N}x{N} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
-                               "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])",
+        "config": {"workload": (f"{N * world}x{N}x{N} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
+                                "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])")
+                   if args.workload == "ppp" else
+                   (f"{N}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
+                    "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])"),
                    "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}), RCCL halo + all-to-all transposes",
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
@@ -222,13 +234,13 @@ def main():
                      else "per-field WENO-5 tendency kernels (5 launches)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
-                     "traffic": measured_traffic(args.tendency_impl, N) if world == 1 else None,
+                     "traffic": measured_traffic(args.tendency_impl, N) if world == 1 and args.workload == "ppp" else None,
                      "traffic_source": "profiles/r01_tendency_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                     "algorithmic_bytes_per_launch": bytes_per_cell * float(N) ** 3,
+                     "algorithmic_bytes_per_launch": bytes_per_cell * cells_per_gpu,
                      "algorithmic_bytes_note": ("average over the 3 launches of a time-step: 80 B/cell (tendencies) + 80 B/cell on the 2 "
                                                 "launches that carry the fused RK3 substep of the next stage") if fused_substep
                      else "80 B/cell: 5 fields read + 5 tendencies written",
-                     "valu": measured_valu(args.tendency_impl, N, t_launch) if world == 1 else None,
+                     "valu": measured_valu(args.tendency_impl, N, t_launch) if world == 1 and args.workload == "ppp" else None,
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,
                      "share_of_step": tend_ms / (1e3 * elapsed) if elapsed else None},
     }

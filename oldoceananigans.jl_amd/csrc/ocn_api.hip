@@ -1061,6 +1061,8 @@ extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const dou
                                                const double *f_complex, double *t, double *phi_complex) {
     NEED_INIT();
     if (Nx < 1 || Ny < 1 || Nz < 1 || !a || !b || !c || !f_complex || !t || !phi_complex) return fail(OCN_EINVAL, "invalid argument");
+    if ((const void *)f_complex == (const void *)phi_complex || (const void *)t == (const void *)b)
+        return fail(OCN_EINVAL, "the right-hand side and the solution (and the scratch and the diagonal) must be distinct arrays");
     hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((Nx + 63) / 64, Ny), dim3(64), 0, g_stream, Nx, Nx, Ny, Nz, a, b, c,
                        (const double2 *)f_complex, t, (double2 *)phi_complex, 1.0, false);
     KERNEL_CHECK();

@@ -346,9 +346,10 @@ __global__ void __launch_bounds__(256) copy_real_kernel(DGrid g, FView phi, cons
 // Nxs columns per row are solved; f / phi have row length Nxs, the real coefficient arrays b / t row length ldb
 // (ldb = Nx > Nxs = Nx/2+1 when only the Hermitian half spectrum is solved). fscale multiplies the right-hand side
 // (1 for the reference semantics; the folded inverse-FFT normalisation on the real-transform path).
-__global__ void __launch_bounds__(64) tridiagonal_z_kernel(int Nxs, int ldb, int Ny, int Nz, const double *a, const double *b,
-                                                           const double *c, const double2 *f, double *t, double2 *phi,
-                                                           double fscale, bool apply_scale) {
+__global__ void __launch_bounds__(64) tridiagonal_z_kernel(int Nxs, int ldb, int Ny, int Nz, const double *__restrict__ a,
+                                                           const double *__restrict__ b, const double *__restrict__ c,
+                                                           const double2 *__restrict__ f, double *__restrict__ t,
+                                                           double2 *__restrict__ phi, double fscale, bool apply_scale) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (i >= Nxs || j >= Ny) return;
@@ -359,28 +360,59 @@ __global__ void __launch_bounds__(64) tridiagonal_z_kernel(int Nxs, int ldb, int
     if (apply_scale) { f1.x *= fscale; f1.y *= fscale; }
     double2 prev = make_double2(f1.x / beta, f1.y / beta);
     phi[q] = prev;
-    for (int k = 1; k < Nz; ++k) {
-        q += st; qb += stb;
-        double ck1 = c[k - 1], ak1 = a[k - 1], bk = b[qb];
-        double tk = ck1 / beta;
-        t[qb] = tk;
-        beta = bk - ak1 * tk;
-        double2 fk = f[q];
-        if (apply_scale) { fk.x *= fscale; fk.y *= fscale; }
-        bool dd = fabs(beta) > 10.0 * 2.220446049250313e-16;
-        double2 star = make_double2((fk.x - ak1 * prev.x) / beta, (fk.y - ak1 * prev.y) / beta);
-        double2 old = phi[q];
-        prev = dd ? star : old;
-        phi[q] = prev;
+    // The recurrences are serial in k, but every load is independent of them: with < 1 wave per SIMD (Nxs * Ny columns only)
+    // the kernel is pure memory latency unless the loads of several levels are in flight together => blocks of TB levels are
+    // fetched into registers first, then swept.
+    constexpr int TB = 8;
+    for (int k0 = 1; k0 < Nz; k0 += TB) {
+        double2 fb[TB], ob[TB];
+        double bb[TB], cb[TB], ab[TB];
+#pragma unroll
+        for (int n = 0; n < TB; ++n) {
+            const int k = k0 + n;
+            if (k < Nz) {
+                fb[n] = f[q + (long)(n + 1) * st]; ob[n] = phi[q + (long)(n + 1) * st]; bb[n] = b[qb + (long)(n + 1) * stb];
+                cb[n] = c[k - 1]; ab[n] = a[k - 1];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < TB; ++n) {
+            const int k = k0 + n;
+            if (k < Nz) {
+                q += st; qb += stb;
+                const double ck1 = cb[n], ak1 = ab[n], bk = bb[n];
+                const double tk = ck1 / beta;
+                t[qb] = tk;
+                beta = bk - ak1 * tk;
+                double2 fk = fb[n];
+                if (apply_scale) { fk.x *= fscale; fk.y *= fscale; }
+                const bool dd = fabs(beta) > 10.0 * 2.220446049250313e-16;
+                const double2 star = make_double2((fk.x - ak1 * prev.x) / beta, (fk.y - ak1 * prev.y) / beta);
+                prev = dd ? star : ob[n];
+                phi[q] = prev;
+            }
+        }
     }
-    for (int k = Nz - 2; k >= 0; --k) {
-        double tk1 = t[qb];          // t[k+1]
-        q -= st; qb -= stb;
-        double2 cur = phi[q];
-        cur.x -= tk1 * prev.x;
-        cur.y -= tk1 * prev.y;
-        phi[q] = cur;
-        prev = cur;
+    for (int k0 = Nz - 2; k0 >= 0; k0 -= TB) {
+        double tb[TB];
+        double2 pb[TB];
+#pragma unroll
+        for (int n = 0; n < TB; ++n) {
+            const int k = k0 - n;
+            if (k >= 0) { tb[n] = t[qb - (long)n * stb]; pb[n] = phi[q - (long)(n + 1) * st]; }     // t[k+1], phi[k]
+        }
+#pragma unroll
+        for (int n = 0; n < TB; ++n) {
+            const int k = k0 - n;
+            if (k >= 0) {
+                q -= st; qb -= stb;
+                double2 cur = pb[n];
+                cur.x -= tb[n] * prev.x;
+                cur.y -= tb[n] * prev.y;
+                phi[q] = cur;
+                prev = cur;
+            }
+        }
     }
 }
 
