@@ -18,7 +18,7 @@
  *  - All work is enqueued on ONE non-blocking HIP stream per device (the reference runs every kernel on the default
  *    stream in program order, kernel_launching.jl:335-336). Entry points are asynchronous w.r.t. the host unless
  *    stated otherwise; ocn_sync() is `sync_device!` (ext/OceananigansAMDGPUExt.jl:112-113).
- *  - location codes: 0 = Center, 1 = Face. topology codes: 0 = Periodic, 1 = Bounded.
+ *  - location codes: 0 = Center, 1 = Face. topology codes: 0 = Periodic, 1 = Bounded, 2 = FullyConnected (x), 3 = Flat.
  */
 #ifndef OCN_MI355X_H
 #define OCN_MI355X_H
@@ -32,6 +32,8 @@ extern "C" {
 #define OCN_PERIODIC 0
 #define OCN_BOUNDED 1
 #define OCN_CONNECTED 2     /* FullyConnected: halo owned by a neighbouring rank (distributed_grids.jl:339-346); x only */
+#define OCN_FLAT 3          /* Flat: size 1, halo 0, unit spacing and extent; differences 0, interpolations the identity
+                             * (Grids/grid_utils.jl, Operators/difference_operators.jl:30-49, Advection/flat_advective_fluxes.jl) */
 #define OCN_CENTER 0
 #define OCN_FACE 1
 

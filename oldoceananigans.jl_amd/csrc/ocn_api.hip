@@ -162,8 +162,15 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
     if (!grid || !N || !H || !topo || !L) return fail(OCN_EINVAL, "NULL argument");
     for (int d = 0; d < 3; ++d) {
         if (N[d] < 1) return fail(OCN_EINVAL, "size must be positive (dimension %d)", d);
+        if (topo[d] == OCN_FLAT) {
+            // Flat direction: one cell, no halo, unit spacing (validate_size / validate_halo of Grids/input_validation.jl)
+            if (N[d] != 1 || H[d] != 0) return fail(OCN_EINVAL, "a Flat direction has size 1 and halo 0 (dimension %d)", d);
+            const double spacing = d == 0 ? dx : (d == 1 ? dy : dz);
+            if (spacing != 1.0 || L[d] != 1.0 || (d == 2 && dzc)) return fail(OCN_EINVAL, "a Flat direction has unit spacing and extent (dimension %d)", d);
+            continue;
+        }
         if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(topo[d] == OCN_CONNECTED && d == 0))
-            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded and (x only) FullyConnected "
+            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) FullyConnected "
                                      "are accelerated", topo[d], d);
         // WENO(order=5) needs a halo of 3 (nonhydrostatic_model.jl:184, inflate_grid_halo_size) and N >= 3 so that
         // adapt_advection_order (Advection/adapt_advection_order.jl:90-96) keeps the scheme
@@ -637,6 +644,7 @@ struct ocn_poisson_s {
 // Solvers/poisson_eigenvalues.jl:8-23
 static void poisson_eigenvalues(int N, double L, int topo, std::vector<double> &lam) {
     lam.resize(N);
+    if (topo == OCN_FLAT) { for (double &x : lam) x = 0.0; return; }      // poisson_eigenvalues(N, L, dim, ::Flat) = zeros
     for (int i = 1; i <= N; ++i) {
         double arg = topo == OCN_PERIODIC ? ((double)(i - 1) * M_PI) / (double)N : ((double)(i - 1) * M_PI) / (double)(2 * N);
         double s = 2.0 * sin(arg) / (L / (double)N);
@@ -750,10 +758,12 @@ static int ensure_complex(ocn_poisson_s *s) {
         HIP_TRY(dev_alloc((void **)&s->buffer, s->n * sizeof(double2)));
         const int N[3] = {g.Nx, g.Ny, g.Nz};
         const int ndims = s->kind == 0 ? 3 : 2;
+        const int T[3] = {g.tx, g.ty, g.tz};
         for (int d = 0; d < ndims; ++d) {
+            if (T[d] == OCN_FLAT) continue;
             int shared = -1;
             for (int e = 0; e < d; ++e)
-                if (N[e] == N[d]) shared = e;
+                if (N[e] == N[d] && T[e] != OCN_FLAT) shared = e;
             if (shared >= 0) { s->plan_line[d] = s->plan_line[shared]; continue; }
             int nn[1] = {N[d]};
             hipfftResult r = hipfftPlanMany(&s->plan_line[d], 1, nn, nullptr, 1, N[d], nullptr, 1, N[d], HIPFFT_Z2Z, (int)(s->n / N[d]));
@@ -783,6 +793,7 @@ static int ensure_complex(ocn_poisson_s *s) {
 static int transform_dim(ocn_poisson_s *s, double2 *A, int d, bool forward) {
     const DGrid &g = s->grid->d;
     const int T[3] = {g.tx, g.ty, g.tz};
+    if (T[d] == OCN_FLAT) return OCN_OK;
     const int mode = T[d] == OCN_BOUNDED ? (forward ? 1 : 2) : 0;
     { int rc_ = plan_set_stream(s->plan_line[d]); if (rc_) return rc_; }
     const int dir = forward ? HIPFFT_FORWARD : HIPFFT_BACKWARD;
@@ -818,7 +829,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
     if (!solver || !grid) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = grid->d;
     for (int t : {g.tx, g.ty, g.tz})
-        if (t != OCN_PERIODIC && t != OCN_BOUNDED)
+        if (t != OCN_PERIODIC && t != OCN_BOUNDED && t != OCN_FLAT)
             return fail(OCN_ENOTSUP, "Poisson solvers need Periodic or Bounded directions (a FullyConnected x belongs to ocn_dist_poisson_create)");
     if (kind == -1) kind = (g.tz == OCN_BOUNDED) ? 1 : 0;   // see DESIGN.md: z-Bounded takes the tridiagonal path by default
     if (kind == 0 && !grid->z_regular) return fail(OCN_EINVAL, "FFTBasedPoissonSolver requires a regular grid");
@@ -828,7 +839,8 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
     ocn_poisson_s *s = new ocn_poisson_s();
     s->grid = grid; s->kind = kind;
     s->n = (size_t)g.Nx * g.Ny * g.Nz;
-    s->general = g.tx == OCN_BOUNDED || g.ty == OCN_BOUNDED || (kind == 0 && g.tz == OCN_BOUNDED);
+    s->general = g.tx == OCN_BOUNDED || g.ty == OCN_BOUNDED || (kind == 0 && g.tz == OCN_BOUNDED) ||
+                 g.tx == OCN_FLAT || g.ty == OCN_FLAT || g.tz == OCN_FLAT;      // Flat directions are not transformed
     int rc = OCN_OK;
 #define TRY_OR_FREE(expr)                                                                                  \
     do {                                                                                                   \

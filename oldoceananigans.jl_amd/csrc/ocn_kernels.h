@@ -18,6 +18,8 @@ template <int AQ> __device__ __forceinline__ double area_q(const DGrid &g, const
 // symmetric interpolation of a transport along D; CEN: ᶜ variant (stencil of face idx+1)
 template <int AQ, int D, bool CEN>
 __device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, int i, int j, int k) {
+    // interpolation along a Flat direction is the identity (flat_advective_fluxes.jl:35-50)
+    if ((D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == OCN_FLAT) return area_q<AQ>(g, f, i, j, k);
     const int idx = D == 0 ? i : (D == 1 ? j : k);
     const int o = CEN ? 1 : 0;
     double q[4];
@@ -47,6 +49,7 @@ __device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, b
 // DB (CB).
 template <int AQ, int DS, bool CS, int DB, bool CB>
 __device__ __forceinline__ double mom_flux(const DGrid &g, const FView &adv, const FView &psi, int i, int j, int k) {
+    if ((DB == 0 ? g.tx : (DB == 1 ? g.ty : g.tz)) == OCN_FLAT) return 0.0;     // fluxes along a Flat direction vanish (:13-27)
     double ut = sym_transport<AQ, DS, CS>(g, adv, i, j, k);
     double pr = biased_field<DB, CB>(g, psi, ut > 0, i, j, k);
     return ut * pr;
@@ -54,6 +57,7 @@ __device__ __forceinline__ double mom_flux(const DGrid &g, const FView &adv, con
 
 // advective_tracer_flux_{x,y,z} (:99-121): A * U[i,j,k] * cR
 template <int D> __device__ __forceinline__ double tracer_flux(const DGrid &g, const FView &vel, const FView &c, int i, int j, int k) {
+    if ((D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == OCN_FLAT) return 0.0;
     double ut = vel.at(i, j, k);
     double cr = biased_field<D, false>(g, c, ut > 0, i, j, k);
     double a = D == 0 ? g.ax[k - 1 + g.Hz] : (D == 1 ? g.ay[k - 1 + g.Hz] : g.az);
@@ -273,9 +277,10 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
     const int kk = k - 1 + g.Hz;
     const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
-    double dx = ax * u.at(i + 1, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
-    double dy = ay * v.at(i, j + 1, k) - ay * v.at(i, j, k);
-    double dz = az * w.at(i, j, k + 1) - az * w.at(i, j, k);
+    // δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49)
+    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(i + 1, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
+    double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, j + 1, k) - ay * v.at(i, j, k);
+    double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, k + 1) - az * w.at(i, j, k);
     double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
     double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
     const long q = (long)(i - 1) + sj * (j - 1) + sk * (k - 1);
@@ -291,9 +296,9 @@ __global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
     const double pc = p.at(i, j, k);
-    u.at(i, j, k) -= (pc - p.at(i - 1, j, k)) * g.rdx;            // ∂xᶠᶜᶜ = δx * Δx⁻¹
-    v.at(i, j, k) -= (pc - p.at(i, j - 1, k)) * g.rdy;
-    w.at(i, j, k) -= (pc - p.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz];
+    u.at(i, j, k) -= (g.tx == OCN_FLAT ? 0.0 : pc - p.at(i - 1, j, k)) * g.rdx;            // ∂xᶠᶜᶜ = δx * Δx⁻¹
+    v.at(i, j, k) -= (g.ty == OCN_FLAT ? 0.0 : pc - p.at(i, j - 1, k)) * g.rdy;
+    w.at(i, j, k) -= (g.tz == OCN_FLAT ? 0.0 : pc - p.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz];
 }
 
 __global__ void __launch_bounds__(256) divide_interior_kernel(DGrid g, FView p, double divisor) {
@@ -744,9 +749,9 @@ __global__ void __launch_bounds__(256) max_abs_div_kernel(DGrid g, FView u, FVie
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
         int i = 1 + q % g.Nx, j = 1 + (q / g.Nx) % g.Ny, k = 1 + q / ((long)g.Nx * g.Ny);
         const int kk = k - 1 + g.Hz;
-        double dx = g.ax[kk] * u.at(i + 1, j, k) - g.ax[kk] * u.at(i, j, k);
-        double dy = g.ay[kk] * v.at(i, j + 1, k) - g.ay[kk] * v.at(i, j, k);
-        double dz = g.az * w.at(i, j, k + 1) - g.az * w.at(i, j, k);
+        double dx = g.tx == OCN_FLAT ? 0.0 : g.ax[kk] * u.at(i + 1, j, k) - g.ax[kk] * u.at(i, j, k);
+        double dy = g.ty == OCN_FLAT ? 0.0 : g.ay[kk] * v.at(i, j + 1, k) - g.ay[kk] * v.at(i, j, k);
+        double dz = g.tz == OCN_FLAT ? 0.0 : g.az * w.at(i, j, k + 1) - g.az * w.at(i, j, k);
         double d = fabs(g.vinv_c[kk] * ((dx + dy) + dz));
         m = d > m ? d : m;
     }

@@ -35,8 +35,6 @@ class Face:
 
 def _topo_code(t):
     t = t if isinstance(t, type) else type(t)
-    if t is Flat:
-        raise NotImplementedError("Flat topologies are outside the accelerated hot path")
     return t.code
 
 
@@ -100,14 +98,27 @@ class RectilinearGrid:
     def __init__(self, architecture, size, x=None, y=None, z=None, extent=None,
                  topology=(Periodic, Periodic, Periodic), halo=(3, 3, 3)):
         self.architecture = architecture
-        self.Nx, self.Ny, self.Nz = (int(n) for n in size)
-        self.Hx, self.Hy, self.Hz = (int(h) for h in halo)
         self.topology = tuple(t if isinstance(t, type) else type(t) for t in topology)
+        flat = [t is Flat for t in self.topology]
+        # Flat directions (Grids/input_validation.jl): `size`, `halo` and `extent` list the non-Flat directions only (full
+        # 3-tuples with 1 / 0 entries are accepted too); a Flat direction has one cell, no halo, unit spacing
+        def expand(values, fill, what):
+            values = tuple(values) if isinstance(values, (tuple, list)) else (values,)
+            if len(values) == 3:
+                return tuple(fill if f else v for v, f in zip(values, flat))
+            if len(values) != 3 - sum(flat):
+                raise ValueError(f"{what} must have {3 - sum(flat)} (non-Flat directions) or 3 entries")
+            it = iter(values)
+            return tuple(fill if f else next(it) for f in flat)
+        self.Nx, self.Ny, self.Nz = (int(n) for n in expand(size, 1, "size"))
+        self.Hx, self.Hy, self.Hz = (int(h) for h in expand(halo, 0, "halo"))
         if extent is not None:
             if any(c is not None for c in (x, y, z)):
                 raise ValueError("Cannot specify both extent and x, y, z keyword arguments!")
             # default_horizontal_extent / default_vertical_extent (Grids/input_validation.jl:161-162)
-            x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
+            ext = expand(extent, 1.0, "extent")
+            x, y, z = (0.0, float(ext[0])), (0.0, float(ext[1])), (-float(ext[2]), 0.0)
+        x, y, z = ((0.0, 1.0) if f else c for c, f in zip((x, y, z), flat))
         if x is None or y is None or z is None:
             raise ValueError("Must supply extent or x, y, z keyword when topology is not Flat")
         for name, c in (("x", x), ("y", y)):

@@ -306,6 +306,7 @@ typedef double (*aq_fn)(const vel *, int, int, int);
 /* symmetric interpolation of an area-weighted transport along direction d. `center`: ᶜ variant (face index idx+1). */
 static inline double sym_transport(const vel *V, aq_fn q, int d, int center, int i, int j, int k) {
     const oro_grid *g = V->g;
+    if (g->topo[d] == ORO_FLAT) return q(V, i, j, k);     /* flat_advective_fluxes.jl:35-50: interpolation along a Flat direction = ψ[i, j, k] */
     int idx = (d == 0) ? i : (d == 1) ? j : k;
     int f = idx + (center ? 1 : 0);
     double Q[4];
@@ -329,6 +330,7 @@ static inline double biased_field(const oro_grid *g, const fld *c, int left, int
 
 #define FLUX(name, aq, dsym, csym, dbias, cbias, fieldmember)                                                  \
     static inline double name(const vel *V, const fld *psi, int i, int j, int k) {                             \
+        if (V->g->topo[dbias] == ORO_FLAT) return 0.0;   /* flat_advective_fluxes.jl:13-27 */                   \
         double ut = sym_transport(V, aq, dsym, csym, i, j, k);                                                 \
         double pr = biased_field(V->g, psi, ut > 0, dbias, cbias, i, j, k);                                    \
         return ut * pr;                                                                                        \
@@ -346,16 +348,19 @@ FLUX(flux_Ww, Az_q_ccf, 2, 1, 2, 1, w)  /* :87-93 */
 
 /* tracer fluxes :99-121: Ax * u[i,j,k] * cR (left-assoc) */
 static inline double flux_cx(const vel *V, const fld *c, int i, int j, int k) {
+    if (V->g->topo[0] == ORO_FLAT) return 0.0;
     double ut = AT(V->u, i, j, k);
     double cr = biased_field(V->g, c, ut > 0, 0, 0, i, j, k);
     return (DC(V->g, 1, j) * DC(V->g, 2, k)) * ut * cr;
 }
 static inline double flux_cy(const vel *V, const fld *c, int i, int j, int k) {
+    if (V->g->topo[1] == ORO_FLAT) return 0.0;
     double vt = AT(V->v, i, j, k);
     double cr = biased_field(V->g, c, vt > 0, 1, 0, i, j, k);
     return (DC(V->g, 0, i) * DC(V->g, 2, k)) * vt * cr;
 }
 static inline double flux_cz(const vel *V, const fld *c, int i, int j, int k) {
+    if (V->g->topo[2] == ORO_FLAT) return 0.0;
     double wt = AT(V->w, i, j, k);
     double cr = biased_field(V->g, c, wt > 0, 2, 0, i, j, k);
     return (DC(V->g, 0, i) * DC(V->g, 1, j)) * wt * cr;
@@ -500,9 +505,10 @@ void oro_compute_source_term(const oro_grid *g, const double *u, const double *v
         for (int j = 1; j <= Ny; ++j)
             for (int i = 1; i <= Nx; ++i) {
                 double Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
-                double dx = Ax_q_fcc(&V, i + 1, j, k) - Ax_q_fcc(&V, i, j, k);
-                double dy = Ay_q_cfc(&V, i, j + 1, k) - Ay_q_cfc(&V, i, j, k);
-                double dz = Az_q_ccf(&V, i, j, k + 1) - Az_q_ccf(&V, i, j, k);
+                /* δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49) */
+                double dx = g->topo[0] == ORO_FLAT ? 0.0 : Ax_q_fcc(&V, i + 1, j, k) - Ax_q_fcc(&V, i, j, k);
+                double dy = g->topo[1] == ORO_FLAT ? 0.0 : Ay_q_cfc(&V, i, j + 1, k) - Ay_q_cfc(&V, i, j, k);
+                double dz = g->topo[2] == ORO_FLAT ? 0.0 : Az_q_ccf(&V, i, j, k + 1) - Az_q_ccf(&V, i, j, k);
                 double div = Vinv * ((dx + dy) + dz);
                 /* `active * δ` with active = true; Fourier-tridiagonal: active * Δzᶜᶜᶜ * δ */
                 double val = weight_by_dz ? (1.0 * DC(g, 2, k)) * div : 1.0 * div;
@@ -517,9 +523,9 @@ void oro_make_pressure_correction(const oro_grid *g, double *u, double *v, doubl
     for (int k = 1; k <= g->N[2]; ++k)
         for (int j = 1; j <= g->N[1]; ++j)
             for (int i = 1; i <= g->N[0]; ++i) {
-                AT(U, i, j, k) -= (AT(P, i, j, k) - AT(P, i - 1, j, k)) * (1.0 / DF(g, 0, i));
-                AT(Vv, i, j, k) -= (AT(P, i, j, k) - AT(P, i, j - 1, k)) * (1.0 / DF(g, 1, j));
-                AT(W, i, j, k) -= (AT(P, i, j, k) - AT(P, i, j, k - 1)) * (1.0 / DF(g, 2, k));
+                AT(U, i, j, k) -= (g->topo[0] == ORO_FLAT ? 0.0 : AT(P, i, j, k) - AT(P, i - 1, j, k)) * (1.0 / DF(g, 0, i));
+                AT(Vv, i, j, k) -= (g->topo[1] == ORO_FLAT ? 0.0 : AT(P, i, j, k) - AT(P, i, j - 1, k)) * (1.0 / DF(g, 1, j));
+                AT(W, i, j, k) -= (g->topo[2] == ORO_FLAT ? 0.0 : AT(P, i, j, k) - AT(P, i, j, k - 1)) * (1.0 / DF(g, 2, k));
             }
 }
 
@@ -654,6 +660,7 @@ static void transform_dim(cplx *A, const int n[3], int d, int kind /*0 fft fwd,1
 
 /* Solvers/poisson_eigenvalues.jl:8-23 */
 void oro_poisson_eigenvalues(int N, double L, int topo, double *lam) {
+    if (topo == ORO_FLAT) { for (int i = 0; i < N; ++i) lam[i] = 0.0; return; }     /* poisson_eigenvalues.jl: Flat -> zeros */
     for (int i = 1; i <= N; ++i) {
         double arg = (topo == ORO_PERIODIC) ? ((double)(i - 1) * M_PI) / (double)N
                                             : ((double)(i - 1) * M_PI) / (double)(2 * N);

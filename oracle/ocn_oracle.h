@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-enum { ORO_PERIODIC = 0, ORO_BOUNDED = 1 };
+enum { ORO_PERIODIC = 0, ORO_BOUNDED = 1, ORO_FLAT = 3 };   /* Flat: N = 1, H = 0, Δ = 1 (Grids/grid_utils.jl); 2 is the product's FullyConnected */
 enum { ORO_CENTER = 0, ORO_FACE = 1 };
 
 typedef struct {

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-PERIODIC, BOUNDED = 0, 1
+PERIODIC, BOUNDED, FLAT = 0, 1, 3
 CENTER, FACE = 0, 1
 LOC = {"u": (FACE, CENTER, CENTER), "v": (CENTER, FACE, CENTER), "w": (CENTER, CENTER, FACE), "c": (CENTER,) * 3}
 
@@ -199,13 +199,17 @@ class Grid:
     def __init__(self, size, halo=(3, 3, 3), topology=(PERIODIC, PERIODIC, PERIODIC),
                  x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0)):
         self.N = tuple(int(n) for n in size)
-        self.H = tuple(int(h) for h in halo)
         self.topo = tuple(int(t) for t in topology)
+        # Flat directions: one cell, no halo, unit spacing and extent (Grids/grid_utils.jl, spacings_and_areas_and_volumes.jl:123)
+        assert all(self.N[d] == 1 for d in range(3) if self.topo[d] == FLAT), "a Flat direction has size 1"
+        self.H = tuple(0 if self.topo[d] == FLAT else int(h) for d, h in enumerate(halo))
         self.L = [0.0] * 3
         self.dc, self.df = [None] * 3, [None] * 3
         for d, coord in enumerate((x, y, z)):
             n = self.N[d] + 2 * self.H[d] + 1
-            if isinstance(coord, tuple) and len(coord) == 2 and np.isscalar(coord[0]):
+            if self.topo[d] == FLAT:
+                self.L[d], self.dc[d], self.df[d] = 1.0, np.ones(n), np.ones(n)
+            elif isinstance(coord, tuple) and len(coord) == 2 and np.isscalar(coord[0]):
                 delta, L = regular_spacing(coord, self.N[d])
                 self.L[d] = L
                 self.dc[d] = np.full(n, delta)

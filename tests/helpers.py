@@ -32,7 +32,9 @@ def smooth_state(grid_nodes, seed=1234):
             # the z-dependence keeps the state generic: a tracer that is EXACTLY uniform along a direction (with a large offset)
             # makes the WENO smoothness indicators in that direction pure round-off, and the oracle itself then moves by
             # 1e-13 relative under sub-ulp perturbations of u (measured) -- conditioning of the scheme, not of an implementation
-            out[name] = 35 + np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.2 * np.cos(2 * np.pi * z)
+            # (hence one term per direction: on grids with Flat directions the product term alone can vanish)
+            out[name] = (35 + np.sin(2 * np.pi * x) * np.cos(2 * np.pi * y) + 0.2 * np.cos(2 * np.pi * z) +
+                         0.3 * np.sin(2 * np.pi * y) + 0.25 * np.cos(2 * np.pi * x))
     return out
 
 
@@ -42,7 +44,7 @@ def rel_err(a, b):
     return np.max(np.abs(a - b)) / (scale if scale > 0 else 1.0)
 
 
-ORACLE_TOPO = {"Periodic": 0, "Bounded": 1}
+ORACLE_TOPO = {"Periodic": 0, "Bounded": 1, "Flat": 3}
 
 
 def make_pair(ocn, O, arch, size, topology=("Periodic", "Periodic", "Periodic"), z=None, ntracers=2):

@@ -307,3 +307,37 @@ def test_fast_reciprocals_are_correctly_rounded(ocn, arch):
     assert bad.value == 0, bad.value
     _lib.check(L.ocn_debug_rcp64_check(1 << 24, -60, 0, 99, C.byref(bad)))       # below the range in use: still exact
     assert bad.value == 0, bad.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Flat directions (Grids/grid_utils.jl, Operators/difference_operators.jl:30-49, Advection/flat_advective_fluxes.jl): two- and
+# one-dimensional models, the set-up of the reference's own WENO convergence test
+# (validation/convergence_tests/src/OneDimensionalGaussianAdvectionDiffusion.jl:14-40 uses (Nx, 1, 1) Flat grids)
+# ---------------------------------------------------------------------------------------------------------------------
+FLAT_CASES = [(("Periodic", "Flat", "Bounded"), (16, 1, 12), True), (("Periodic", "Flat", "Periodic"), (16, 1, 16), False),
+              (("Flat", "Periodic", "Bounded"), (1, 12, 10), False), (("Bounded", "Periodic", "Flat"), (12, 16, 1), False),
+              (("Periodic", "Flat", "Flat"), (32, 1, 1), False), (("Flat", "Flat", "Bounded"), (1, 1, 16), True)]
+
+
+@pytest.mark.parametrize("topology,size,stretched", FLAT_CASES)
+def test_flat_topologies_match_oracle(ocn, oracle, arch, topology, size, stretched):
+    z = tanh_faces(size[2]) if stretched else None
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=z)
+    assert m_gpu.fields()["v"].shape == g_cpu.parent_size((0, 1, 0))
+    # tendencies on identical random inputs: bit-identical
+    set_both(ocn, m_gpu, m_cpu, seed=3, enforce_incompressibility=False)
+    ocn.update_state(m_gpu, True)
+    m_cpu.update_state(True)
+    for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+        assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), n
+    # 10 RK3 steps from a smooth state
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.1 * min(d for d, t in zip((g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))), topology) if t != "Flat") / 0.6
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    H = [0 if t == "Flat" else 3 for t in topology]
+    core = tuple(slice(h, -h if h else None) for h in H)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
+    assert ocn.max_abs_divergence(m_gpu) < 5e-8

@@ -364,3 +364,92 @@ def test_advection_order_and_directional_symmetry(oracle):
     for ax in (1, 2):
         assert np.allclose(e[ax], e[0], rtol=1e-9), (e[0], e[ax])
     assert np.log2(e[0][0] / e[0][1]) > 3.5, e[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Flat directions (Grids/grid_utils.jl; Operators/difference_operators.jl:30-49; Advection/flat_advective_fluxes.jl:9-50)
+# ---------------------------------------------------------------------------------------------------------------------
+FLAT = 3
+
+
+def test_flat_one_dimensional_advection_as_the_reference_runs_it(oracle):
+    """validation/convergence_tests/src/OneDimensionalGaussianAdvectionDiffusion.jl:14-40 builds (Nx, 1, 1) grids with Flat y, z:
+    same errors as the x-oriented run on a 3-D periodic grid (the Flat shortcuts only remove zero contributions), high-order
+    convergence, and the three orientations agree (one_dimensional_advection_schemes.jl:108-118)"""
+    def run(n, axis, flat):
+        size, topo = [4, 4, 4], [0, 0, 0]
+        if flat:
+            size, topo = [1, 1, 1], [FLAT, FLAT, FLAT]
+            topo[axis] = 0
+        size[axis] = n
+        ext = [(0.0, 4.0 / n)] * 3
+        ext[axis] = (0.0, 1.0)
+        g = oracle.Grid(tuple(size), topology=tuple(topo), x=ext[0], y=ext[1], z=ext[2])
+        h = 1.0 / n
+        s = (np.arange(n) + 0.5) * h
+        shp = [1, 1, 1]
+        shp[axis] = n
+        c0 = np.exp(-((s - 0.5) ** 2) / 0.01).reshape(shp) * np.ones(size)
+        m = oracle.Model(g, 1)
+        vel = {"u": 0.0, "v": 0.0, "w": 0.0}
+        vel["uvw"[axis]] = 1.0
+        m.set(u=vel["u"] + 0 * c0, v=vel["v"] + 0 * c0, w=vel["w"] + 0 * c0, c0=c0)
+        dt, nsteps = 0.01 * h, 10
+        for _ in range(nsteps):
+            m.time_step(dt)
+        exact = np.exp(-((s - 0.5 - dt * nsteps) ** 2) / 0.01).reshape(shp) * np.ones(size)
+        return np.abs(g.interior_cells(m.field("c0")) - exact).max()
+    e3 = [run(n, 0, False) for n in (32, 64)]
+    for axis in range(3):
+        ef = [run(n, axis, True) for n in (32, 64)]
+        assert np.allclose(ef, e3, rtol=1e-9), (axis, ef, e3)
+    assert np.log2(e3[0] / e3[1]) > 3.5
+
+
+@pytest.mark.parametrize("flat_dim", [0, 1, 2])
+def test_flat_direction_equals_uniform_periodic_direction(oracle, flat_dim):
+    """a two-dimensional model (one Flat direction) reproduces the three-dimensional periodic model whose fields are uniform
+    along that direction: identical bits for every field whose stencils never interpolate along it, round-off for the others"""
+    N = [12, 10, 8]
+
+    def init(name, x, y, z):
+        tp = 2 * np.pi
+        c = [x, y, z]
+        a, b = [c[d] for d in range(3) if d != flat_dim]
+        f = {"u": 0.5 * np.sin(tp * a) * np.cos(tp * b) + 0.1, "v": 0.3 * np.cos(tp * a) * np.sin(tp * b) + 0.2,
+             "w": -0.4 * np.cos(tp * a) * np.cos(tp * b) + 0.05, "c0": np.exp(-((a - 0.5) ** 2 + (b - 0.5) ** 2) / 0.02),
+             "c1": 1.0 + 0.3 * np.sin(tp * a) * np.sin(tp * b)}
+        return f[name]
+
+    def run(flat):
+        size, topo = list(N), [0, 0, 0]
+        size[flat_dim] = 1 if flat else 4
+        if flat:
+            topo[flat_dim] = FLAT
+        g = oracle.Grid(tuple(size), topology=tuple(topo), x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0))
+        m = oracle.Model(g, 2)
+        vals = {}
+        for n in m.names():
+            loc = m.loc(n)
+            ax = []
+            for d in range(3):
+                a = (np.arange(size[d]) + (0.0 if loc[d] else 0.5)) / size[d]
+                shp = [1, 1, 1]
+                shp[d] = size[d]
+                ax.append(a.reshape(shp))
+            vals[n] = init(n, *ax) + np.zeros(size)
+        m.set(**vals)
+        for _ in range(5):
+            m.time_step(0.1 / 12 / 0.6)
+        take = [slice(None)] * 3
+        take[flat_dim] = 0
+        return {n: g.interior(m.field(n), m.loc(n) if n != "p" else (0, 0, 0))[tuple(take)].copy() for n in m.names() + ["p"]}, \
+            m.max_abs_divergence()
+    (a, da), (b, db) = run(True), run(False)
+    assert da < 1e-13 and db < 1e-13
+    for n in a:
+        assert rel_err_(a[n], b[n]) < 1e-14, (n, rel_err_(a[n], b[n]))
+
+
+def rel_err_(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
