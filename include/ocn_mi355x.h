@@ -121,6 +121,15 @@ int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fie
                                        const int *range, double *const *next, const double *const *Gm, double dt,
                                        double gamma, double zeta, int has_zeta);
 
+/* closure = ScalarDiffusivity(ν, κ): isotropic, constant, explicit (SURVEY.md 8f.1 -- the first "next" row).
+ * ∂ⱼ_τ₁ⱼ / ∂ⱼ_τ₂ⱼ / ∂ⱼ_τ₃ⱼ / ∇_dot_qᶜ (TurbulenceClosures/closure_kernel_operators.jl:22-48) with viscous_flux_* = -2 ν Σᵢⱼ and
+ * diffusive_flux_* = -κ ∂c (abstract_scalar_diffusivity_closure.jl:194-242). ADDS the closure term to tendencies that already
+ * hold the advective part, in the order of nonhydrostatic_tendency_kernel_functions.jl:91-100: G = (G - ∂ⱼτᵢⱼ) + 0.
+ * kappa: one value per tracer. range as in ocn_compute_tendencies. */
+int ocn_compute_closure_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                                   const double *const *tracers, int ntracers, double nu, const double *kappa,
+                                   double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range);
+
 /* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
 /* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage
  * method `U += Δt γ¹ G¹`. */
@@ -219,6 +228,8 @@ int ocn_model_get_option(ocn_model_t model, const char *key, int *value);
 /* boundary_conditions = (name = FieldBoundaryConditions(side = BoundaryCondition(kind, value)),) of the model
  * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0"..; side 0..5 = west .. top. OCN_EINVAL mirrors
  * the reference's validation: Bounded sides only; Flux/Value/Gradient on Center-located, Open on Face-located fields */
+/* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) of the model constructor; all zeros / NULL: closure = nothing */
+int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
 /* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
  * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */

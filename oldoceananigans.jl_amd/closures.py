@@ -1,0 +1,34 @@
+"""Turbulence closures on the accelerated path: ScalarDiffusivity with constant isotropic ν, κ and explicit time
+discretisation (reference: TurbulenceClosures/turbulence_closure_implementations/scalar_diffusivity.jl)."""
+import ctypes as C
+
+import numpy as np
+
+
+class ScalarDiffusivity:
+    """ScalarDiffusivity(ν = 0, κ = 0): κ a number (all tracers) or a dict tracer-name -> number (scalar_diffusivity.jl:21-118)."""
+
+    def __init__(self, ν=0.0, κ=0.0, nu=None, kappa=None):
+        ν = ν if nu is None else nu
+        κ = κ if kappa is None else kappa
+        if callable(ν) or callable(κ) or (isinstance(κ, dict) and any(callable(x) for x in κ.values())):
+            raise NotImplementedError("only constant (Number) viscosity / diffusivity is on the accelerated path")
+        self.ν, self.κ = float(ν), κ
+        if self.ν < 0:
+            raise ValueError("viscosity must be non-negative")
+
+    def kappa_array(self, tracer_names):
+        if isinstance(self.κ, dict):
+            missing = [n for n in tracer_names if n not in self.κ]
+            if missing:
+                raise ValueError(f"κ is missing tracers {missing}")     # with_tracers(), scalar_diffusivity.jl:151-160
+            vals = [float(self.κ[n]) for n in tracer_names]
+        else:
+            vals = [float(self.κ)] * len(tracer_names)
+        if any(v < 0 for v in vals):
+            raise ValueError("diffusivity must be non-negative")
+        arr = np.ascontiguousarray(vals if vals else [0.0], dtype=np.float64)
+        return arr, arr.ctypes.data_as(C.POINTER(C.c_double))
+
+    def __repr__(self):
+        return f"ScalarDiffusivity{{ExplicitTimeDiscretization}}(ν={self.ν}, κ={self.κ})"

@@ -495,6 +495,44 @@ extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const do
     return OCN_OK;
 }
 
+static int closure_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr, int ntr,
+                              double nu, const double *kappa, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range) {
+    const FView vu = make_view(g, u, LOC_U), vv = make_view(g, v, LOC_V), vw = make_view(g, w, LOC_W);
+    auto launch = [&](int F, const double *c, double *G, const int loc[3], double coef) -> int {
+        if (coef == 0.0) return OCN_OK;
+        Range6 r;
+        int rc = check_range(g, range, &r, loc, F != F_C);
+        if (rc) return rc;
+        const int nx = r.i1 - r.i0 + 1, ny = r.j1 - r.j0 + 1, nz = r.k1 - r.k0 + 1;
+        if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
+        const FView vc = make_view(g, c ? c : u, LOC_C), vG = make_view(g, G, loc);
+        const dim3 grd = grid3(nx, ny, nz, BLK);
+        if (F == F_U) hipLaunchKernelGGL(closure_tendency_kernel<F_U>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
+        if (F == F_V) hipLaunchKernelGGL(closure_tendency_kernel<F_V>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
+        if (F == F_W) hipLaunchKernelGGL(closure_tendency_kernel<F_W>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
+        if (F == F_C) hipLaunchKernelGGL(closure_tendency_kernel<F_C>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
+        return OCN_OK;
+    };
+    int rc;
+    if ((rc = launch(F_U, nullptr, Gu, LOC_U, nu)) || (rc = launch(F_V, nullptr, Gv, LOC_V, nu)) || (rc = launch(F_W, nullptr, Gw, LOC_W, nu)))
+        return rc;
+    for (int t = 0; t < ntr; ++t)
+        if ((rc = launch(F_C, tr[t], Gc[t], LOC_C, kappa ? kappa[t] : 0.0))) return rc;
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_closure_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                                              const double *const *tracers, int ntracers, double nu, const double *kappa,
+                                              double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
+        (ntracers > 0 && (!tracers || !Gc || !kappa)))
+        return fail(OCN_EINVAL, "invalid argument");
+    if (nu < 0) return fail(OCN_EINVAL, "viscosity must be non-negative");
+    return closure_tendencies(grid->d, u, v, w, tracers, ntracers, nu, kappa, Gu, Gv, Gw, Gc, range);
+}
+
 extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fields, int ntracers, double *const *Gn,
                                                   const int *range, double *const *next, const double *const *Gm, double dt,
                                                   double gamma, double zeta, int has_zeta) {
@@ -1381,6 +1419,8 @@ struct ocn_model_s {
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
     bool any_bc = false, any_flux_bc = false;
+    bool has_closure = false;               // closure = ScalarDiffusivity(ν, κ)
+    double nu = 0.0, kappa[OCN_MAX_FIELDS] = {};
     double *p;
     ocn_poisson_t solver;
     double *blockmax;
@@ -1498,7 +1538,8 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
 }
 
 static bool can_fuse_substep(const ocn_model_s *m) {
-    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
+    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure &&
+           fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
 
 extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) {
@@ -1531,6 +1572,9 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl, sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
+        if (!rc && m->has_closure)
+            rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1], m->Gn[2],
+                                    m->Gn + 3, nullptr);
         // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)
         if (m->any_flux_bc)
             for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
@@ -1557,6 +1601,19 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
     if (rc) return rc;
     double dtp = std::fmax(2.220446049250313e-16, dt);
     return divide_interior(g, m->p, dtp);
+}
+
+extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kappa) {
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    if (nu < 0) return fail(OCN_EINVAL, "viscosity must be non-negative");
+    m->nu = nu;
+    m->has_closure = nu != 0.0;
+    for (int t = 0; t < m->ntr; ++t) {
+        m->kappa[t] = kappa ? kappa[t] : 0.0;
+        if (m->kappa[t] < 0) return fail(OCN_EINVAL, "diffusivity must be non-negative");
+        if (m->kappa[t] != 0.0) m->has_closure = true;
+    }
+    return OCN_OK;
 }
 
 extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name, int side, int kind, double value) {

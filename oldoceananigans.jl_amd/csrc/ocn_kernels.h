@@ -101,6 +101,71 @@ __global__ void __launch_bounds__(256) tendency_kernel(DGrid g, FView u, FView v
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// ScalarDiffusivity(ν, κ): isotropic, constant, explicit closure (TurbulenceClosures/closure_kernel_operators.jl:
+// 22-48, abstract_scalar_diffusivity_closure.jl:194-242, velocity_tracer_gradients.jl:5-42). viscous_flux_* = -2 ν Σᵢⱼ,
+// diffusive_flux_* = -κ ∂c, ∂ = δ * (1/Δ); differences along a Flat direction vanish. The kernel ADDS the closure term to a
+// tendency that already holds the advective part: G = (G - ∂ⱼτᵢⱼ) + 0.0 -- the order of the terms in
+// nonhydrostatic_tendency_kernel_functions.jl:91-100 -- so it composes with the fused advection kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ClosureCtx {
+    const DGrid &g;
+    const FView &u, &v, &w;
+    double nu;
+    bool fx, fy, fz;
+    __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
+    // ∂ at Center-in-d (f[+1] - f[0]) and at Face-in-d (f[0] - f[-1])
+    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i + 1, j, k) - f.at(i, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j + 1, k) - f.at(i, j, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k + 1) - f.at(i, j, k)) * (1.0 / dzc(k)); }
+    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i, j, k) - f.at(i - 1, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j, k) - f.at(i, j - 1, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k) - f.at(i, j, k - 1)) * (1.0 / dzf(k)); }
+    __device__ __forceinline__ double S11(int i, int j, int k) const { return ddx_c(u, i, j, k); }
+    __device__ __forceinline__ double S22(int i, int j, int k) const { return ddy_c(v, i, j, k); }
+    __device__ __forceinline__ double S33(int i, int j, int k) const { return ddz_c(w, i, j, k); }
+    __device__ __forceinline__ double S12(int i, int j, int k) const { return 0.5 * (ddy_f(u, i, j, k) + ddx_f(v, i, j, k)); }
+    __device__ __forceinline__ double S13(int i, int j, int k) const { return 0.5 * (ddz_f(u, i, j, k) + ddx_f(w, i, j, k)); }
+    __device__ __forceinline__ double S23(int i, int j, int k) const { return 0.5 * (ddz_f(v, i, j, k) + ddy_f(w, i, j, k)); }
+    __device__ __forceinline__ double vf(double S) const { return -(2 * (nu * S)); }
+};
+
+template <int F>
+__global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, double coef, Range6 r) {
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT};
+    const double dx_ = g.dx, dy_ = g.dy;
+    double dx, dy, dz, vinv;
+    if (F == F_U) {            // ∂ⱼ_τ₁ⱼ at fcc: Ax_qᶜᶜᶜ, Ay_qᶠᶠᶜ, Az_qᶠᶜᶠ
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf(X.S11(i, j, k)) - (dy_ * X.dzc(k)) * X.vf(X.S11(i - 1, j, k));
+        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf(X.S12(i, j + 1, k)) - (dx_ * X.dzc(k)) * X.vf(X.S12(i, j, k));
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S13(i, j, k + 1)) - (dx_ * dy_) * X.vf(X.S13(i, j, k));
+    } else if (F == F_V) {     // ∂ⱼ_τ₂ⱼ at cfc: Ax_qᶠᶠᶜ, Ay_qᶜᶜᶜ, Az_qᶜᶠᶠ
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf(X.S12(i + 1, j, k)) - (dy_ * X.dzc(k)) * X.vf(X.S12(i, j, k));
+        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf(X.S22(i, j, k)) - (dx_ * X.dzc(k)) * X.vf(X.S22(i, j - 1, k));
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S23(i, j, k + 1)) - (dx_ * dy_) * X.vf(X.S23(i, j, k));
+    } else if (F == F_W) {     // ∂ⱼ_τ₃ⱼ at ccf: Ax_qᶠᶜᶠ, Ay_qᶜᶠᶠ, Az_qᶜᶜᶜ
+        vinv = g.vinv_f[k - 1 + g.Hz];
+        dx = X.fx ? 0.0 : (dy_ * X.dzf(k)) * X.vf(X.S13(i + 1, j, k)) - (dy_ * X.dzf(k)) * X.vf(X.S13(i, j, k));
+        dy = X.fy ? 0.0 : (dx_ * X.dzf(k)) * X.vf(X.S23(i, j + 1, k)) - (dx_ * X.dzf(k)) * X.vf(X.S23(i, j, k));
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S33(i, j, k)) - (dx_ * dy_) * X.vf(X.S33(i, j, k - 1));
+    } else {                   // ∇_dot_qᶜ at ccc: Ax_qᶠᶜᶜ, Ay_qᶜᶠᶜ, Az_qᶜᶜᶠ of -(κ ∂c)
+        vinv = g.vinv_c[k - 1 + g.Hz];
+        const double ax = dy_ * X.dzc(k), ay = dx_ * X.dzc(k), az = dx_ * dy_;
+        dx = X.fx ? 0.0 : ax * -(coef * X.ddx_f(c, i + 1, j, k)) - ax * -(coef * X.ddx_f(c, i, j, k));
+        dy = X.fy ? 0.0 : ay * -(coef * X.ddy_f(c, i, j + 1, k)) - ay * -(coef * X.ddy_f(c, i, j, k));
+        dz = X.fz ? 0.0 : az * -(coef * X.ddz_f(c, i, j, k + 1)) - az * -(coef * X.ddz_f(c, i, j, k));
+    }
+    const double div = vinv * ((dx + dy) + dz);
+    G.at(i, j, k) = (G.at(i, j, k) - div) + 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // halo fills (src/BoundaryConditions). One launch handles up to OCN_MAX_FIELDS fields of identical parent shape.
 // ---------------------------------------------------------------------------------------------------------------------
 struct FieldList {

@@ -241,7 +241,7 @@ class DeviceBackend:
         g = self.grid.local
         no_flux = not any(bc.classification == "Flux" and bc.condition != 0.0
                           for fb in getattr(self, "bcs", {}).values() for bc in fb.sides.values())
-        return no_flux and g.topology[1] is not Bounded and self.ntracers <= 3
+        return no_flux and getattr(self, "closure", None) is None and g.topology[1] is not Bounded and self.ntracers <= 3
 
     def swap_prognostic(self):
         """after a fused evaluation: the updated fields become the live ones (list contents swap, Field objects stay)"""
@@ -265,6 +265,8 @@ class DeviceBackend:
         if ev:
             ev[1].record()
             self.events.append(ev)
+        if getattr(self, "closure", None) is not None:
+            kernels.compute_closure_tendencies(self.grid.local, self.U, self.Gn, self.closure, self.tracer_names, kernel_parameters=rng)
 
     def profile_read(self):
         """(total ms of the event-timed tendency launches, number of tendency EVALUATIONS) since the last read"""
@@ -321,7 +323,7 @@ class DistributedNonhydrostaticModel:
     """NonhydrostaticModel on a Distributed architecture (x-slabs): WENO(order=5), RK3, DistributedFFTBasedPoissonSolver."""
 
     def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None,
-                 boundary_conditions=None):
+                 boundary_conditions=None, closure=None):
         if advection is not None and not isinstance(advection, WENO):
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
         self.grid, self.ctx = grid, grid.ctx
@@ -330,6 +332,8 @@ class DistributedNonhydrostaticModel:
         self.time, self.iteration, self.stage = 0.0, 0, 1
         self.last_Δt = self.last_stage_Δt = float("inf")
         self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
+        if closure is not None:
+            self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
         if boundary_conditions:
             names = ["u", "v", "w"] + list(self.tracer_names)
             self.backend.set_boundary_conditions({names.index(n): fb for n, fb in boundary_conditions.items()})

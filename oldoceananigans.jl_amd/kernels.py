@@ -41,6 +41,15 @@ def compute_tendencies_and_substep(grid, fields, Gn, next_fields, Gm, Î”t, Î³, Î
         _ptr_array(Gm), float(Î”t), float(Î³), 0.0 if Î¶ is None else float(Î¶), 0 if Î¶ is None else 1))
 
 
+def compute_closure_tendencies(grid, fields, Gn, closure, tracer_names, kernel_parameters=None):
+    """adds the ScalarDiffusivity terms (-âˆ‚â±¼Ï„áµ¢â±¼, -âˆ‡Â·q) to tendencies that hold the advective part; fields = u, v, w, tracers..."""
+    karr, kp = closure.kappa_array(tracer_names)
+    tr, gc = fields[3:], Gn[3:]
+    _lib.check(_lib.lib().ocn_compute_closure_tendencies(
+        grid.handle, fields[0].data, fields[1].data, fields[2].data, _ptr_array(tr) if tr else None, len(tr), closure.Î½, kp,
+        Gn[0].data, Gn[1].data, Gn[2].data, _ptr_array(gc) if gc else None, _range(kernel_parameters)))
+
+
 def rk3_substep(grid, fields, Gn, Gm, Î”t, Î³, Î¶):
     """rk3_substep_field! over a tuple of fields (Î¶ = None -> first stage)"""
     _lib.check(_lib.lib().ocn_rk3_substep(grid.handle, _ptr_array(fields), _ptr_array(Gn), _ptr_array(Gm),

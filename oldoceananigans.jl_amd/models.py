@@ -46,9 +46,13 @@ class NonhydrostaticModel:
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
         if timestepper not in ("RungeKutta3", ":RungeKutta3"):
             raise NotImplementedError("only timestepper = :RungeKutta3 is on the accelerated hot path")
-        for name, val in (("buoyancy", buoyancy), ("coriolis", coriolis), ("closure", closure), ("forcing", forcing)):
+        for name, val in (("buoyancy", buoyancy), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the accelerated hot path (SURVEY.md 8f)")
+        from .closures import ScalarDiffusivity
+        if closure is not None and not isinstance(closure, ScalarDiffusivity):
+            raise NotImplementedError("only closure = nothing | ScalarDiffusivity(ν, κ) is on the accelerated path (SURVEY.md 8f)")
+        self.closure = closure
         self.grid, self.advection = grid, advection
         self.tracer_names = tuple(str(t) for t in (tracers if isinstance(tracers, (tuple, list)) else (tracers,)))
         h = C.c_void_p()
@@ -61,6 +65,9 @@ class NonhydrostaticModel:
         self.tracers = T(*[self._field("c%d" % n) for n in range(len(self.tracer_names))])
         P = namedtuple("Pressures", "pNHS")
         self.pressures = P(self._field("p"))
+        if closure is not None:
+            self._kappa, kp = closure.kappa_array(self.tracer_names)
+            _lib.check(_lib.lib().ocn_model_set_closure(self.handle, closure.ν, kp))
         # boundary_conditions = (u = FieldBoundaryConditions(top = FluxBoundaryCondition(Q)), ...) (nonhydrostatic_model.jl:
         # 163-190): constant Flux / Value / Gradient / Open conditions on Bounded sides
         self.boundary_conditions = dict(boundary_conditions or {})

@@ -466,6 +466,86 @@ void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const d
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * ScalarDiffusivity(ν, κ) -- isotropic, constant, explicit
+ * TurbulenceClosures/closure_kernel_operators.jl:22-48 (flux divergences), abstract_scalar_diffusivity_closure.jl:194-242
+ * (viscous_flux_* = -2 ν Σᵢⱼ, diffusive_flux_* = -κ ∂c), velocity_tracer_gradients.jl:5-42 (strain rates),
+ * Operators/derivative_operators.jl:20-26 (∂ = δ * Δ⁻¹, Δ⁻¹ = 1/Δ). Differences along a Flat direction are zero.
+ * Added to a tendency that already holds the advective part: G = (G - ∂ⱼτᵢⱼ) + 0.0, the order of the terms in
+ * nonhydrostatic_tendency_kernel_functions.jl:91-100.
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { const oro_grid *g; fld u, v, w; double nu; } visc;
+#define FLATD(g, d) ((g)->topo[d] == ORO_FLAT)
+/* ∂ along d of a field: (f[idx] - f[idx-1]) at Face-in-d results, (f[idx+1] - f[idx]) at Center-in-d results */
+static inline double ddx_c(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 0) ? 0.0 : (AT(*f, i + 1, j, k) - AT(*f, i, j, k)) * (1.0 / DC(g, 0, i)); }
+static inline double ddy_c(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 1) ? 0.0 : (AT(*f, i, j + 1, k) - AT(*f, i, j, k)) * (1.0 / DC(g, 1, j)); }
+static inline double ddz_c(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 2) ? 0.0 : (AT(*f, i, j, k + 1) - AT(*f, i, j, k)) * (1.0 / DC(g, 2, k)); }
+static inline double ddx_f(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 0) ? 0.0 : (AT(*f, i, j, k) - AT(*f, i - 1, j, k)) * (1.0 / DF(g, 0, i)); }
+static inline double ddy_f(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 1) ? 0.0 : (AT(*f, i, j, k) - AT(*f, i, j - 1, k)) * (1.0 / DF(g, 1, j)); }
+static inline double ddz_f(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 2) ? 0.0 : (AT(*f, i, j, k) - AT(*f, i, j, k - 1)) * (1.0 / DF(g, 2, k)); }
+/* strain rates (velocity_tracer_gradients.jl:25-42) */
+static inline double S11(const visc *V, int i, int j, int k) { return ddx_c(V->g, &V->u, i, j, k); }
+static inline double S22(const visc *V, int i, int j, int k) { return ddy_c(V->g, &V->v, i, j, k); }
+static inline double S33(const visc *V, int i, int j, int k) { return ddz_c(V->g, &V->w, i, j, k); }
+static inline double S12(const visc *V, int i, int j, int k) { return 0.5 * (ddy_f(V->g, &V->u, i, j, k) + ddx_f(V->g, &V->v, i, j, k)); }   /* ffc */
+static inline double S13(const visc *V, int i, int j, int k) { return 0.5 * (ddz_f(V->g, &V->u, i, j, k) + ddx_f(V->g, &V->w, i, j, k)); }   /* fcf */
+static inline double S23(const visc *V, int i, int j, int k) { return 0.5 * (ddz_f(V->g, &V->v, i, j, k) + ddy_f(V->g, &V->w, i, j, k)); }   /* cff */
+/* A * viscous_flux: Ax_qᶜᶜᶜ(viscous_flux_ux) etc.; areas Ax = Δy Δz, Ay = Δx Δz, Az = Δx Δy at the flux location */
+#define VF(S) (-(2 * (V->nu * (S))))
+static inline double AxFux(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DC(V->g, 2, k)) * VF(S11(V, i, j, k)); }   /* ccc */
+static inline double AyFuy(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 2, k)) * VF(S12(V, i, j, k)); }   /* ffc */
+static inline double AzFuz(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 1, j)) * VF(S13(V, i, j, k)); }   /* fcf */
+static inline double AxFvx(const visc *V, int i, int j, int k) { return (DF(V->g, 1, j) * DC(V->g, 2, k)) * VF(S12(V, i, j, k)); }   /* ffc */
+static inline double AyFvy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 2, k)) * VF(S22(V, i, j, k)); }   /* ccc */
+static inline double AzFvz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 1, j)) * VF(S23(V, i, j, k)); }   /* cff */
+static inline double AxFwx(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DF(V->g, 2, k)) * VF(S13(V, i, j, k)); }   /* fcf */
+static inline double AyFwy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 2, k)) * VF(S23(V, i, j, k)); }   /* cff */
+static inline double AzFwz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 1, j)) * VF(S33(V, i, j, k)); }   /* ccc */
+#undef VF
+
+/* which: 0 u, 1 v, 2 w (coef = ν), 3 tracer c (coef = κ) */
+void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                              double coef, double *Gp, const int *range) {
+    static const int *LOCS[4] = {LOC_U, LOC_V, LOC_W, LOC_C};
+    int r[6];
+    if (range) memcpy(r, range, sizeof r); else default_range(g, LOCS[which], which < 3, r);
+    visc Vs = {g, mkfld(g, u, LOC_U), mkfld(g, v, LOC_V), mkfld(g, w, LOC_W), coef};
+    const visc *V = &Vs;
+    fld C = mkfld(g, c ? c : u, LOC_C);
+    fld G = mkfld(g, Gp, LOCS[which]);
+    const int fx = FLATD(g, 0), fy = FLATD(g, 1), fz = FLATD(g, 2);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                double dx, dy, dz, Vinv;
+                if (which == 0) {            /* ∂ⱼ_τ₁ⱼ at fcc */
+                    Vinv = 1.0 / ((DF(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
+                    dx = fx ? 0.0 : AxFux(V, i, j, k) - AxFux(V, i - 1, j, k);
+                    dy = fy ? 0.0 : AyFuy(V, i, j + 1, k) - AyFuy(V, i, j, k);
+                    dz = fz ? 0.0 : AzFuz(V, i, j, k + 1) - AzFuz(V, i, j, k);
+                } else if (which == 1) {     /* ∂ⱼ_τ₂ⱼ at cfc */
+                    Vinv = 1.0 / ((DC(g, 0, i) * DF(g, 1, j)) * DC(g, 2, k));
+                    dx = fx ? 0.0 : AxFvx(V, i + 1, j, k) - AxFvx(V, i, j, k);
+                    dy = fy ? 0.0 : AyFvy(V, i, j, k) - AyFvy(V, i, j - 1, k);
+                    dz = fz ? 0.0 : AzFvz(V, i, j, k + 1) - AzFvz(V, i, j, k);
+                } else if (which == 2) {     /* ∂ⱼ_τ₃ⱼ at ccf */
+                    Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DF(g, 2, k));
+                    dx = fx ? 0.0 : AxFwx(V, i + 1, j, k) - AxFwx(V, i, j, k);
+                    dy = fy ? 0.0 : AyFwy(V, i, j + 1, k) - AyFwy(V, i, j, k);
+                    dz = fz ? 0.0 : AzFwz(V, i, j, k) - AzFwz(V, i, j, k - 1);
+                } else {                     /* ∇_dot_qᶜ at ccc: A * (-(κ ∂c)) */
+                    Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
+                    const double ax = DC(g, 1, j) * DC(g, 2, k), ay = DC(g, 0, i) * DC(g, 2, k), az = DC(g, 0, i) * DC(g, 1, j);
+                    dx = fx ? 0.0 : ax * -(coef * ddx_f(g, &C, i + 1, j, k)) - ax * -(coef * ddx_f(g, &C, i, j, k));
+                    dy = fy ? 0.0 : ay * -(coef * ddy_f(g, &C, i, j + 1, k)) - ay * -(coef * ddy_f(g, &C, i, j, k));
+                    dz = fz ? 0.0 : az * -(coef * ddz_f(g, &C, i, j, k + 1)) - az * -(coef * ddz_f(g, &C, i, j, k));
+                }
+                const double div = Vinv * ((dx + dy) + dz);
+                AT(G, i, j, k) = (AT(G, i, j, k) - div) + 0.0;
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
  * RK3 substep and tendency caching
  * ------------------------------------------------------------------------------------------------------------------ */
 /* TimeSteppers/runge_kutta_3.jl:212-226, launched :xyz with exclude_periphery=true (:187) */
@@ -822,6 +902,8 @@ struct oro_model {
     int loc[3 + ORO_MAXTR][3];
     oro_bc bcs[3 + ORO_MAXTR][6];
     int any_flux_bc;
+    int has_closure;
+    double nu, kappa[ORO_MAXTR];
     double *p;
     oro_poisson *solver;
     double time, last_dt, last_stage_dt;
@@ -915,7 +997,16 @@ int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double 
     return 0;
 }
 
-/* update_nonhydrostatic_model_state.jl:20-56 with closure/buoyancy = nothing */
+void oro_model_set_closure(oro_model *m, double nu, const double *kappa) {
+    m->nu = nu;
+    m->has_closure = nu != 0.0;
+    for (int t = 0; t < m->ntr; ++t) {
+        m->kappa[t] = kappa ? kappa[t] : 0.0;
+        if (m->kappa[t] != 0.0) m->has_closure = 1;
+    }
+}
+
+/* update_nonhydrostatic_model_state.jl:20-56 with buoyancy = nothing */
 void oro_model_update_state(oro_model *m, int compute_tendencies) {
     const oro_grid *g = m->g;
     for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions_bcs(g, m->U[f], m->loc[f], m->bcs[f], /*fill_open_bcs=*/0);
@@ -924,6 +1015,11 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
         oro_compute_Gv(g, m->U[0], m->U[1], m->U[2], m->Gn[1], NULL);
         oro_compute_Gw(g, m->U[0], m->U[1], m->U[2], m->Gn[2], NULL);
         for (int t = 0; t < m->ntr; ++t) oro_compute_Gc(g, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->Gn[3 + t], NULL);
+        if (m->has_closure) {
+            for (int f = 0; f < 3; ++f) oro_add_closure_tendency(g, f, m->U[0], m->U[1], m->U[2], NULL, m->nu, m->Gn[f], NULL);
+            for (int t = 0; t < m->ntr; ++t)
+                oro_add_closure_tendency(g, 3, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->kappa[t], m->Gn[3 + t], NULL);
+        }
         /* compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) */
         if (m->any_flux_bc)
             for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);

@@ -67,6 +67,11 @@ void oro_compute_Gw(const oro_grid *g, const double *u, const double *v, const d
 void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const double *w, const double *c, double *Gc,
                     const int *range);
 
+/* ScalarDiffusivity(ν, κ): isotropic constant explicit closure. Adds -∂ⱼτᵢⱼ (which = 0, 1, 2: u, v, w with
+ * coef = ν) or -∇·q (which = 3: tracer c with coef = κ) to a tendency that already holds the advective part */
+void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                              double coef, double *G, const int *range);
+
 /* single-point WENO kernels exported for KATs */
 double oro_weno5_biased(const double S[6], int left);
 double oro_weno3_biased(const double S[4], int left);
@@ -103,6 +108,8 @@ double *oro_model_field(oro_model *m, const char *name); /* "u","v","w","c0".., 
 void oro_model_field_loc(oro_model *m, const char *name, int loc[3]);
 /* side 0..5 = west, east, south, north, bottom, top; returns 0, or -1 for an invalid combination */
 int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value);
+/* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) ; nu = 0 and kappa = NULL/0 -> closure = nothing */
+void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
 void oro_model_update_state(oro_model *m, int compute_tendencies);
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
 void oro_model_time_step(oro_model *m, double dt);

@@ -68,6 +68,8 @@ def lib():
         L.oro_fill_halo_regions_bcs.argtypes = [vp, dp, ip, C.POINTER(BC), C.c_int]
         L.oro_compute_flux_bcs.argtypes = [vp, dp, ip, C.POINTER(BC)]
         L.oro_model_set_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_double]
+        L.oro_model_set_closure.argtypes = [vp, C.c_double, dp]
+        L.oro_add_closure_tendency.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_double, dp, ip]
         for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
             getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
         L.oro_compute_Gc.argtypes = [vp, dp, dp, dp, dp, dp, ip]
@@ -310,6 +312,14 @@ class Model:
         loc = (C.c_int * 3)()
         lib().oro_model_field_loc(self.handle, name.encode(), loc)
         return tuple(loc)
+
+    def set_closure(self, nu=0.0, kappa=0.0):
+        """closure = ScalarDiffusivity(ν = nu, κ = kappa) -- kappa a number or one value per tracer"""
+        k = np.atleast_1d(np.asarray(kappa, dtype=np.float64))
+        if k.size == 1:
+            k = np.full(max(self.ntracers, 1), float(k[0]))
+        k = np.ascontiguousarray(k)
+        lib().oro_model_set_closure(self.handle, float(nu), k.ctypes.data_as(C.POINTER(C.c_double)))
 
     def set_bc(self, name, side, kind, value=0.0):
         """field boundary condition with a constant value: kind in flux | value | gradient | open | default"""

@@ -341,3 +341,39 @@ def test_flat_topologies_match_oracle(ocn, oracle, arch, topology, size, stretch
     for name, a, b in field_pairs(m_gpu, m_cpu):
         assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
     assert ocn.max_abs_divergence(m_gpu) < 5e-8
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# closure = ScalarDiffusivity(ν, κ)
+# ---------------------------------------------------------------------------------------------------------------------
+CLOSURE_CASES = [(("Periodic", "Periodic", "Periodic"), (16, 12, 10), False), (("Periodic", "Periodic", "Bounded"), (16, 12, 10), True),
+                 (("Bounded", "Bounded", "Bounded"), (9, 8, 7), True), (("Periodic", "Flat", "Bounded"), (16, 1, 12), False)]
+
+
+@pytest.mark.parametrize("topology,size,stretched", CLOSURE_CASES)
+def test_scalar_diffusivity_matches_oracle(ocn, oracle, arch, topology, size, stretched):
+    z = tanh_faces(size[2]) if stretched else None
+    topo_cls = tuple(getattr(ocn, t) for t in topology)
+    zc = z if z is not None else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=zc, topology=topo_cls)
+    g_cpu = oracle.Grid(size, topology=tuple({"Periodic": 0, "Bounded": 1, "Flat": 3}[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=zc)
+    closure = ocn.ScalarDiffusivity(ν=2e-3, κ={"T": 1e-3, "S": 5e-4})
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, advection=ocn.WENO(), tracers=("T", "S"), closure=closure)
+    assert m_gpu.get_option("fuse_substep_active") == 0
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_closure(nu=2e-3, kappa=[1e-3, 5e-4])
+    # tendencies (advection + closure) on identical random inputs: bit-identical
+    set_both(ocn, m_gpu, m_cpu, seed=8, enforce_incompressibility=False)
+    ocn.update_state(m_gpu, True)
+    m_cpu.update_state(True)
+    for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+        assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), n
+    # 10 RK3 steps
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.1 * min(d for d, t in zip((g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))), topology) if t != "Flat") / 0.6
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    core = tuple(slice(None) if t == "Flat" else slice(3, -3) for t in topology)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))

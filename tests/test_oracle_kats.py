@@ -453,3 +453,79 @@ def test_flat_direction_equals_uniform_periodic_direction(oracle, flat_dim):
 
 def rel_err_(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# closure = ScalarDiffusivity(ν, κ): the reference's data-free dynamics tests (test/test_dynamics.jl)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_scalar_diffusivity_leaves_uniform_fields_alone(oracle):
+    """test_diffusion_simple (test/test_dynamics.jl:17-32): ν = κ = 1, Δt = 1, 10 steps, a field equal to π stays π"""
+    for name in ("u", "v", "c0"):
+        g = oracle.Grid((4, 4, 16), topology=(P, P, B), z=(-1.0, 0.0))
+        m = oracle.Model(g, 1)
+        m.set_closure(nu=1.0, kappa=1.0)
+        vals = {n: 0.0 for n in m.names()}
+        vals[name] = np.pi
+        m.set(enforce_incompressibility=False, **vals)
+        for _ in range(10):
+            m.time_step(1.0)
+        assert np.allclose(g.interior(m.field(name), m.loc(name)), np.pi, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("name", ["u", "v", "c0"])
+def test_scalar_diffusivity_diffusing_cosine(oracle, name):
+    """test_diffusion_cosine (test/test_dynamics.jl:65-87): cos(2 z) decays as exp(-κ 4 t); κ = ν = 1, Δt = 1e-6 Lz², 5 steps,
+    isapprox(atol = 1e-6, rtol = 1e-6)"""
+    N, Lz = 128, np.pi / 2
+    g = oracle.Grid((4, 4, N), topology=(P, P, B), z=(0.0, Lz))
+    m = oracle.Model(g, 1)
+    m.set_closure(nu=1.0, kappa=1.0)
+    z = ((np.arange(N) + 0.5) * Lz / N).reshape(1, 1, N)
+    f0 = np.cos(2 * z) + np.zeros((4, 4, N))
+    vals = {n: np.zeros(g.interior(m.field(n), m.loc(n)).shape) for n in m.names()}
+    vals[name] = f0
+    m.set(enforce_incompressibility=False, **vals)
+    dt = 1e-6 * Lz ** 2
+    for _ in range(5):
+        m.time_step(dt)
+    exact = np.exp(-4 * m.time) * f0
+    assert np.allclose(g.interior(m.field(name), m.loc(name)), exact, rtol=1e-6, atol=1e-6)
+    assert np.abs(g.interior(m.field(name), m.loc(name)) - f0).max() > 1e-6          # it did diffuse
+
+
+def test_viscous_taylor_green_vortex(oracle):
+    """taylor_green_vortex_test (test/test_dynamics.jl:216-261): u = -sin(2πy) e^{-4π²νt}, v = sin(2πx) e^{-4π²νt}, ν = 1, N = 64,
+    Δt = Δx² / (10π ν), 10 steps, max relative error < 5e-6"""
+    N = 64
+    g = oracle.Grid((N, N, 4))
+    m = oracle.Model(g, 0)
+    m.set_closure(nu=1.0)
+    h = 1.0 / N
+    xC, xF = ((np.arange(N) + 0.5) * h).reshape(N, 1, 1), (np.arange(N) * h).reshape(N, 1, 1)
+    yC, yF = xC.reshape(1, N, 1), xF.reshape(1, N, 1)
+    one = np.ones((N, N, 4))
+    m.set(u=-np.sin(2 * np.pi * yC) * one, v=np.sin(2 * np.pi * xC) * one, w=0 * one)
+    dt = (1 / (10 * np.pi)) * h ** 2
+    for _ in range(10):
+        m.time_step(dt)
+    decay = np.exp(-4 * np.pi ** 2 * m.time)
+    u, v = g.interior(m.field("u"), (1, 0, 0)), g.interior(m.field("v"), (0, 1, 0))
+    ue, ve = -np.sin(2 * np.pi * yC) * decay * one, np.sin(2 * np.pi * xC) * decay * one
+    assert np.abs((u - ue) / ue).max() < 5e-6 and np.abs((v - ve) / ve).max() < 5e-6
+    assert abs(decay - 1) > 1e-3                                                        # the vortex did decay
+
+
+def test_scalar_diffusivity_conserves_the_mean(oracle):
+    """test_ScalarDiffusivity_budget (test/test_dynamics.jl:34-56): random field, ν = κ = 1, Δt = 1e-4 Δz², 10 steps, mean kept"""
+    rng = np.random.default_rng(2)
+    for name in ("u", "c0"):
+        g = oracle.Grid((6, 5, 8), topology=(P, B, B), z=(-1.0, 0.0))
+        m = oracle.Model(g, 1)
+        m.set_closure(nu=1.0, kappa=1.0)
+        vals = {n: np.zeros(g.interior(m.field(n), m.loc(n)).shape) for n in m.names()}
+        vals[name] = rng.random(vals[name].shape)
+        m.set(enforce_incompressibility=False, **vals)
+        before = g.interior(m.field(name), m.loc(name)).mean()
+        for _ in range(10):
+            m.time_step(1e-4 * (1 / 8) ** 2)
+        assert abs(g.interior(m.field(name), m.loc(name)).mean() - before) < 1e-13
