@@ -133,6 +133,10 @@ int ocn_compute_closure_tendencies(ocn_grid_t grid, const double *u, const doubl
 /* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
 /* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage
  * method `U += Δt γ¹ G¹`. */
+/* ab2_step_field! (TimeSteppers/quasi_adams_bashforth_2.jl:160-173), launched with exclude_periphery: U += Δt ((3/2 + χ) Gⁿ -
+ * (1/2 + χ) G⁻); χ = -0.5 is the forward-Euler step (G⁻ is not read) */
+int ocn_ab2_step(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm, const int (*locs)[3],
+                 int nfields, double dt, double chi);
 int ocn_rk3_substep(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm,
                     const int (*locs)[3], int nfields, double dt, double gamma, double zeta, int has_zeta);
 /* _cache_field_tendencies! (TimeSteppers/store_tendencies.jl:6-9) */
@@ -210,6 +214,10 @@ int ocn_model_update_state(ocn_model_t model, int compute_tendencies);
 int ocn_model_set_finalize(ocn_model_t model, int enforce_incompressibility);
 /* time_step!(model, Δt) (runge_kutta_3.jl:93-170) */
 int ocn_model_time_step(ocn_model_t model, double dt);
+/* time_step!(model::AbstractModel{<:QuasiAdamsBashforth2TimeStepper}, Δt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:74-123;
+ * SURVEY.md 8f.1): χ = 0.1 is the reference's default; a forward-Euler step is taken when Δt differs from clock.last_Δt (first
+ * step) or euler != 0 */
+int ocn_model_time_step_ab2(ocn_model_t model, double dt, double chi, int euler);
 int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *stage, double *last_dt,
                     double *last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */

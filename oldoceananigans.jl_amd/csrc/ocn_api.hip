@@ -576,6 +576,24 @@ static int rk3_substep(const DGrid &g, double *const *U, const double *const *Gn
     return OCN_OK;
 }
 
+static int ab2_step(const DGrid &g, double *const *U, const double *const *Gn, const double *const *Gm, const int (*locs)[3], int n,
+                    double dt, double chi) {
+    SubstepArgs a;
+    int nx, ny, nz;
+    int rc = fill_substep_args(g, a, U, Gn, Gm, locs, n, true, &nx, &ny, &nz);
+    if (rc || n == 0 || nx <= 0 || ny <= 0 || nz <= 0) return rc;
+    hipLaunchKernelGGL(ab2_step_kernel, grid3(nx, ny, nz * n, BLK), BLK, 0, g_stream, a, dt, chi);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_ab2_step(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm, const int (*locs)[3],
+                            int nfields, double dt, double chi) {
+    NEED_INIT();
+    if (!grid || !U || !Gn || !Gm || !locs) return fail(OCN_EINVAL, "NULL argument");
+    return ab2_step(grid->d, U, Gn, Gm, locs, nfields, dt, chi);
+}
+
 extern "C" int ocn_rk3_substep(ocn_grid_t grid, double *const *U, const double *const *Gn, const double *const *Gm,
                                const int (*locs)[3], int nfields, double dt, double gamma, double zeta, int has_zeta) {
     NEED_INIT();
@@ -1719,6 +1737,23 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
         } else if ((rc = update_state(m, true))) return rc;
     }
     return OCN_OK;
+}
+
+// time_step!(model::AbstractModel{<:QuasiAdamsBashforth2TimeStepper}, Δt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:74-123)
+extern "C" int ocn_model_time_step_ab2(ocn_model_t m, double dt, double chi, int euler) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = m->grid->d;
+    int rc;
+    if (m->iteration == 0 && (rc = update_state(m, true))) return rc;
+    const bool eul = euler != 0 || dt != m->last_dt;            // Δt changed, or first step (last_Δt = Inf)
+    const double x = eul ? -0.5 : chi;
+    if ((rc = ab2_step(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, x))) return rc;
+    tick(m, dt, false);
+    if ((rc = compute_pressure_correction(m))) return rc;
+    if ((rc = make_pressure_correction(m, dt))) return rc;
+    if ((rc = cache_previous_tendencies(m))) return rc;
+    return update_state(m, true);
 }
 
 extern "C" int ocn_model_clock(ocn_model_t m, double *time, int64_t *iteration, int *stage, double *last_dt, double *last_stage_dt) {

@@ -317,6 +317,21 @@ __global__ void __launch_bounds__(256) rk3_substep_kernel(SubstepArgs a, double 
     a.U[f][q] = Uv;
 }
 
+// ab2_step_field! (TimeSteppers/quasi_adams_bashforth_2.jl:160-173): Gu = (1.5 + χ) Gⁿ - (0.5 + χ) G⁻ * not_euler; u += Δt Gu
+__global__ void __launch_bounds__(256) ab2_step_kernel(SubstepArgs a, double dt, double chi) {
+    const int f = blockIdx.z % a.n;
+    const Range6 r = a.r[f];
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z / a.n;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const long q = a.view[f].lin(i, j, k);
+    const bool not_euler = chi != -0.5;            // `* false` is a strong zero: leftover NaNs in G⁻ cannot leak into a Euler step
+    const double prev = not_euler ? (0.5 + chi) * a.Gm[f][q] * 1.0 : 0.0;
+    const double Gu = (1.5 + chi) * a.Gn[f][q] - prev;
+    a.U[f][q] += dt * Gu;
+}
+
 __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
     const int f = blockIdx.z % a.n;
     const Range6 r = a.r[f];

@@ -44,8 +44,10 @@ class NonhydrostaticModel:
             advection = WENO()
         if not isinstance(advection, WENO):
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
-        if timestepper not in ("RungeKutta3", ":RungeKutta3"):
-            raise NotImplementedError("only timestepper = :RungeKutta3 is on the accelerated hot path")
+        timestepper = str(timestepper).lstrip(":")
+        if timestepper not in ("RungeKutta3", "QuasiAdamsBashforth2"):
+            raise NotImplementedError("timestepper must be :RungeKutta3 (hot path) or :QuasiAdamsBashforth2 (SURVEY.md 8f.1)")
+        self.timestepper, self.χ = timestepper, 0.1          # QuasiAdamsBashforth2TimeStepper(χ = 0.1)
         for name, val in (("buoyancy", buoyancy), ("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the accelerated hot path (SURVEY.md 8f)")
@@ -146,9 +148,13 @@ def update_state(model, compute_tendencies=True):
     _lib.check(_lib.lib().ocn_model_update_state(model.handle, int(compute_tendencies)))
 
 
-def time_step(model, Δt):
-    """time_step!(model, Δt) (runge_kutta_3.jl:93-170)"""
-    _lib.check(_lib.lib().ocn_model_time_step(model.handle, float(Δt)))
+def time_step(model, Δt, euler=False):
+    """time_step!(model, Δt) (runge_kutta_3.jl:93-170; quasi_adams_bashforth_2.jl:74-123 when the model's timestepper is
+    :QuasiAdamsBashforth2 -- `euler` as in the reference)"""
+    if getattr(model, "timestepper", "RungeKutta3") == "QuasiAdamsBashforth2":
+        _lib.check(_lib.lib().ocn_model_time_step_ab2(model.handle, float(Δt), float(model.χ), int(euler)))
+    else:
+        _lib.check(_lib.lib().ocn_model_time_step(model.handle, float(Δt)))
 
 
 def max_abs_divergence(model):

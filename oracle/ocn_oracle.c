@@ -1020,10 +1020,14 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
             for (int t = 0; t < m->ntr; ++t)
                 oro_add_closure_tendency(g, 3, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->kappa[t], m->Gn[3 + t], NULL);
         }
-        /* compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) */
-        if (m->any_flux_bc)
-            for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
     }
+}
+
+/* compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184): the time steppers call it right before every
+ * substep (runge_kutta_3.jl:118,135,152; quasi_adams_bashforth_2.jl:99), not compute_tendencies! */
+static void compute_flux_bc_tendencies(oro_model *m) {
+    if (!m->any_flux_bc) return;
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(m->g, m->Gn[f], m->loc[f], m->bcs[f]);
 }
 
 /* pressure_correction.jl:8-20 + solve_for_pressure.jl:91-95 */
@@ -1076,7 +1080,7 @@ void oro_model_time_step(oro_model *m, double dt) {
     double dt1 = dt * g1, dt2 = dt * (g2 + z2), dt3 = dt * (g3 + z3);   /* :176-177 */
     double tn1 = m->time + dt;
 
-    /* compute_flux_bc_tendencies!: no Flux BCs with values in scope (compute_flux_bcs.jl:24-28) */
+    compute_flux_bc_tendencies(m);
     rk3_substep(m, dt, g1, 0.0, 0);
     tick(m, dt1, 1);
     compute_pressure_correction(m, dt1);
@@ -1084,6 +1088,7 @@ void oro_model_time_step(oro_model *m, double dt) {
     cache_previous_tendencies(m);
     oro_model_update_state(m, 1);
 
+    compute_flux_bc_tendencies(m);
     rk3_substep(m, dt, g2, z2, 1);
     tick(m, dt2, 1);
     compute_pressure_correction(m, dt2);
@@ -1091,6 +1096,7 @@ void oro_model_time_step(oro_model *m, double dt) {
     cache_previous_tendencies(m);
     oro_model_update_state(m, 1);
 
+    compute_flux_bc_tendencies(m);
     rk3_substep(m, dt, g3, z3, 1);
     double corrected = tn1 - m->time;
     tick(m, dt3, 0);
@@ -1098,6 +1104,37 @@ void oro_model_time_step(oro_model *m, double dt) {
     m->last_dt = dt;
     compute_pressure_correction(m, dt3);
     make_pressure_correction(m, dt3);
+    oro_model_update_state(m, 1);
+}
+
+/* TimeSteppers/quasi_adams_bashforth_2.jl:74-175: χ = 0.1 by default; forward Euler (χ = -0.5) when Δt differs
+ * from clock.last_Δt (first step: last_Δt = Inf) or on request. ab2_step_field! :160-173:
+ *   Gu = (1.5 + χ) Gⁿ - (0.5 + χ) G⁻ * not_euler ;  u += Δt Gu   (`* false` is a strong zero) */
+void oro_ab2_step_field(const oro_grid *g, double *U, const int loc[3], double dt, double chi, const double *Gn, const double *Gm) {
+    int r[6];
+    default_range(g, loc, 1, r);
+    fld Uf = mkfld(g, U, loc), Gnf = mkfld(g, Gn, loc), Gmf = mkfld(g, Gm, loc);
+    const int not_euler = chi != -0.5;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = r[4]; k <= r[5]; ++k)
+        for (int j = r[2]; j <= r[3]; ++j)
+            for (int i = r[0]; i <= r[1]; ++i) {
+                const double prev = not_euler ? (0.5 + chi) * AT(Gmf, i, j, k) * 1.0 : 0.0;
+                const double Gu = (1.5 + chi) * AT(Gnf, i, j, k) - prev;
+                AT(Uf, i, j, k) += dt * Gu;
+            }
+}
+
+void oro_model_time_step_ab2(oro_model *m, double dt, double chi, int euler) {
+    if (m->iteration == 0) oro_model_update_state(m, 1);
+    euler = euler || (dt != m->last_dt);
+    const double x = euler ? -0.5 : chi;
+    compute_flux_bc_tendencies(m);
+    for (int f = 0; f < 3 + m->ntr; ++f) oro_ab2_step_field(m->g, m->U[f], m->loc[f], dt, x, m->Gn[f], m->Gm[f]);
+    tick(m, dt, 0);
+    compute_pressure_correction(m, dt);
+    make_pressure_correction(m, dt);
+    cache_previous_tendencies(m);
     oro_model_update_state(m, 1);
 }
 

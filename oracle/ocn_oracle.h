@@ -113,6 +113,9 @@ void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
 void oro_model_update_state(oro_model *m, int compute_tendencies);
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
 void oro_model_time_step(oro_model *m, double dt);
+/* QuasiAdamsBashforth2TimeStepper (TimeSteppers/quasi_adams_bashforth_2.jl:74-175), χ default 0.1 */
+void oro_model_time_step_ab2(oro_model *m, double dt, double chi, int euler);
+void oro_ab2_step_field(const oro_grid *g, double *U, const int loc[3], double dt, double chi, const double *Gn, const double *Gm);
 double oro_model_time(const oro_model *m);
 int oro_model_iteration(const oro_model *m);
 double oro_model_max_abs_divergence(oro_model *m);

@@ -102,6 +102,7 @@ def lib():
         L.oro_model_update_state.argtypes = [vp, C.c_int]
         L.oro_model_set_finalize.argtypes = [vp, C.c_int]
         L.oro_model_time_step.argtypes = [vp, C.c_double]
+        L.oro_model_time_step_ab2.argtypes = [vp, C.c_double, C.c_double, C.c_int]
         L.oro_model_time.restype = C.c_double
         L.oro_model_time.argtypes = [vp]
         L.oro_model_iteration.argtypes = [vp]
@@ -337,6 +338,10 @@ class Model:
 
     def time_step(self, dt):
         lib().oro_model_time_step(self.handle, float(dt))
+
+    def time_step_ab2(self, dt, chi=0.1, euler=False):
+        """time_step!(model::AbstractModel{<:QuasiAdamsBashforth2TimeStepper}, Δt; euler)"""
+        lib().oro_model_time_step_ab2(self.handle, float(dt), float(chi), int(euler))
 
     @property
     def time(self):

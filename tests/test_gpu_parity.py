@@ -377,3 +377,28 @@ def test_scalar_diffusivity_matches_oracle(ocn, oracle, arch, topology, size, st
     core = tuple(slice(None) if t == "Flat" else slice(3, -3) for t in topology)
     for name, a, b in field_pairs(m_gpu, m_cpu):
         assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
+
+
+@pytest.mark.parametrize("topology,stretched", [(TOPOS[0], False), (TOPOS[1], True)])
+def test_quasi_adams_bashforth_2_matches_oracle(ocn, oracle, arch, topology, stretched):
+    """timestepper = :QuasiAdamsBashforth2 with a ScalarDiffusivity closure: Euler first step, AB2 steps, a
+    change of Δt (Euler again), against the oracle"""
+    size = (16, 16, 12)
+    z = tanh_faces(size[2]) if stretched else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+    topo_cls = tuple(getattr(ocn, t) for t in topology)
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo_cls)
+    g_cpu = oracle.Grid(size, topology=tuple(1 if t == "Bounded" else 0 for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T", "S"), timestepper="QuasiAdamsBashforth2",
+                                    closure=ocn.ScalarDiffusivity(ν=1e-3, κ=1e-3))
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_closure(nu=1e-3, kappa=1e-3)
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.05 * g_gpu.Δxᶜᵃᵃ / 0.6
+    for n in range(12):
+        step = dt if n < 8 else 0.5 * dt
+        ocn.time_step(m_gpu, step)
+        m_cpu.time_step_ab2(step)
+    assert m_gpu.clock.iteration == 12 and m_gpu.clock.time == m_cpu.time
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (name, rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]))
+    assert ocn.max_abs_divergence(m_gpu) < 5e-8

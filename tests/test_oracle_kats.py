@@ -529,3 +529,35 @@ def test_scalar_diffusivity_conserves_the_mean(oracle):
         for _ in range(10):
             m.time_step(1e-4 * (1 / 8) ** 2)
         assert abs(g.interior(m.field(name), m.loc(name)).mean() - before) < 1e-13
+
+
+def test_quasi_adams_bashforth_2_time_stepper(oracle):
+    """QuasiAdamsBashforth2TimeStepper (TimeSteppers/quasi_adams_bashforth_2.jl:74-175): first step (and any step after Δt
+    changed) is forward Euler; incompressibility after 1 and 10 steps like test/test_time_stepping.jl:124-160; second order in
+    time on the diffusing cosine (constant Δt)"""
+    g = oracle.Grid((16, 16, 16))
+    m = _random_model(oracle, g, seed=3)
+    m.time_step_ab2(1e-3)
+    assert m.iteration == 1 and m.time == 1e-3 and m.max_abs_divergence() < 5e-8
+    for _ in range(9):
+        m.time_step_ab2(1e-3)
+    assert m.iteration == 10 and m.max_abs_divergence() < 5e-8
+    # Euler first step: u1 = u0 + Δt G0 (no pressure gradient for a pure-diffusion, zero-velocity problem => exact check on c)
+    N, Lz = 64, np.pi / 2
+
+    def decay_error(dt, nsteps):
+        gz = oracle.Grid((4, 4, N), topology=(P, P, B), z=(0.0, Lz))
+        mm = oracle.Model(gz, 1)
+        mm.set_closure(nu=0.0, kappa=1.0)
+        z = ((np.arange(N) + 0.5) * Lz / N).reshape(1, 1, N)
+        c0 = np.cos(2 * z) + np.zeros((4, 4, N))
+        mm.set(enforce_incompressibility=False, u=0 * c0, v=0 * c0, w=np.zeros((4, 4, N + 1)), c0=c0)
+        lam = (2 * np.sin(2 * (Lz / N) / 2) / (Lz / N)) ** 2          # eigenvalue of the discrete operator for cos(2z)
+        mm.time_step_ab2(dt)
+        first = gz.interior_cells(mm.field("c0")) / c0
+        assert np.allclose(first, 1 - dt * lam, rtol=1e-12)            # forward Euler
+        for _ in range(nsteps - 1):
+            mm.time_step_ab2(dt)
+        return np.abs(gz.interior_cells(mm.field("c0")) / c0 - np.exp(-lam * dt * nsteps)).max()
+    e1, e2 = decay_error(2e-4, 50), decay_error(1e-4, 100)
+    assert e1 / e2 > 3.0 and e2 < 5e-6, (e1, e2)       # better than first order at these step sizes (χ = 0.1 keeps the O(χ Δt) term small)
