@@ -121,6 +121,14 @@ int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fie
                                        const int *range, double *const *next, const double *const *Gm, double dt,
                                        double gamma, double zeta, int has_zeta);
 
+/* buoyancy, gravity along -z: kind 1 = BuoyancyTracer (bT = the buoyancy tracer), kind 2 = SeawaterBuoyancy with
+ * a LinearEquationOfState, b = g (α T - β S) (bT = T). _update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-22, over
+ * i = 0:Nx+1, j = 0:Ny+1) and the -∂x pHY′, -∂y pHY′ terms of the u, v tendencies (nonhydrostatic_tendency_kernel_functions.jl:
+ * 14-19,97,159), added to tendencies that hold the advective part (range: the cells whose tendencies are updated, NULL = all). */
+int ocn_update_hydrostatic_pressure(ocn_grid_t grid, int kind, const double *bT, const double *S, double g, double alpha, double beta,
+                                    double *pHY);
+int ocn_add_hydrostatic_pressure_gradient(ocn_grid_t grid, const double *pHY, double *Gu, double *Gv, const int *range);
+
 /* closure = ScalarDiffusivity(ν, κ): isotropic, constant, explicit (SURVEY.md 8f.1 -- the first "next" row).
  * ∂ⱼ_τ₁ⱼ / ∂ⱼ_τ₂ⱼ / ∂ⱼ_τ₃ⱼ / ∇_dot_qᶜ (TurbulenceClosures/closure_kernel_operators.jl:22-48) with viscous_flux_* = -2 ν Σᵢⱼ and
  * diffusive_flux_* = -κ ∂c (abstract_scalar_diffusivity_closure.jl:194-242). ADDS the closure term to tendencies that already
@@ -236,6 +244,10 @@ int ocn_model_get_option(ocn_model_t model, const char *key, int *value);
 /* boundary_conditions = (name = FieldBoundaryConditions(side = BoundaryCondition(kind, value)),) of the model
  * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0"..; side 0..5 = west .. top. OCN_EINVAL mirrors
  * the reference's validation: Bounded sides only; Flux/Value/Gradient on Center-located, Open on Face-located fields */
+/* buoyancy = nothing (kind 0) | BuoyancyTracer() (kind 1, tracer index) | SeawaterBuoyancy(LinearEquationOfState(α, β), g)
+ * (kind 2, tracer indices of T and S). With buoyancy the model carries the hydrostatic pressure anomaly, field name "pHY"
+ * (nonhydrostatic_model.jl:144-158). */
+int ocn_model_set_buoyancy(ocn_model_t model, int kind, int b_or_T_index, int S_index, double g, double alpha, double beta);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) of the model constructor; all zeros / NULL: closure = nothing */
 int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);

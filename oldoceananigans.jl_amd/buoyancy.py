@@ -1,0 +1,34 @@
+"""Buoyancy formulations on the accelerated path, gravity along -z (reference: src/BuoyancyFormulations/)."""
+
+
+class BuoyancyTracer:
+    """BuoyancyTracer(): the tracer `b` is the buoyancy (buoyancy_tracer.jl:1-12)"""
+    required_tracers = ("b",)
+
+    def __repr__(self):
+        return "BuoyancyTracer()"
+
+
+class LinearEquationOfState:
+    """LinearEquationOfState(thermal_expansion = 1.67e-4, haline_contraction = 7.80e-4) (linear_equation_of_state.jl:39-41)"""
+
+    def __init__(self, thermal_expansion=1.67e-4, haline_contraction=7.80e-4):
+        self.thermal_expansion, self.haline_contraction = float(thermal_expansion), float(haline_contraction)
+
+
+class SeawaterBuoyancy:
+    """SeawaterBuoyancy(equation_of_state = LinearEquationOfState(), gravitational_acceleration = g_Earth): b = g (α T - β S)
+    (seawater_buoyancy.jl, linear_equation_of_state.jl:71-73). Nonlinear equations of state (TEOS-10) are third-party code absent
+    from the reference tree and stay out of scope."""
+    required_tracers = ("T", "S")
+
+    def __init__(self, equation_of_state=None, gravitational_acceleration=9.80665):
+        self.equation_of_state = equation_of_state if equation_of_state is not None else LinearEquationOfState()
+        if not isinstance(self.equation_of_state, LinearEquationOfState):
+            raise NotImplementedError("only LinearEquationOfState is on the accelerated path")
+        self.gravitational_acceleration = float(gravitational_acceleration)
+
+    def __repr__(self):
+        e = self.equation_of_state
+        return (f"SeawaterBuoyancy(g={self.gravitational_acceleration}, LinearEquationOfState(α={e.thermal_expansion}, "
+                f"β={e.haline_contraction}))")

@@ -495,6 +495,42 @@ extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const do
     return OCN_OK;
 }
 
+static int update_hydrostatic_pressure(const DGrid &g, int kind, const double *bT, const double *S, double grav, double alpha, double beta,
+                                       double *pHY) {
+    if (g.tz == OCN_FLAT) return OCN_OK;                   // update_hydrostatic_pressure!(::ZFlatGrid) = nothing
+    const int i0 = g.tx == OCN_FLAT ? 1 : 0, i1 = g.tx == OCN_FLAT ? g.Nx : g.Nx + 1;
+    const int j0 = g.ty == OCN_FLAT ? 1 : 0, j1 = g.ty == OCN_FLAT ? g.Ny : g.Ny + 1;
+    const BuoyancyArgs B{kind, bT, S, grav, alpha, beta};
+    const dim3 blk(64, 4, 1);
+    hipLaunchKernelGGL(hydrostatic_pressure_kernel, dim3((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4), blk, 0, g_stream, g, make_view(g, bT, LOC_C), B,
+                       pHY, i0, i1, j0, j1);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+static int add_hydrostatic_pressure_gradient(const DGrid &g, const double *pHY, double *Gu, double *Gv, const int *range) {
+    Range6 ru, rv;
+    int rc;
+    if ((rc = check_range(g, range, &ru, LOC_U, true)) || (rc = check_range(g, range, &rv, LOC_V, true))) return rc;
+    hipLaunchKernelGGL(hydrostatic_gradient_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, pHY, LOC_C),
+                       make_view(g, Gu, LOC_U), make_view(g, Gv, LOC_V), ru, rv);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_update_hydrostatic_pressure(ocn_grid_t grid, int kind, const double *bT, const double *S, double grav, double alpha,
+                                               double beta, double *pHY) {
+    NEED_INIT();
+    if (!grid || !bT || !pHY || (kind != 1 && kind != 2) || (kind == 2 && !S)) return fail(OCN_EINVAL, "invalid argument");
+    return update_hydrostatic_pressure(grid->d, kind, bT, S, grav, alpha, beta, pHY);
+}
+
+extern "C" int ocn_add_hydrostatic_pressure_gradient(ocn_grid_t grid, const double *pHY, double *Gu, double *Gv, const int *range) {
+    NEED_INIT();
+    if (!grid || !pHY || !Gu || !Gv) return fail(OCN_EINVAL, "NULL argument");
+    return add_hydrostatic_pressure_gradient(grid->d, pHY, Gu, Gv, range);
+}
+
 static int closure_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr, int ntr,
                               double nu, const double *kappa, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range) {
     const FView vu = make_view(g, u, LOC_U), vv = make_view(g, v, LOC_V), vw = make_view(g, w, LOC_W);
@@ -1439,6 +1475,9 @@ struct ocn_model_s {
     bool any_bc = false, any_flux_bc = false;
     bool has_closure = false;               // closure = ScalarDiffusivity(ν, κ)
     double nu = 0.0, kappa[OCN_MAX_FIELDS] = {};
+    int buoyancy_kind = 0, bT_index = 0, S_index = 0;    // 0 nothing, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy
+    double grav = 0.0, alpha = 0.0, beta = 0.0;
+    double *pHY = nullptr;                  // hydrostatic pressure anomaly (only with buoyancy)
     double *p;
     ocn_poisson_t solver;
     double *blockmax;
@@ -1459,6 +1498,7 @@ extern "C" int ocn_model_destroy(ocn_model_t m) {
     if (!m) return OCN_OK;
     for (auto &e : m->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->U2[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
+    hipFree(m->pHY);
     hipFree(m->p); hipFree(m->blockmax);
     ocn_poisson_destroy(m->solver);
     delete m;
@@ -1508,6 +1548,10 @@ static int field_lookup(ocn_model_s *m, const char *name, double ***slot, int **
     const char *q = name;
     char kind = 'U';
     if (!strcmp(name, "p")) { *slot = &m->p; *loc = const_cast<int *>(LOC_C); return OCN_OK; }
+    if (!strcmp(name, "pHY")) {
+        if (!m->pHY) return fail(OCN_ESTATE, "the model has no hydrostatic pressure anomaly (buoyancy = nothing)");
+        *slot = &m->pHY; *loc = const_cast<int *>(LOC_C); return OCN_OK;
+    }
     if (q[0] == 'G' || q[0] == 'M') { kind = q[0]; ++q; }
     int f = -1;
     if (!strcmp(q, "u")) f = 0;
@@ -1556,7 +1600,7 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
 }
 
 static bool can_fuse_substep(const ocn_model_s *m) {
-    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure &&
+    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure && !m->buoyancy_kind &&
            fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
 
@@ -1575,6 +1619,10 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
     const DGrid &g = m->grid->d;
     int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, /*fill_open_bcs=*/false, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
+    // compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69)
+    if (m->buoyancy_kind &&
+        (rc = update_hydrostatic_pressure(g, m->buoyancy_kind, m->U[3 + m->bT_index], m->U[3 + m->S_index], m->grav, m->alpha, m->beta, m->pHY)))
+        return rc;
     if (compute_tend) {
         std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
         if (m->profile) {
@@ -1590,6 +1638,7 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl, sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
+        if (!rc && m->buoyancy_kind) rc = add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1], nullptr);
         if (!rc && m->has_closure)
             rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1], m->Gn[2],
                                     m->Gn + 3, nullptr);
@@ -1619,6 +1668,24 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
     if (rc) return rc;
     double dtp = std::fmax(2.220446049250313e-16, dt);
     return divide_interior(g, m->p, dtp);
+}
+
+extern "C" int ocn_model_set_buoyancy(ocn_model_t m, int kind, int b_or_T_index, int S_index, double grav, double alpha, double beta) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    if (kind < 0 || kind > 2) return fail(OCN_EINVAL, "buoyancy kind must be 0 (nothing), 1 (BuoyancyTracer) or 2 (linear SeawaterBuoyancy)");
+    if (kind && (b_or_T_index < 0 || b_or_T_index >= m->ntr)) return fail(OCN_EINVAL, "tracer index %d out of range", b_or_T_index);
+    if (kind == 2 && (S_index < 0 || S_index >= m->ntr)) return fail(OCN_EINVAL, "tracer index %d out of range", S_index);
+    if (kind && !m->pHY) {
+        int P[3];
+        parent_size(m->grid->d, LOC_C, P);
+        const size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
+        HIP_TRY(dev_alloc((void **)&m->pHY, bytes));
+        HIP_TRY(hipMemsetAsync(m->pHY, 0, bytes, g_stream));
+    }
+    m->buoyancy_kind = kind; m->bT_index = b_or_T_index; m->S_index = kind == 2 ? S_index : b_or_T_index;
+    m->grav = grav; m->alpha = alpha; m->beta = beta;
+    return OCN_OK;
 }
 
 extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kappa) {

@@ -166,6 +166,54 @@ __global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u,
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Buoyancy: BuoyancyTracer | SeawaterBuoyancy(LinearEquationOfState), gravity along -z.
+// _update_hydrostatic_pressure! (Models/NonhydrostaticModels/update_hydrostatic_pressure.jl:12-22) over i = 0:Nx+1, j = 0:Ny+1
+// (:43-50): pHY′[Nz] = -z_dot_g_b(Nz+1) Δzᶠ(Nz+1); pHY′[k] = pHY′[k+1] - z_dot_g_b(k+1) Δzᶠ(k+1), z_dot_g_bᶜᶜᶠ = 1 * ℑzᵃᵃᶠ(b)
+// (BuoyancyFormulations/g_dot_b.jl:4). One thread per column, coalesced in x.
+// ---------------------------------------------------------------------------------------------------------------------
+struct BuoyancyArgs {
+    int kind;                 // 1: tracer b; 2: g (α T - β S) (linear_equation_of_state.jl:71-73)
+    const double *bT, *S;
+    double grav, alpha, beta;
+};
+__device__ __forceinline__ double buoyancy_perturbation(const BuoyancyArgs &B, long q) {
+    return B.kind == 1 ? B.bT[q] : B.grav * (B.alpha * B.bT[q] - B.beta * B.S[q]);
+}
+
+__global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FView c, BuoyancyArgs B, double *pHY, int i0, int i1, int j0, int j1) {
+    const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    if (i > i1 || j > j1) return;
+    const int Nz = g.Nz;
+    long q = c.lin(i, j, Nz + 1);
+    double bk1 = buoyancy_perturbation(B, q);          // b[k+1]
+    double p = 0.0;
+    for (int k = Nz; k >= 1; --k) {
+        q -= c.s2;
+        const double bk = buoyancy_perturbation(B, q);
+        const double zb = 1 * (0.5 * (bk + bk1));
+        const double dzf = g.dzf[k + g.Hz];            // Δzᶠ(k+1)
+        p = k == Nz ? -zb * dzf : p - zb * dzf;
+        pHY[q] = p;
+        bk1 = bk;
+    }
+}
+
+// G_u -= ∂xᶠᶜᶜ pHY′, G_v -= ∂yᶜᶠᶜ pHY′ (nonhydrostatic_tendency_kernel_functions.jl:14-19,97,159) on tendencies holding the
+// advective part; ranges = the tendency ranges of u and v
+__global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FView p, FView Gu, FView Gv, Range6 ru, Range6 rv) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const double pc = p.at(i, j, k);
+    if (i >= ru.i0 && i <= ru.i1 && j >= ru.j0 && j <= ru.j1 && k >= ru.k0 && k <= ru.k1)
+        Gu.at(i, j, k) = Gu.at(i, j, k) - (g.tx == OCN_FLAT ? 0.0 : (pc - p.at(i - 1, j, k)) * (1.0 / g.dx));
+    if (i >= rv.i0 && i <= rv.i1 && j >= rv.j0 && j <= rv.j1 && k >= rv.k0 && k <= rv.k1)
+        Gv.at(i, j, k) = Gv.at(i, j, k) - (g.ty == OCN_FLAT ? 0.0 : (pc - p.at(i, j - 1, k)) * (1.0 / g.dy));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // halo fills (src/BoundaryConditions). One launch handles up to OCN_MAX_FIELDS fields of identical parent shape.
 // ---------------------------------------------------------------------------------------------------------------------
 struct FieldList {

@@ -48,9 +48,13 @@ class NonhydrostaticModel:
         if timestepper not in ("RungeKutta3", "QuasiAdamsBashforth2"):
             raise NotImplementedError("timestepper must be :RungeKutta3 (hot path) or :QuasiAdamsBashforth2 (SURVEY.md 8f.1)")
         self.timestepper, self.χ = timestepper, 0.1          # QuasiAdamsBashforth2TimeStepper(χ = 0.1)
-        for name, val in (("buoyancy", buoyancy), ("coriolis", coriolis), ("forcing", forcing)):
+        for name, val in (("coriolis", coriolis), ("forcing", forcing)):
             if val is not None:
                 raise NotImplementedError(f"{name} != nothing is outside the accelerated hot path (SURVEY.md 8f)")
+        from .buoyancy import BuoyancyTracer, SeawaterBuoyancy
+        if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
+            raise NotImplementedError("buoyancy must be nothing, BuoyancyTracer() or SeawaterBuoyancy(LinearEquationOfState)")
+        self.buoyancy = buoyancy
         from .closures import ScalarDiffusivity
         if closure is not None and not isinstance(closure, ScalarDiffusivity):
             raise NotImplementedError("only closure = nothing | ScalarDiffusivity(ν, κ) is on the accelerated path (SURVEY.md 8f)")
@@ -65,8 +69,23 @@ class NonhydrostaticModel:
         self.velocities = V(self._field("u"), self._field("v"), self._field("w"))
         T = namedtuple("Tracers", self.tracer_names) if self.tracer_names else tuple
         self.tracers = T(*[self._field("c%d" % n) for n in range(len(self.tracer_names))])
-        P = namedtuple("Pressures", "pNHS")
-        self.pressures = P(self._field("p"))
+        if buoyancy is not None:
+            # validate_buoyancy / tracernames (nonhydrostatic_model.jl:166-170): the formulation's tracers must exist
+            missing = [t for t in buoyancy.required_tracers if t not in self.tracer_names]
+            if missing:
+                raise ValueError(f"{buoyancy!r} requires the tracers {missing}")
+            idx = [self.tracer_names.index(t) for t in buoyancy.required_tracers]
+            if isinstance(buoyancy, BuoyancyTracer):
+                _lib.check(_lib.lib().ocn_model_set_buoyancy(self.handle, 1, idx[0], 0, 0.0, 0.0, 0.0))
+            else:
+                e = buoyancy.equation_of_state
+                _lib.check(_lib.lib().ocn_model_set_buoyancy(self.handle, 2, idx[0], idx[1], buoyancy.gravitational_acceleration,
+                                                             e.thermal_expansion, e.haline_contraction))
+            P = namedtuple("Pressures", "pNHS pHY")          # pHY′: the hydrostatic pressure anomaly (nonhydrostatic_model.jl:144-158)
+            self.pressures = P(self._field("p"), self._field("pHY"))
+        else:
+            P = namedtuple("Pressures", "pNHS")
+            self.pressures = P(self._field("p"))
         if closure is not None:
             self._kappa, kp = closure.kappa_array(self.tracer_names)
             _lib.check(_lib.lib().ocn_model_set_closure(self.handle, closure.ν, kp))

@@ -546,6 +546,58 @@ void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, con
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Buoyancy: BuoyancyTracer and SeawaterBuoyancy with a LinearEquationOfState, gravity along -z.
+ * NonhydrostaticModel separates the hydrostatic pressure anomaly pHY′ whenever buoyancy is present
+ * (nonhydrostatic_model.jl:144-158): update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-22) integrates
+ * z_dot_g_bᶜᶜᶠ = ĝ_z ℑzᵃᵃᶠ(b) (g_dot_b.jl:4, ĝ_z = 1) downwards over i = 0:Nx+1, j = 0:Ny+1 (:43-50); u and v tendencies get
+ * -∂x pHY′, -∂y pHY′ (nonhydrostatic_tendency_kernel_functions.jl:14-19,97,159), the w tendency gets no buoyancy term (:168).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { int kind; const double *b, *T, *S; double g, alpha, beta; } buoy;   /* kind 1: tracer b; 2: linear seawater */
+static inline double buoyancy_perturbation(const oro_grid *g, const buoy *B, int i, int j, int k) {
+    if (B->kind == 1) { fld b = mkfld(g, B->b, LOC_C); return AT(b, i, j, k); }                 /* buoyancy_tracer.jl:12 */
+    fld T = mkfld(g, B->T, LOC_C), S = mkfld(g, B->S, LOC_C);                                   /* linear_equation_of_state.jl:71-73 */
+    return B->g * (B->alpha * AT(T, i, j, k) - B->beta * AT(S, i, j, k));
+}
+
+void oro_update_hydrostatic_pressure(const oro_grid *g, int kind, const double *b_or_T, const double *S, double grav, double alpha,
+                                     double beta, double *pHY) {
+    if (g->topo[2] == ORO_FLAT) return;                               /* update_hydrostatic_pressure!(::ZFlatGrid) = nothing */
+    const buoy B = {kind, b_or_T, b_or_T, S, grav, alpha, beta};
+    fld P = mkfld(g, pHY, LOC_C);
+    const int Nz = g->N[2];
+    const int i0 = g->topo[0] == ORO_FLAT ? 1 : 0, i1 = g->topo[0] == ORO_FLAT ? g->N[0] : g->N[0] + 1;
+    const int j0 = g->topo[1] == ORO_FLAT ? 1 : 0, j1 = g->topo[1] == ORO_FLAT ? g->N[1] : g->N[1] + 1;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int j = j0; j <= j1; ++j)
+        for (int i = i0; i <= i1; ++i) {
+            /* z_dot_g_bᶜᶜᶠ(k) = 1 * (0.5 * (b[k-1] + b[k])) */
+            double zb = 1 * (0.5 * (buoyancy_perturbation(g, &B, i, j, Nz) + buoyancy_perturbation(g, &B, i, j, Nz + 1)));
+            AT(P, i, j, Nz) = -zb * DF(g, 2, Nz + 1);
+            for (int k = Nz - 1; k >= 1; --k) {
+                zb = 1 * (0.5 * (buoyancy_perturbation(g, &B, i, j, k) + buoyancy_perturbation(g, &B, i, j, k + 1)));
+                AT(P, i, j, k) = AT(P, i, j, k + 1) - zb * DF(g, 2, k + 1);
+            }
+        }
+}
+
+/* G_u -= ∂xᶠᶜᶜ pHY′, G_v -= ∂yᶜᶠᶜ pHY′ on tendencies holding the advective part (the terms between are zeros) */
+void oro_add_hydrostatic_pressure_gradient(const oro_grid *g, const double *pHY, double *Gu, double *Gv) {
+    fld P = mkfld(g, pHY, LOC_C), GU = mkfld(g, Gu, LOC_U), GV = mkfld(g, Gv, LOC_V);
+    int ru[6], rv[6];
+    default_range(g, LOC_U, 1, ru);
+    default_range(g, LOC_V, 1, rv);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) {
+                if (i >= ru[0] && j >= ru[2])
+                    AT(GU, i, j, k) = AT(GU, i, j, k) - (g->topo[0] == ORO_FLAT ? 0.0 : (AT(P, i, j, k) - AT(P, i - 1, j, k)) * (1.0 / DF(g, 0, i)));
+                if (i >= rv[0] && j >= rv[2])
+                    AT(GV, i, j, k) = AT(GV, i, j, k) - (g->topo[1] == ORO_FLAT ? 0.0 : (AT(P, i, j, k) - AT(P, i, j - 1, k)) * (1.0 / DF(g, 1, j)));
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
  * RK3 substep and tendency caching
  * ------------------------------------------------------------------------------------------------------------------ */
 /* TimeSteppers/runge_kutta_3.jl:212-226, launched :xyz with exclude_periphery=true (:187) */
@@ -904,6 +956,9 @@ struct oro_model {
     int any_flux_bc;
     int has_closure;
     double nu, kappa[ORO_MAXTR];
+    int buoyancy_kind, b_index, T_index, S_index;   /* 0 none, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy */
+    double grav, alpha, beta;
+    double *pHY;
     double *p;
     oro_poisson *solver;
     double time, last_dt, last_stage_dt;
@@ -946,6 +1001,7 @@ void oro_model_destroy(oro_model *m) {
     if (!m) return;
     for (int f = 0; f < 3 + m->ntr; ++f) { free(m->U[f]); free(m->Gn[f]); free(m->Gm[f]); }
     free(m->p);
+    free(m->pHY);
     oro_poisson_destroy(m->solver);
     free(m);
 }
@@ -959,13 +1015,14 @@ static int field_index(const oro_model *m, const char *name, char *kind) {
     if (!strcmp(q, "v")) return 1;
     if (!strcmp(q, "w")) return 2;
     if (q[0] == 'c') { int n = atoi(q + 1); if (n >= 0 && n < m->ntr) return 3 + n; }
-    if (!strcmp(name, "p")) { *kind = 'p'; return 0; }
+    if (!strcmp(name, "p") || !strcmp(name, "pHY")) { *kind = 'p'; return 0; }
     return -1;
 }
 
 double *oro_model_field(oro_model *m, const char *name) {
     char kind;
     int f = field_index(m, name, &kind);
+    if (!strcmp(name, "pHY")) return m->pHY;
     if (f < 0) return NULL;
     if (kind == 'p') return m->p;
     return kind == 'U' ? m->U[f] : kind == 'G' ? m->Gn[f] : m->Gm[f];
@@ -997,6 +1054,18 @@ int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double 
     return 0;
 }
 
+/* buoyancy = BuoyancyTracer() (kind 1, tracer index b) | SeawaterBuoyancy(equation_of_state = LinearEquationOfState(α, β),
+ * gravitational_acceleration = g) (kind 2, tracer indices T, S) | nothing (kind 0) */
+int oro_model_set_buoyancy(oro_model *m, int kind, int b_or_T_index, int S_index, double grav, double alpha, double beta) {
+    if (kind < 0 || kind > 2) return -1;
+    if (kind && (b_or_T_index < 0 || b_or_T_index >= m->ntr)) return -1;
+    if (kind == 2 && (S_index < 0 || S_index >= m->ntr)) return -1;
+    m->buoyancy_kind = kind; m->b_index = m->T_index = b_or_T_index; m->S_index = S_index;
+    m->grav = grav; m->alpha = alpha; m->beta = beta;
+    if (kind && !m->pHY) m->pHY = (double *)calloc(parent_len(m->g, LOC_C), sizeof(double));
+    return 0;
+}
+
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa) {
     m->nu = nu;
     m->has_closure = nu != 0.0;
@@ -1010,11 +1079,17 @@ void oro_model_set_closure(oro_model *m, double nu, const double *kappa) {
 void oro_model_update_state(oro_model *m, int compute_tendencies) {
     const oro_grid *g = m->g;
     for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions_bcs(g, m->U[f], m->loc[f], m->bcs[f], /*fill_open_bcs=*/0);
+    /* compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69) */
+    if (m->buoyancy_kind == 1)
+        oro_update_hydrostatic_pressure(g, 1, m->U[3 + m->b_index], NULL, 0, 0, 0, m->pHY);
+    else if (m->buoyancy_kind == 2)
+        oro_update_hydrostatic_pressure(g, 2, m->U[3 + m->T_index], m->U[3 + m->S_index], m->grav, m->alpha, m->beta, m->pHY);
     if (compute_tendencies) {
         oro_compute_Gu(g, m->U[0], m->U[1], m->U[2], m->Gn[0], NULL);
         oro_compute_Gv(g, m->U[0], m->U[1], m->U[2], m->Gn[1], NULL);
         oro_compute_Gw(g, m->U[0], m->U[1], m->U[2], m->Gn[2], NULL);
         for (int t = 0; t < m->ntr; ++t) oro_compute_Gc(g, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->Gn[3 + t], NULL);
+        if (m->buoyancy_kind) oro_add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1]);
         if (m->has_closure) {
             for (int f = 0; f < 3; ++f) oro_add_closure_tendency(g, f, m->U[0], m->U[1], m->U[2], NULL, m->nu, m->Gn[f], NULL);
             for (int t = 0; t < m->ntr; ++t)

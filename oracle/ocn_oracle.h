@@ -108,6 +108,12 @@ double *oro_model_field(oro_model *m, const char *name); /* "u","v","w","c0".., 
 void oro_model_field_loc(oro_model *m, const char *name, int loc[3]);
 /* side 0..5 = west, east, south, north, bottom, top; returns 0, or -1 for an invalid combination */
 int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value);
+/* buoyancy: kind 0 nothing; 1 BuoyancyTracer (tracer index b); 2 SeawaterBuoyancy with LinearEquationOfState
+ * (tracer indices T, S; b = g (α T - β S)). The model then carries the hydrostatic pressure anomaly "pHY". */
+int oro_model_set_buoyancy(oro_model *m, int kind, int b_or_T_index, int S_index, double grav, double alpha, double beta);
+void oro_update_hydrostatic_pressure(const oro_grid *g, int kind, const double *b_or_T, const double *S, double grav, double alpha,
+                                     double beta, double *pHY);
+void oro_add_hydrostatic_pressure_gradient(const oro_grid *g, const double *pHY, double *Gu, double *Gv);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) ; nu = 0 and kappa = NULL/0 -> closure = nothing */
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
 void oro_model_update_state(oro_model *m, int compute_tendencies);

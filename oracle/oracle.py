@@ -69,6 +69,9 @@ def lib():
         L.oro_compute_flux_bcs.argtypes = [vp, dp, ip, C.POINTER(BC)]
         L.oro_model_set_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_double]
         L.oro_model_set_closure.argtypes = [vp, C.c_double, dp]
+        L.oro_model_set_buoyancy.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.oro_update_hydrostatic_pressure.argtypes = [vp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, dp]
+        L.oro_add_hydrostatic_pressure_gradient.argtypes = [vp, dp, dp, dp]
         L.oro_add_closure_tendency.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_double, dp, ip]
         for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
             getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
@@ -313,6 +316,14 @@ class Model:
         loc = (C.c_int * 3)()
         lib().oro_model_field_loc(self.handle, name.encode(), loc)
         return tuple(loc)
+
+    def set_buoyancy_tracer(self, b_index=0):
+        """buoyancy = BuoyancyTracer(): tracer c<b_index> is the buoyancy"""
+        assert lib().oro_model_set_buoyancy(self.handle, 1, b_index, 0, 0.0, 0.0, 0.0) == 0
+
+    def set_seawater_buoyancy(self, T_index=0, S_index=1, g=9.80665, alpha=1.67e-4, beta=7.80e-4):
+        """buoyancy = SeawaterBuoyancy(equation_of_state = LinearEquationOfState(α, β)) with the reference's default constants"""
+        assert lib().oro_model_set_buoyancy(self.handle, 2, T_index, S_index, g, alpha, beta) == 0
 
     def set_closure(self, nu=0.0, kappa=0.0):
         """closure = ScalarDiffusivity(ν = nu, κ = kappa) -- kappa a number or one value per tracer"""

@@ -561,3 +561,59 @@ def test_quasi_adams_bashforth_2_time_stepper(oracle):
         return np.abs(gz.interior_cells(mm.field("c0")) / c0 - np.exp(-lam * dt * nsteps)).max()
     e1, e2 = decay_error(2e-4, 50), decay_error(1e-4, 100)
     assert e1 / e2 > 3.0 and e2 < 5e-6, (e1, e2)       # better than first order at these step sizes (χ = 0.1 keeps the O(χ Δt) term small)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# buoyancy: BuoyancyTracer / linear SeawaterBuoyancy with the separated hydrostatic pressure anomaly
+# ---------------------------------------------------------------------------------------------------------------------
+def test_stratified_fluid_remains_at_rest(oracle):
+    """stratified_fluid_remains_at_rest_* (test/test_dynamics.jl:263-306) with vertical gravity: b = N² z with Gradient
+    conditions N² at top and bottom, Δt = 10 minutes for one hour: ∂z b stays N² everywhere and nothing moves"""
+    N, L, N2 = 16, 2000.0, 1e-5
+    g = oracle.Grid((4, N, N), topology=(P, B, B), x=(0.0, L), y=(0.0, L), z=(-L, 0.0))
+    m = oracle.Model(g, 1)
+    m.set_buoyancy_tracer(0)
+    m.set_bc("c0", "bottom", "gradient", N2)
+    m.set_bc("c0", "top", "gradient", N2)
+    z = (-L + (np.arange(N) + 0.5) * L / N).reshape(1, 1, N)
+    m.set(u=np.zeros((4, N, N)), v=np.zeros((4, N + 1, N)), w=np.zeros((4, N, N + 1)), c0=N2 * z + np.zeros((4, N, N)))
+    for _ in range(6):
+        m.time_step(600.0)
+    b = g.interior_cells(m.field("c0"))
+    assert np.allclose(np.diff(b, axis=2) / (L / N), N2, rtol=1e-12)
+    assert all(np.abs(m.field(n)).max() == 0.0 for n in "uvw")
+    # the hydrostatic pressure anomaly balances the stratification: ∂z pHY′ = b at the faces between cells
+    p = g.interior_cells(m.field("pHY"))
+    assert np.allclose(np.diff(p, axis=2) / (L / N), 0.5 * (b[:, :, 1:] + b[:, :, :-1]), rtol=1e-12)
+
+
+def test_internal_wave_dynamics(oracle):
+    """internal_wave_dynamics_test (test/test_internal_wave_dynamics.jl:4-86, test/test_dynamics.jl:640-700) on the
+    (Periodic, Flat, Bounded) 128 x 128 grid, BuoyancyTracer, ScalarDiffusivity(ν = κ = 1e-9), here with f = 0 (Coriolis is out of
+    scope): after 10 steps of Δt = 0.01 / σ the mean-square relative error of u is below the reference's 1e-4"""
+    Lx, Nx, Nz = 2 * np.pi, 128, 128
+    g = oracle.Grid((Nx, 1, Nz), topology=(P, FLAT, B), x=(0.0, Lx), z=(-Lx, 0.0))
+    m = oracle.Model(g, 1)
+    m.set_buoyancy_tracer(0)
+    m.set_closure(nu=1e-9, kappa=1e-9)
+    z0, d, a0, mz, kx, NN = -Lx / 3, Lx / 20, 1e-3, 16, 1, 1.0
+    sig = np.sqrt(NN ** 2 * kx ** 2 / (kx ** 2 + mz ** 2))
+    dt = 0.01 / sig
+    cg = mz * sig / (kx ** 2 + mz ** 2) * (0 - 1)
+    U, W, Bm = a0 * kx * sig / sig ** 2, a0 * mz * sig / (sig ** 2 - NN ** 2), a0 * mz * NN ** 2 / (sig ** 2 - NN ** 2)
+
+    def env(z, t):
+        return np.exp(-(z - cg * t - z0) ** 2 / (2 * d) ** 2)
+    xc, xf = ((np.arange(Nx) + 0.5) * Lx / Nx).reshape(Nx, 1, 1), (np.arange(Nx) * Lx / Nx).reshape(Nx, 1, 1)
+    zc, zf = (-Lx + (np.arange(Nz) + 0.5) * Lx / Nz).reshape(1, 1, Nz), (-Lx + np.arange(Nz + 1) * Lx / Nz).reshape(1, 1, Nz + 1)
+
+    def u_exact(t):
+        return env(zc, t) * U * np.cos(kx * xf + mz * zc - sig * t)
+    m.set(u=u_exact(0.0), v=np.zeros((Nx, 1, Nz)), w=env(zf, 0) * W * np.cos(kx * xc + mz * zf),
+          c0=env(zc, 0) * Bm * np.sin(kx * xc + mz * zc) + NN ** 2 * zc)
+    for _ in range(10):
+        m.time_step(dt)
+    u = g.interior(m.field("u"), (1, 0, 0))
+    ue = u_exact(m.time)
+    assert np.mean((u - ue) ** 2) / np.mean(ue ** 2) < 1e-4
+    assert np.mean((u - u_exact(0.0)) ** 2) / np.mean(ue ** 2) > 1e-4        # the wave did propagate
