@@ -237,11 +237,21 @@ class DeviceBackend:
     def swap_tendencies(self):
         self.Gn, self.Gm = self.Gm, self.Gn
 
+    def set_buoyancy(self, buoyancy, tracer_names):
+        self.buoyancy, self.tracer_names = buoyancy, tuple(tracer_names)
+        self.pHY = Field((Center,) * 3, self.grid.local)
+
+    def update_hydrostatic_pressure(self):
+        if getattr(self, "buoyancy", None) is not None:
+            from . import kernels
+            kernels.update_hydrostatic_pressure(self.grid.local, self.buoyancy, dict(zip(self.tracer_names, self.U[3:])), self.pHY)
+
     def can_fuse_substep(self):
         g = self.grid.local
         no_flux = not any(bc.classification == "Flux" and bc.condition != 0.0
                           for fb in getattr(self, "bcs", {}).values() for bc in fb.sides.values())
-        return no_flux and getattr(self, "closure", None) is None and g.topology[1] is not Bounded and self.ntracers <= 3
+        return (no_flux and getattr(self, "closure", None) is None and getattr(self, "buoyancy", None) is None and
+                g.topology[1] is not Bounded and self.ntracers <= 3)
 
     def swap_prognostic(self):
         """after a fused evaluation: the updated fields become the live ones (list contents swap, Field objects stay)"""
@@ -265,6 +275,8 @@ class DeviceBackend:
         if ev:
             ev[1].record()
             self.events.append(ev)
+        if getattr(self, "buoyancy", None) is not None:
+            kernels.add_hydrostatic_pressure_gradient(self.grid.local, self.pHY, self.Gn[0], self.Gn[1], kernel_parameters=rng)
         if getattr(self, "closure", None) is not None:
             kernels.compute_closure_tendencies(self.grid.local, self.U, self.Gn, self.closure, self.tracer_names, kernel_parameters=rng)
 
@@ -323,7 +335,7 @@ class DistributedNonhydrostaticModel:
     """NonhydrostaticModel on a Distributed architecture (x-slabs): WENO(order=5), RK3, DistributedFFTBasedPoissonSolver."""
 
     def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None,
-                 boundary_conditions=None, closure=None):
+                 boundary_conditions=None, closure=None, buoyancy=None):
         if advection is not None and not isinstance(advection, WENO):
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
         self.grid, self.ctx = grid, grid.ctx
@@ -334,6 +346,11 @@ class DistributedNonhydrostaticModel:
         self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
         if closure is not None:
             self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
+        if buoyancy is not None:
+            missing = [t for t in buoyancy.required_tracers if t not in self.tracer_names]
+            if missing:
+                raise ValueError(f"{buoyancy!r} requires the tracers {missing}")
+            self.backend.set_buoyancy(buoyancy, self.tracer_names)
         if boundary_conditions:
             names = ["u", "v", "w"] + list(self.tracer_names)
             self.backend.set_boundary_conditions({names.index(n): fb for n, fb in boundary_conditions.items()})
@@ -394,8 +411,12 @@ def update_state(model, compute_tendencies=True):
     g = model.grid.local
     if compute_tendencies and hasattr(b, "n_evals"):
         b.n_evals += 1
-    if not compute_tendencies or ctx.world == 1 or not model.async_halos or g.Nx <= 2 * g.Hx:
+    # with buoyancy, pHY′ in the x-halo columns needs the exchanged tracers: fill, integrate, then evaluate (no overlap)
+    if (not compute_tendencies or ctx.world == 1 or not model.async_halos or g.Nx <= 2 * g.Hx or
+            getattr(b, "buoyancy", None) is not None):
         fill_halo_regions(model, b.U, fill_open_bcs=False)
+        if hasattr(b, "update_hydrostatic_pressure"):
+            b.update_hydrostatic_pressure()           # compute_auxiliaries! (update_nonhydrostatic_model_state.jl:58-69)
         if compute_tendencies:
             b.compute_tendencies(None)
             if hasattr(b, "flux_bc_tendencies"):

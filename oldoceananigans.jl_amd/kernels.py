@@ -50,6 +50,23 @@ def compute_closure_tendencies(grid, fields, Gn, closure, tracer_names, kernel_p
         Gn[0].data, Gn[1].data, Gn[2].data, _ptr_array(gc) if gc else None, _range(kernel_parameters)))
 
 
+def update_hydrostatic_pressure(grid, buoyancy, tracers_by_name, pHY):
+    """update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-49) for BuoyancyTracer | linear SeawaterBuoyancy"""
+    from .buoyancy import BuoyancyTracer
+    if isinstance(buoyancy, BuoyancyTracer):
+        _lib.check(_lib.lib().ocn_update_hydrostatic_pressure(grid.handle, 1, tracers_by_name["b"].data, None, 0.0, 0.0, 0.0, pHY.data))
+    else:
+        e = buoyancy.equation_of_state
+        _lib.check(_lib.lib().ocn_update_hydrostatic_pressure(grid.handle, 2, tracers_by_name["T"].data, tracers_by_name["S"].data,
+                                                              buoyancy.gravitational_acceleration, e.thermal_expansion,
+                                                              e.haline_contraction, pHY.data))
+
+
+def add_hydrostatic_pressure_gradient(grid, pHY, Gu, Gv, kernel_parameters=None):
+    """-∂x pHY′, -∂y pHY′ of the u, v tendencies"""
+    _lib.check(_lib.lib().ocn_add_hydrostatic_pressure_gradient(grid.handle, pHY.data, Gu.data, Gv.data, _range(kernel_parameters)))
+
+
 def rk3_substep(grid, fields, Gn, Gm, Δt, γ, ζ):
     """rk3_substep_field! over a tuple of fields (ζ = None -> first stage)"""
     _lib.check(_lib.lib().ocn_rk3_substep(grid.handle, _ptr_array(fields), _ptr_array(Gn), _ptr_array(Gm),

@@ -32,6 +32,10 @@ def _bcs(ocn, zkind):
             "T": F(top=ocn.FluxBoundaryCondition(5e-3), bottom=ocn.GradientBoundaryCondition(0.4))}
 
 
+def _tracers_and_buoyancy(ocn, zkind):
+    return (("T", "S"), ocn.SeawaterBuoyancy()) if zkind == "bounded" else (("T", "S"), None)
+
+
 def _closure(ocn, zkind):
     return ocn.ScalarDiffusivity(ν=2e-3, κ={"T": 1e-3, "S": 5e-4}) if zkind == "bounded" else None
 
@@ -49,7 +53,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
             z, topo = _z_and_topology(ocn, zkind, size[2])
             grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
             model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind),
-                                                        closure=_closure(ocn, zkind))
+                                                        closure=_closure(ocn, zkind), buoyancy=_tracers_and_buoyancy(ocn, zkind)[1])
             model.async_halos = async_halos
             flds = model.fields()
             vals = {n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()}
@@ -91,7 +95,8 @@ def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_h
     # single-GPU product model on the global grid
     z, topo = _z_and_topology(ocn, zkind, size[2])
     grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
-    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
+                                    buoyancy=_tracers_and_buoyancy(ocn, zkind)[1])
     ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
     dt = 0.1 * grid.Δxᶜᵃᵃ / 0.6
     for _ in range(nsteps):
