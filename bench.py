@@ -123,9 +123,11 @@ def main():
     ap.add_argument("--size", type=int, default=256, help="cells per side per GPU")
     ap.add_argument("--tendency-impl", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched"],
+    ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched", "ppb_physics"],
                     help="ppp: BASELINE.json configs[1] (the metric's configuration, default); ppb_stretched: configs[2], "
-                         "256x256x128 (Periodic, Periodic, Bounded) with tanh-stretched z (Fourier-tridiagonal solver), single GPU")
+                         "256x256x128 (Periodic, Periodic, Bounded) with tanh-stretched z (Fourier-tridiagonal solver), single GPU; "
+                         "ppb_physics: the same grid with the SURVEY 8f.1 physics switched on -- ScalarDiffusivity, linear "
+                         "SeawaterBuoyancy (hydrostatic pressure anomaly), surface Flux / bottom Gradient boundary conditions")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -152,13 +154,19 @@ def main():
         dist.set_model(model, **vals)
     else:
         arch = ocn.GPU(local_rank)
-        if args.workload == "ppb_stretched":
+        physics = {}
+        if args.workload in ("ppb_stretched", "ppb_physics"):
             from helpers import tanh_faces
             grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
                                        topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+            if args.workload == "ppb_physics":
+                F = ocn.FieldBoundaryConditions
+                physics = dict(closure=ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4), buoyancy=ocn.SeawaterBuoyancy(),
+                               boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                                    "T": F(top=ocn.FluxBoundaryCondition(1e-4), bottom=ocn.GradientBoundaryCondition(0.01))})
         else:
             grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
-        model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+        model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"), **physics)
         step = lambda dt: ocn.time_step(model, dt)            # noqa: E731
         barrier = lambda: None                                # noqa: E731
         ocn.set_model(model, **initial_state(ocn, model))
@@ -207,7 +215,7 @@ def main():
         ctx.dist.destroy_process_group()
     if rank != 0:
         return
-    cells = float(N) ** 3 * world * (0.5 if args.workload == "ppb_stretched" else 1.0)
+    cells = float(N) ** 3 * world * (1.0 if args.workload == "ppp" else 0.5)
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
@@ -224,7 +232,9 @@ def main():
                                 "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])")
                    if args.workload == "ppp" else
                    (f"{N}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
-                    "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])"),
+                    "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +
+                    ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
+                     if args.workload == "ppb_physics" else "")),
                    "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}), RCCL halo + all-to-all transposes",
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
