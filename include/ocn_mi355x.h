@@ -129,6 +129,10 @@ int ocn_update_hydrostatic_pressure(ocn_grid_t grid, int kind, const double *bT,
                                     double *pHY);
 int ocn_add_hydrostatic_pressure_gradient(ocn_grid_t grid, const double *pHY, double *Gu, double *Gv, const int *range);
 
+/* coriolis = FPlane(f) (Coriolis/f_plane.jl:48-52): G_u -= x_f_cross_U = -f active_weighted_ℑxyᶠᶜᶜ(v), G_v -=
+ * y_f_cross_U = f active_weighted_ℑxyᶜᶠᶜ(u) (Operators/interpolation_operators.jl:116-130), on tendencies holding the advective part */
+int ocn_add_fplane_coriolis(ocn_grid_t grid, double f, const double *u, const double *v, double *Gu, double *Gv, const int *range);
+
 /* closure = ScalarDiffusivity(ν, κ): isotropic, constant, explicit (SURVEY.md 8f.1 -- the first "next" row).
  * ∂ⱼ_τ₁ⱼ / ∂ⱼ_τ₂ⱼ / ∂ⱼ_τ₃ⱼ / ∇_dot_qᶜ (TurbulenceClosures/closure_kernel_operators.jl:22-48) with viscous_flux_* = -2 ν Σᵢⱼ and
  * diffusive_flux_* = -κ ∂c (abstract_scalar_diffusivity_closure.jl:194-242). ADDS the closure term to tendencies that already
@@ -248,6 +252,8 @@ int ocn_model_get_option(ocn_model_t model, const char *key, int *value);
  * (kind 2, tracer indices of T and S). With buoyancy the model carries the hydrostatic pressure anomaly, field name "pHY"
  * (nonhydrostatic_model.jl:144-158). */
 int ocn_model_set_buoyancy(ocn_model_t model, int kind, int b_or_T_index, int S_index, double g, double alpha, double beta);
+/* coriolis = FPlane(f = f) of the model constructor; enabled = 0: coriolis = nothing */
+int ocn_model_set_coriolis(ocn_model_t model, int enabled, double f);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) of the model constructor; all zeros / NULL: closure = nothing */
 int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);

@@ -8,7 +8,7 @@ from .advection import WENO
 from .architectures import GPU, architecture, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
-from .buoyancy import BuoyancyTracer, LinearEquationOfState, SeawaterBuoyancy
+from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
 from .closures import ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid

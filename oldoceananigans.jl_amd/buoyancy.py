@@ -32,3 +32,16 @@ class SeawaterBuoyancy:
         e = self.equation_of_state
         return (f"SeawaterBuoyancy(g={self.gravitational_acceleration}, LinearEquationOfState(α={e.thermal_expansion}, "
                 f"β={e.haline_contraction}))")
+
+
+class FPlane:
+    """FPlane(f = ...) | FPlane(rotation_rate = Ω, latitude = φ): f = 2 Ω sind(φ) (Coriolis/f_plane.jl:13-44)"""
+
+    def __init__(self, f=None, rotation_rate=7.292115e-5, latitude=None):
+        import math
+        if (f is None) == (latitude is None):
+            raise ValueError("Either both keywords rotation_rate and latitude must be specified, *or* only f must be specified.")
+        self.f = float(f) if f is not None else 2 * rotation_rate * math.sin(math.radians(latitude))
+
+    def __repr__(self):
+        return f"FPlane(f={self.f})"

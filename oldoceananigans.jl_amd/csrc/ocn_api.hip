@@ -531,6 +531,22 @@ extern "C" int ocn_add_hydrostatic_pressure_gradient(ocn_grid_t grid, const doub
     return add_hydrostatic_pressure_gradient(grid->d, pHY, Gu, Gv, range);
 }
 
+static int add_fplane_coriolis(const DGrid &g, double f, const double *u, const double *v, double *Gu, double *Gv, const int *range) {
+    Range6 ru, rv;
+    int rc;
+    if ((rc = check_range(g, range, &ru, LOC_U, true)) || (rc = check_range(g, range, &rv, LOC_V, true))) return rc;
+    hipLaunchKernelGGL(fplane_coriolis_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, f, make_view(g, u, LOC_U),
+                       make_view(g, v, LOC_V), make_view(g, Gu, LOC_U), make_view(g, Gv, LOC_V), ru, rv);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_add_fplane_coriolis(ocn_grid_t grid, double f, const double *u, const double *v, double *Gu, double *Gv, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !Gu || !Gv) return fail(OCN_EINVAL, "NULL argument");
+    return add_fplane_coriolis(grid->d, f, u, v, Gu, Gv, range);
+}
+
 static int closure_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr, int ntr,
                               double nu, const double *kappa, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range) {
     const FView vu = make_view(g, u, LOC_U), vv = make_view(g, v, LOC_V), vw = make_view(g, w, LOC_W);
@@ -1475,6 +1491,8 @@ struct ocn_model_s {
     bool any_bc = false, any_flux_bc = false;
     bool has_closure = false;               // closure = ScalarDiffusivity(ν, κ)
     double nu = 0.0, kappa[OCN_MAX_FIELDS] = {};
+    bool has_coriolis = false;              // coriolis = FPlane(f)
+    double fcor = 0.0;
     int buoyancy_kind = 0, bT_index = 0, S_index = 0;    // 0 nothing, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy
     double grav = 0.0, alpha = 0.0, beta = 0.0;
     double *pHY = nullptr;                  // hydrostatic pressure anomaly (only with buoyancy)
@@ -1600,7 +1618,7 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
 }
 
 static bool can_fuse_substep(const ocn_model_s *m) {
-    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure && !m->buoyancy_kind &&
+    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure && !m->buoyancy_kind && !m->has_coriolis &&
            fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
 
@@ -1638,6 +1656,7 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl, sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
+        if (!rc && m->has_coriolis) rc = add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1], nullptr);
         if (!rc && m->buoyancy_kind) rc = add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1], nullptr);
         if (!rc && m->has_closure)
             rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1], m->Gn[2],
@@ -1685,6 +1704,13 @@ extern "C" int ocn_model_set_buoyancy(ocn_model_t m, int kind, int b_or_T_index,
     }
     m->buoyancy_kind = kind; m->bT_index = b_or_T_index; m->S_index = kind == 2 ? S_index : b_or_T_index;
     m->grav = grav; m->alpha = alpha; m->beta = beta;
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_set_coriolis(ocn_model_t m, int enabled, double f) {
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    m->has_coriolis = enabled != 0;
+    m->fcor = f;
     return OCN_OK;
 }
 

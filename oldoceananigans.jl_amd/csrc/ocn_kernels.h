@@ -214,6 +214,45 @@ __global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FVie
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// coriolis = FPlane(f) (Coriolis/f_plane.jl:48-52): x_f_cross_U = -f active_weighted_ℑxyᶠᶜᶜ(v), y_f_cross_U =
+// f active_weighted_ℑxyᶜᶠᶜ(u). The active-weighted average (Operators/interpolation_operators.jl:116-130) divides the four-point
+// average by the fraction of non-peripheral nodes (Grids/inactive_node.jl:152-156). G_u -= x_f_cross_U, G_v -= y_f_cross_U on
+// tendencies holding the advective part.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inactive_cell(const DGrid &g, int i, int j, int k) {
+    return (g.tx == OCN_BOUNDED && (i < 1 || i > g.Nx)) | (g.ty == OCN_BOUNDED && (j < 1 || j > g.Ny)) |
+           (g.tz == OCN_BOUNDED && (k < 1 || k > g.Nz));
+}
+
+__global__ void __launch_bounds__(256) fplane_coriolis_kernel(DGrid g, double f, FView u, FView v, FView Gu, FView Gv, Range6 ru, Range6 rv) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
+    if (i >= ru.i0 && i <= ru.i1 && j >= ru.j0 && j <= ru.j1 && k >= ru.k0 && k <= ru.k1) {
+        // ℑxyᶠᶜᵃ = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ ·): X(jj) = 0.5 (q[i-1, jj] + q[i, jj]); 0.5 (X(j) + X(j+1)); not_peripheral at (c, f, c)
+        auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii, jj - 1, k)) ? 1.0 : 0.0; };
+        auto Xq = [&](int jj) { return fx ? v.at(i, jj, k) : 0.5 * (v.at(i - 1, jj, k) + v.at(i, jj, k)); };
+        auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i - 1, jj) + np(i, jj)); };
+        const double qa = fy ? Xq(j) : 0.5 * (Xq(j) + Xq(j + 1));
+        const double an = fy ? Xn(j) : 0.5 * (Xn(j) + Xn(j + 1));
+        const double aw = an == 0 ? 0.0 : qa / an;
+        Gu.at(i, j, k) = Gu.at(i, j, k) - (-f * aw);
+    }
+    if (i >= rv.i0 && i <= rv.i1 && j >= rv.j0 && j <= rv.j1 && k >= rv.k0 && k <= rv.k1) {
+        // ℑxyᶜᶠᵃ = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ ·): X(jj) = 0.5 (q[i, jj] + q[i+1, jj]); 0.5 (X(j-1) + X(j)); not_peripheral at (f, c, c)
+        auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii - 1, jj, k)) ? 1.0 : 0.0; };
+        auto Xq = [&](int jj) { return fx ? u.at(i, jj, k) : 0.5 * (u.at(i, jj, k) + u.at(i + 1, jj, k)); };
+        auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i, jj) + np(i + 1, jj)); };
+        const double qa = fy ? Xq(j) : 0.5 * (Xq(j - 1) + Xq(j));
+        const double an = fy ? Xn(j) : 0.5 * (Xn(j - 1) + Xn(j));
+        const double aw = an == 0 ? 0.0 : qa / an;
+        Gv.at(i, j, k) = Gv.at(i, j, k) - (f * aw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // halo fills (src/BoundaryConditions). One launch handles up to OCN_MAX_FIELDS fields of identical parent shape.
 // ---------------------------------------------------------------------------------------------------------------------
 struct FieldList {

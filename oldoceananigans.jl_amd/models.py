@@ -48,10 +48,12 @@ class NonhydrostaticModel:
         if timestepper not in ("RungeKutta3", "QuasiAdamsBashforth2"):
             raise NotImplementedError("timestepper must be :RungeKutta3 (hot path) or :QuasiAdamsBashforth2 (SURVEY.md 8f.1)")
         self.timestepper, self.χ = timestepper, 0.1          # QuasiAdamsBashforth2TimeStepper(χ = 0.1)
-        for name, val in (("coriolis", coriolis), ("forcing", forcing)):
-            if val is not None:
-                raise NotImplementedError(f"{name} != nothing is outside the accelerated hot path (SURVEY.md 8f)")
-        from .buoyancy import BuoyancyTracer, SeawaterBuoyancy
+        if forcing is not None:
+            raise NotImplementedError("forcing != nothing is outside the accelerated hot path (SURVEY.md 8f)")
+        from .buoyancy import BuoyancyTracer, FPlane, SeawaterBuoyancy
+        if coriolis is not None and not isinstance(coriolis, FPlane):
+            raise NotImplementedError("coriolis must be nothing or FPlane(f)")
+        self.coriolis = coriolis
         if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
             raise NotImplementedError("buoyancy must be nothing, BuoyancyTracer() or SeawaterBuoyancy(LinearEquationOfState)")
         self.buoyancy = buoyancy
@@ -86,6 +88,8 @@ class NonhydrostaticModel:
         else:
             P = namedtuple("Pressures", "pNHS")
             self.pressures = P(self._field("p"))
+        if coriolis is not None:
+            _lib.check(_lib.lib().ocn_model_set_coriolis(self.handle, 1, coriolis.f))
         if closure is not None:
             self._kappa, kp = closure.kappa_array(self.tracer_names)
             _lib.check(_lib.lib().ocn_model_set_closure(self.handle, closure.ν, kp))

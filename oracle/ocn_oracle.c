@@ -598,6 +598,60 @@ void oro_add_hydrostatic_pressure_gradient(const oro_grid *g, const double *pHY,
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * coriolis = FPlane(f) (Coriolis/f_plane.jl:48-52): x_f_cross_U = -f * active_weighted_ℑxyᶠᶜᶜ(v),
+ * y_f_cross_U = f * active_weighted_ℑxyᶜᶠᶜ(u), z = 0. The active-weighted average (Operators/interpolation_operators.jl:116-130)
+ * divides the four-point average by the fraction of nodes that are not peripheral (Grids/inactive_node.jl:152-156: a node is
+ * peripheral when one of the cells it touches lies outside a Bounded direction); interpolation along a Flat direction is the identity.
+ * Added to tendencies holding the advective part: G_u = G_u - x_f_cross_U, G_v = G_v - y_f_cross_U.
+ * ------------------------------------------------------------------------------------------------------------------ */
+static inline int inactive_cell(const oro_grid *g, int i, int j, int k) {
+    return (g->topo[0] == ORO_BOUNDED && (i < 1 || i > g->N[0])) | (g->topo[1] == ORO_BOUNDED && (j < 1 || j > g->N[1])) |
+           (g->topo[2] == ORO_BOUNDED && (k < 1 || k > g->N[2]));
+}
+/* not_peripheral_node at (c, f, c) [v nodes] and (f, c, c) [u nodes], as a Float64 0 / 1 */
+static inline double np_cfc(const oro_grid *g, int i, int j, int k) { return !(inactive_cell(g, i, j, k) | inactive_cell(g, i, j - 1, k)) ? 1.0 : 0.0; }
+static inline double np_fcc(const oro_grid *g, int i, int j, int k) { return !(inactive_cell(g, i, j, k) | inactive_cell(g, i - 1, j, k)) ? 1.0 : 0.0; }
+
+void oro_add_fplane_coriolis(const oro_grid *g, double f, const double *u, const double *v, double *Gu, double *Gv) {
+    fld U = mkfld(g, u, LOC_U), V = mkfld(g, v, LOC_V), GU = mkfld(g, Gu, LOC_U), GV = mkfld(g, Gv, LOC_V);
+    const int fx = g->topo[0] == ORO_FLAT, fy = g->topo[1] == ORO_FLAT;
+    int ru[6], rv[6];
+    default_range(g, LOC_U, 1, ru);
+    default_range(g, LOC_V, 1, rv);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) {
+                if (i >= ru[0] && j >= ru[2]) {
+                    /* ℑxyᶠᶜᵃ(q) = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ q): 0.5 * (X(j) + X(j+1)), X(j) = 0.5 * (q[i-1, j] + q[i, j]) */
+#define XF(F, jj) (fx ? F(i, jj) : 0.5 * (F(i - 1, jj) + F(i, jj)))
+#define VV(ii, jj) AT(V, ii, jj, k)
+#define NPV(ii, jj) np_cfc(g, ii, jj, k)
+                    const double qa = fy ? XF(VV, j) : 0.5 * (XF(VV, j) + XF(VV, j + 1));
+                    const double an = fy ? XF(NPV, j) : 0.5 * (XF(NPV, j) + XF(NPV, j + 1));
+                    const double aw = an == 0 ? 0.0 : qa / an;
+                    AT(GU, i, j, k) = AT(GU, i, j, k) - (-f * aw);
+#undef XF
+#undef VV
+#undef NPV
+                }
+                if (i >= rv[0] && j >= rv[2]) {
+                    /* ℑxyᶜᶠᵃ(q) = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ q): 0.5 * (X(j-1) + X(j)), X(j) = 0.5 * (q[i, j] + q[i+1, j]) */
+#define XC(F, jj) (fx ? F(i, jj) : 0.5 * (F(i, jj) + F(i + 1, jj)))
+#define UU(ii, jj) AT(U, ii, jj, k)
+#define NPU(ii, jj) np_fcc(g, ii, jj, k)
+                    const double qa = fy ? XC(UU, j) : 0.5 * (XC(UU, j - 1) + XC(UU, j));
+                    const double an = fy ? XC(NPU, j) : 0.5 * (XC(NPU, j - 1) + XC(NPU, j));
+                    const double aw = an == 0 ? 0.0 : qa / an;
+                    AT(GV, i, j, k) = AT(GV, i, j, k) - (f * aw);
+#undef XC
+#undef UU
+#undef NPU
+                }
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
  * RK3 substep and tendency caching
  * ------------------------------------------------------------------------------------------------------------------ */
 /* TimeSteppers/runge_kutta_3.jl:212-226, launched :xyz with exclude_periphery=true (:187) */
@@ -956,6 +1010,8 @@ struct oro_model {
     int any_flux_bc;
     int has_closure;
     double nu, kappa[ORO_MAXTR];
+    int has_coriolis;
+    double fcor;
     int buoyancy_kind, b_index, T_index, S_index;   /* 0 none, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy */
     double grav, alpha, beta;
     double *pHY;
@@ -1066,6 +1122,8 @@ int oro_model_set_buoyancy(oro_model *m, int kind, int b_or_T_index, int S_index
     return 0;
 }
 
+void oro_model_set_coriolis(oro_model *m, int has, double f) { m->has_coriolis = has; m->fcor = f; }
+
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa) {
     m->nu = nu;
     m->has_closure = nu != 0.0;
@@ -1089,6 +1147,7 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
         oro_compute_Gv(g, m->U[0], m->U[1], m->U[2], m->Gn[1], NULL);
         oro_compute_Gw(g, m->U[0], m->U[1], m->U[2], m->Gn[2], NULL);
         for (int t = 0; t < m->ntr; ++t) oro_compute_Gc(g, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->Gn[3 + t], NULL);
+        if (m->has_coriolis) oro_add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1]);
         if (m->buoyancy_kind) oro_add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1]);
         if (m->has_closure) {
             for (int f = 0; f < 3; ++f) oro_add_closure_tendency(g, f, m->U[0], m->U[1], m->U[2], NULL, m->nu, m->Gn[f], NULL);

@@ -114,6 +114,9 @@ int oro_model_set_buoyancy(oro_model *m, int kind, int b_or_T_index, int S_index
 void oro_update_hydrostatic_pressure(const oro_grid *g, int kind, const double *b_or_T, const double *S, double grav, double alpha,
                                      double beta, double *pHY);
 void oro_add_hydrostatic_pressure_gradient(const oro_grid *g, const double *pHY, double *Gu, double *Gv);
+/* coriolis = FPlane(f) (Coriolis/f_plane.jl:48-52); has = 0: coriolis = nothing */
+void oro_model_set_coriolis(oro_model *m, int has, double f);
+void oro_add_fplane_coriolis(const oro_grid *g, double f, const double *u, const double *v, double *Gu, double *Gv);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) ; nu = 0 and kappa = NULL/0 -> closure = nothing */
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
 void oro_model_update_state(oro_model *m, int compute_tendencies);

@@ -69,6 +69,8 @@ def lib():
         L.oro_compute_flux_bcs.argtypes = [vp, dp, ip, C.POINTER(BC)]
         L.oro_model_set_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_double]
         L.oro_model_set_closure.argtypes = [vp, C.c_double, dp]
+        L.oro_model_set_coriolis.argtypes = [vp, C.c_int, C.c_double]
+        L.oro_add_fplane_coriolis.argtypes = [vp, C.c_double, dp, dp, dp, dp]
         L.oro_model_set_buoyancy.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]
         L.oro_update_hydrostatic_pressure.argtypes = [vp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, dp]
         L.oro_add_hydrostatic_pressure_gradient.argtypes = [vp, dp, dp, dp]
@@ -324,6 +326,10 @@ class Model:
     def set_seawater_buoyancy(self, T_index=0, S_index=1, g=9.80665, alpha=1.67e-4, beta=7.80e-4):
         """buoyancy = SeawaterBuoyancy(equation_of_state = LinearEquationOfState(α, β)) with the reference's default constants"""
         assert lib().oro_model_set_buoyancy(self.handle, 2, T_index, S_index, g, alpha, beta) == 0
+
+    def set_coriolis(self, f):
+        """coriolis = FPlane(f = f)"""
+        lib().oro_model_set_coriolis(self.handle, 1, float(f))
 
     def set_closure(self, nu=0.0, kappa=0.0):
         """closure = ScalarDiffusivity(ν = nu, κ = kappa) -- kappa a number or one value per tracer"""

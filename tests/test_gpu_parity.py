@@ -456,3 +456,30 @@ def test_buoyancy_matches_oracle(ocn, oracle, arch, kind, topology, size):
         assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
     with pytest.raises(ValueError):
         ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T",), buoyancy=ocn.SeawaterBuoyancy())
+
+
+@pytest.mark.parametrize("topology,size", [(("Periodic", "Periodic", "Bounded"), (16, 12, 10)), (("Bounded", "Bounded", "Bounded"), (9, 8, 7)),
+                                           (("Periodic", "Flat", "Bounded"), (16, 1, 12)), (("Bounded", "Periodic", "Periodic"), (10, 8, 8))])
+def test_fplane_coriolis_matches_oracle(ocn, oracle, arch, topology, size):
+    """coriolis = FPlane(f) with the active-weighted averages next to walls: tendencies bit-identical, 10 steps 1e-12"""
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else (0.0, 1.0)
+    topo_cls = tuple(getattr(ocn, t) for t in topology)
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo_cls)
+    g_cpu = oracle.Grid(size, topology=tuple({"Periodic": 0, "Bounded": 1, "Flat": 3}[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T", "S"), coriolis=ocn.FPlane(f=0.7))
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_coriolis(0.7)
+    set_both(ocn, m_gpu, m_cpu, seed=5, enforce_incompressibility=False)
+    ocn.update_state(m_gpu, True)
+    m_cpu.update_state(True)
+    for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+        assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), n
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.05 * min(d for d, t in zip((g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))), topology) if t != "Flat") / 0.6
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    core = tuple(slice(None) if t == "Flat" else slice(3, -3) for t in topology)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
+    assert ocn.FPlane(latitude=45).f == 2 * 7.292115e-5 * np.sin(np.pi / 4)

@@ -587,30 +587,37 @@ def test_stratified_fluid_remains_at_rest(oracle):
     assert np.allclose(np.diff(p, axis=2) / (L / N), 0.5 * (b[:, :, 1:] + b[:, :, :-1]), rtol=1e-12)
 
 
-def test_internal_wave_dynamics(oracle):
-    """internal_wave_dynamics_test (test/test_internal_wave_dynamics.jl:4-86, test/test_dynamics.jl:640-700) on the
-    (Periodic, Flat, Bounded) 128 x 128 grid, BuoyancyTracer, ScalarDiffusivity(ν = κ = 1e-9), here with f = 0 (Coriolis is out of
-    scope): after 10 steps of Δt = 0.01 / σ the mean-square relative error of u is below the reference's 1e-4"""
+@pytest.mark.parametrize("f,ytopo", [(0.2, FLAT), (0.2, P), (0.0, FLAT)])
+def test_internal_wave_dynamics(oracle, f, ytopo):
+    """internal_wave_dynamics_test (test/test_internal_wave_dynamics.jl:4-86, test/test_dynamics.jl:640-700) AS THE REFERENCE RUNS IT:
+    (Periodic, Flat | Periodic, Bounded) 128 x 128 grid, BuoyancyTracer, FPlane(f = 0.2), ScalarDiffusivity(ν = κ = 1e-9), 10 steps
+    of Δt = 0.01 / σ: the mean-square relative error of u stays below the reference's 1e-4 (f = 0: the pure gravity wave)"""
     Lx, Nx, Nz = 2 * np.pi, 128, 128
-    g = oracle.Grid((Nx, 1, Nz), topology=(P, FLAT, B), x=(0.0, Lx), z=(-Lx, 0.0))
+    Ny = 1 if ytopo == FLAT else 4
+    g = oracle.Grid((Nx, Ny, Nz), topology=(P, ytopo, B), x=(0.0, Lx), y=(0.0, Lx), z=(-Lx, 0.0))
     m = oracle.Model(g, 1)
     m.set_buoyancy_tracer(0)
     m.set_closure(nu=1e-9, kappa=1e-9)
+    if f:
+        m.set_coriolis(f)
     z0, d, a0, mz, kx, NN = -Lx / 3, Lx / 20, 1e-3, 16, 1, 1.0
-    sig = np.sqrt(NN ** 2 * kx ** 2 / (kx ** 2 + mz ** 2))
+    sig = np.sqrt((NN ** 2 * kx ** 2 + f ** 2 * mz ** 2) / (kx ** 2 + mz ** 2))
     dt = 0.01 / sig
-    cg = mz * sig / (kx ** 2 + mz ** 2) * (0 - 1)
-    U, W, Bm = a0 * kx * sig / sig ** 2, a0 * mz * sig / (sig ** 2 - NN ** 2), a0 * mz * NN ** 2 / (sig ** 2 - NN ** 2)
+    cg = mz * sig / (kx ** 2 + mz ** 2) * (f ** 2 / sig ** 2 - 1)
+    U, V = a0 * kx * sig / (sig ** 2 - f ** 2), a0 * kx * f / (sig ** 2 - f ** 2)
+    W, Bm = a0 * mz * sig / (sig ** 2 - NN ** 2), a0 * mz * NN ** 2 / (sig ** 2 - NN ** 2)
 
     def env(z, t):
         return np.exp(-(z - cg * t - z0) ** 2 / (2 * d) ** 2)
     xc, xf = ((np.arange(Nx) + 0.5) * Lx / Nx).reshape(Nx, 1, 1), (np.arange(Nx) * Lx / Nx).reshape(Nx, 1, 1)
     zc, zf = (-Lx + (np.arange(Nz) + 0.5) * Lx / Nz).reshape(1, 1, Nz), (-Lx + np.arange(Nz + 1) * Lx / Nz).reshape(1, 1, Nz + 1)
 
+    one, onew = np.ones((Nx, Ny, Nz)), np.ones((Nx, Ny, Nz + 1))
+
     def u_exact(t):
-        return env(zc, t) * U * np.cos(kx * xf + mz * zc - sig * t)
-    m.set(u=u_exact(0.0), v=np.zeros((Nx, 1, Nz)), w=env(zf, 0) * W * np.cos(kx * xc + mz * zf),
-          c0=env(zc, 0) * Bm * np.sin(kx * xc + mz * zc) + NN ** 2 * zc)
+        return env(zc, t) * U * np.cos(kx * xf + mz * zc - sig * t) * one
+    m.set(u=u_exact(0.0), v=env(zc, 0) * V * np.sin(kx * xc + mz * zc) * one, w=env(zf, 0) * W * np.cos(kx * xc + mz * zf) * onew,
+          c0=(env(zc, 0) * Bm * np.sin(kx * xc + mz * zc) + NN ** 2 * zc) * one)
     for _ in range(10):
         m.time_step(dt)
     u = g.interior(m.field("u"), (1, 0, 0))
