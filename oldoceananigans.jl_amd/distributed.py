@@ -251,6 +251,7 @@ class DeviceBackend:
         no_flux = not any(bc.classification == "Flux" and bc.condition != 0.0
                           for fb in getattr(self, "bcs", {}).values() for bc in fb.sides.values())
         return (no_flux and getattr(self, "closure", None) is None and getattr(self, "buoyancy", None) is None and
+                getattr(self, "coriolis", None) is None and
                 g.topology[1] is not Bounded and self.ntracers <= 3)
 
     def swap_prognostic(self):
@@ -275,6 +276,8 @@ class DeviceBackend:
         if ev:
             ev[1].record()
             self.events.append(ev)
+        if getattr(self, "coriolis", None) is not None:
+            kernels.add_fplane_coriolis(self.grid.local, self.coriolis.f, self.U[0], self.U[1], self.Gn[0], self.Gn[1], kernel_parameters=rng)
         if getattr(self, "buoyancy", None) is not None:
             kernels.add_hydrostatic_pressure_gradient(self.grid.local, self.pHY, self.Gn[0], self.Gn[1], kernel_parameters=rng)
         if getattr(self, "closure", None) is not None:
@@ -335,7 +338,7 @@ class DistributedNonhydrostaticModel:
     """NonhydrostaticModel on a Distributed architecture (x-slabs): WENO(order=5), RK3, DistributedFFTBasedPoissonSolver."""
 
     def __init__(self, grid, advection=None, tracers=("T", "S"), timestepper="RungeKutta3", backend=None,
-                 boundary_conditions=None, closure=None, buoyancy=None):
+                 boundary_conditions=None, closure=None, buoyancy=None, coriolis=None):
         if advection is not None and not isinstance(advection, WENO):
             raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
         self.grid, self.ctx = grid, grid.ctx
@@ -346,6 +349,8 @@ class DistributedNonhydrostaticModel:
         self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
         if closure is not None:
             self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
+        if coriolis is not None:
+            self.backend.coriolis = coriolis
         if buoyancy is not None:
             missing = [t for t in buoyancy.required_tracers if t not in self.tracer_names]
             if missing:

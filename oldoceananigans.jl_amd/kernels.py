@@ -62,6 +62,11 @@ def update_hydrostatic_pressure(grid, buoyancy, tracers_by_name, pHY):
                                                               e.haline_contraction, pHY.data))
 
 
+def add_fplane_coriolis(grid, f, u, v, Gu, Gv, kernel_parameters=None):
+    """- x_f_cross_U, - y_f_cross_U of the u, v tendencies for coriolis = FPlane(f)"""
+    _lib.check(_lib.lib().ocn_add_fplane_coriolis(grid.handle, float(f), u.data, v.data, Gu.data, Gv.data, _range(kernel_parameters)))
+
+
 def add_hydrostatic_pressure_gradient(grid, pHY, Gu, Gv, kernel_parameters=None):
     """-∂x pHY′, -∂y pHY′ of the u, v tendencies"""
     _lib.check(_lib.lib().ocn_add_hydrostatic_pressure_gradient(grid.handle, pHY.data, Gu.data, Gv.data, _range(kernel_parameters)))

@@ -53,7 +53,8 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
             z, topo = _z_and_topology(ocn, zkind, size[2])
             grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
             model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind),
-                                                        closure=_closure(ocn, zkind), buoyancy=_tracers_and_buoyancy(ocn, zkind)[1])
+                                                        closure=_closure(ocn, zkind), buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
+                                                        coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
             model.async_halos = async_halos
             flds = model.fields()
             vals = {n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()}
@@ -96,7 +97,7 @@ def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_h
     z, topo = _z_and_topology(ocn, zkind, size[2])
     grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
-                                    buoyancy=_tracers_and_buoyancy(ocn, zkind)[1])
+                                    buoyancy=_tracers_and_buoyancy(ocn, zkind)[1], coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
     ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
     dt = 0.1 * grid.Δxᶜᵃᵃ / 0.6
     for _ in range(nsteps):
