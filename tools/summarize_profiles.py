@@ -22,7 +22,7 @@ out = os.path.join(ROOT, "gpurun_out")
 def one(pattern):
     files = glob.glob(os.path.join(out, pattern), recursive=True)
     assert files, pattern
-    return files[0]
+    return max(files, key=os.path.getmtime)        # several collections may sit side by side: take the newest
 
 
 def short(name):
@@ -83,7 +83,7 @@ if tend:
     print("wrote", dst)
 
 # ---- VALU issue counters (the binding roof of the tendency kernel) ---------------------------------------------------------
-vfile = glob.glob(os.path.join(out, f"{tag}_valu/**/*counter_collection.csv"), recursive=True)
+vfile = sorted(glob.glob(os.path.join(out, f"{tag}_valu/**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
 if vfile:
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(vfile[0])):
