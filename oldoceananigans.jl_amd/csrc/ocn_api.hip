@@ -1486,6 +1486,7 @@ struct ocn_model_s {
     // handed out by ocn_model_field are the live ones again at every time-step boundary.
     double *U2[OCN_MAX_FIELDS];
     int fuse_substep = 1;
+    int fused_epilogue = 1;                 // Coriolis + hydrostatic gradient + closure (+ substep) as one launch
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
     bool any_bc = false, any_flux_bc = false;
@@ -1613,13 +1614,54 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!strcmp(key, "tendency_impl")) { m->tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "swap_tendencies")) { m->swap_tendencies = value; return OCN_OK; }
     if (!strcmp(key, "fuse_substep")) { m->fuse_substep = value; return OCN_OK; }
+    if (!strcmp(key, "fused_epilogue")) { m->fused_epilogue = value; return OCN_OK; }
     if (!strcmp(key, "profile")) { m->profile = value; m->events_used = 0; return OCN_OK; }
     return ocn_set_option(key, value);
 }
 
+static bool has_physics(const ocn_model_s *m) { return m->has_coriolis || m->buoyancy_kind != 0 || m->has_closure; }
+
+// Coriolis, hydrostatic pressure gradient and closure terms of every field -- and, when `sub` is given, the RK3 substep of the next
+// stage -- in one launch (tendency_epilogue_kernel)
+static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
+    const DGrid &g = m->grid->d;
+    EpilogueArgs a;
+    a.n = m->nf; a.ntr = m->ntr;
+    a.u = make_view(g, m->U[0], LOC_U); a.v = make_view(g, m->U[1], LOC_V); a.w = make_view(g, m->U[2], LOC_W);
+    for (int t = 0; t < m->ntr; ++t) a.c[t] = make_view(g, m->U[3 + t], LOC_C);
+    a.pHY = make_view(g, m->pHY ? m->pHY : m->p, LOC_C);
+    int nx = 0, ny = 0, nz = 0;
+    for (int f = 0; f < m->nf; ++f) {
+        a.Gn[f] = m->Gn[f]; a.Gm[f] = sub ? sub->Gm[f] : nullptr; a.Un[f] = sub ? sub->Un[f] : nullptr;
+        a.r[f] = default_range(g, m->loc[f], f < 3);
+        nx = std::max(nx, a.r[f].i1 - a.r[f].i0 + 1); ny = std::max(ny, a.r[f].j1 - a.r[f].j0 + 1); nz = std::max(nz, a.r[f].k1 - a.r[f].k0 + 1);
+    }
+    a.has_coriolis = m->has_coriolis; a.fcor = m->fcor;
+    a.has_buoyancy = m->buoyancy_kind != 0;
+    a.nu = m->nu;
+    for (int t = 0; t < OCN_MAX_FIELDS; ++t) a.kappa[t] = t < m->ntr ? m->kappa[t] : 0.0;
+    a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
+    a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
+    a.any_flux = m->any_flux_bc;
+    const int T[3] = {g.tx, g.ty, g.tz};
+    for (int f = 0; f < OCN_MAX_FIELDS; ++f)
+        for (int sd = 0; sd < 6; ++sd) {
+            a.has_flux[f][sd] = f < m->nf && T[sd / 2] == OCN_BOUNDED && m->bcs[f][sd].kind == OCN_BC_FLUX && m->bcs[f][sd].value != 0.0;
+            a.flux[f][sd] = f < m->nf ? m->bcs[f][sd].value : 0.0;
+            if (sd < 3) a.loc[f][sd] = f < m->nf ? m->loc[f][sd] : 0;
+        }
+    if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
+    hipLaunchKernelGGL(tendency_epilogue_kernel, grid3(nx, ny, nz * m->nf, BLK), BLK, 0, g_stream, g, a);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
 static bool can_fuse_substep(const ocn_model_s *m) {
-    return m->fuse_substep && m->swap_tendencies && !m->any_flux_bc && !m->has_closure && !m->buoyancy_kind && !m->has_coriolis &&
-           fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
+    // without extra physics the substep rides in the fused advection kernel; with Coriolis / buoyancy / closure terms it rides in
+    // the epilogue pass that completes the tendencies (any advection path); a valued Flux condition is added after both
+    if (!m->fuse_substep || !m->swap_tendencies) return false;
+    if ((has_physics(m) || m->any_flux_bc) && m->fused_epilogue) return true;       // the epilogue pass also applies the Flux conditions
+    return !has_physics(m) && !m->any_flux_bc && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
 
 extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) {
@@ -1653,16 +1695,23 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
             ev = &m->events[m->events_used++];
             HIP_TRY(hipEventRecord(ev->first, g_stream));
         }
+        const bool physics = has_physics(m) || (m->any_flux_bc && m->fused_epilogue);
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
-                                m->tendency_impl, sub);
+                                m->tendency_impl, physics ? nullptr : sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
-        if (!rc && m->has_coriolis) rc = add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1], nullptr);
-        if (!rc && m->buoyancy_kind) rc = add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1], nullptr);
-        if (!rc && m->has_closure)
-            rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1], m->Gn[2],
-                                    m->Gn + 3, nullptr);
-        // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)
-        if (m->any_flux_bc)
+        if (!rc && physics) {
+            if (m->fused_epilogue) rc = tendency_epilogue(m, sub);
+            else {
+                if (sub) return fail(OCN_ESTATE, "fused substep needs the fused epilogue");
+                if (!rc && m->has_coriolis) rc = add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1], nullptr);
+                if (!rc && m->buoyancy_kind) rc = add_hydrostatic_pressure_gradient(g, m->pHY, m->Gn[0], m->Gn[1], nullptr);
+                if (!rc && m->has_closure)
+                    rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1],
+                                            m->Gn[2], m->Gn + 3, nullptr);
+            }
+        }
+        // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) -- inside the epilogue pass when that runs
+        if (m->any_flux_bc && !(physics && m->fused_epilogue))
             for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
     }
     return rc;

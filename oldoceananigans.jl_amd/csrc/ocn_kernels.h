@@ -130,12 +130,10 @@ struct ClosureCtx {
     __device__ __forceinline__ double vf(double S) const { return -(2 * (nu * S)); }
 };
 
+// V⁻¹ (δx(Ax flux) + δy(Ay flux) + δz(Az flux)) of the closure for field F at (i, j, k); coef = ν (momentum) or κ (tracer c)
 template <int F>
-__global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, double coef, Range6 r) {
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z;
-    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+__device__ __forceinline__ double closure_divergence(const DGrid &g, const FView &u, const FView &v, const FView &w, const FView &c,
+                                                     double coef, int i, int j, int k) {
     const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT};
     const double dx_ = g.dx, dy_ = g.dy;
     double dx, dy, dz, vinv;
@@ -161,8 +159,16 @@ __global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u,
         dy = X.fy ? 0.0 : ay * -(coef * X.ddy_f(c, i, j + 1, k)) - ay * -(coef * X.ddy_f(c, i, j, k));
         dz = X.fz ? 0.0 : az * -(coef * X.ddz_f(c, i, j, k + 1)) - az * -(coef * X.ddz_f(c, i, j, k));
     }
-    const double div = vinv * ((dx + dy) + dz);
-    G.at(i, j, k) = (G.at(i, j, k) - div) + 0.0;
+    return vinv * ((dx + dy) + dz);
+}
+
+template <int F>
+__global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, double coef, Range6 r) {
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    G.at(i, j, k) = (G.at(i, j, k) - closure_divergence<F>(g, u, v, w, c, coef, i, j, k)) + 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -188,29 +194,47 @@ __global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FVie
     long q = c.lin(i, j, Nz + 1);
     double bk1 = buoyancy_perturbation(B, q);          // b[k+1]
     double p = 0.0;
-    for (int k = Nz; k >= 1; --k) {
-        q -= c.s2;
-        const double bk = buoyancy_perturbation(B, q);
-        const double zb = 1 * (0.5 * (bk + bk1));
-        const double dzf = g.dzf[k + g.Hz];            // Δzᶠ(k+1)
-        p = k == Nz ? -zb * dzf : p - zb * dzf;
-        pHY[q] = p;
-        bk1 = bk;
+    // the recurrence is serial in k but its loads are not: fetch TB levels, then sweep them (few columns => latency-bound otherwise)
+    constexpr int TB = 8;
+    for (int k0 = Nz; k0 >= 1; k0 -= TB) {
+        double bb[TB];
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+            if (k0 - n >= 1) bb[n] = buoyancy_perturbation(B, q - (long)(n + 1) * c.s2);
+#pragma unroll
+        for (int n = 0; n < TB; ++n) {
+            const int k = k0 - n;
+            if (k >= 1) {
+                q -= c.s2;
+                const double bk = bb[n];
+                const double zb = 1 * (0.5 * (bk + bk1));
+                const double dzf = g.dzf[k + g.Hz];            // Δzᶠ(k+1)
+                p = k == Nz ? -zb * dzf : p - zb * dzf;
+                pHY[q] = p;
+                bk1 = bk;
+            }
+        }
     }
 }
 
 // G_u -= ∂xᶠᶜᶜ pHY′, G_v -= ∂yᶜᶠᶜ pHY′ (nonhydrostatic_tendency_kernel_functions.jl:14-19,97,159) on tendencies holding the
 // advective part; ranges = the tendency ranges of u and v
+__device__ __forceinline__ double hydrostatic_gradient_x(const DGrid &g, const FView &p, int i, int j, int k) {
+    return g.tx == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i - 1, j, k)) * (1.0 / g.dx);
+}
+__device__ __forceinline__ double hydrostatic_gradient_y(const DGrid &g, const FView &p, int i, int j, int k) {
+    return g.ty == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i, j - 1, k)) * (1.0 / g.dy);
+}
+
 __global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FView p, FView Gu, FView Gv, Range6 ru, Range6 rv) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
-    const double pc = p.at(i, j, k);
     if (i >= ru.i0 && i <= ru.i1 && j >= ru.j0 && j <= ru.j1 && k >= ru.k0 && k <= ru.k1)
-        Gu.at(i, j, k) = Gu.at(i, j, k) - (g.tx == OCN_FLAT ? 0.0 : (pc - p.at(i - 1, j, k)) * (1.0 / g.dx));
+        Gu.at(i, j, k) = Gu.at(i, j, k) - hydrostatic_gradient_x(g, p, i, j, k);
     if (i >= rv.i0 && i <= rv.i1 && j >= rv.j0 && j <= rv.j1 && k >= rv.k0 && k <= rv.k1)
-        Gv.at(i, j, k) = Gv.at(i, j, k) - (g.ty == OCN_FLAT ? 0.0 : (pc - p.at(i, j - 1, k)) * (1.0 / g.dy));
+        Gv.at(i, j, k) = Gv.at(i, j, k) - hydrostatic_gradient_y(g, p, i, j, k);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -224,31 +248,105 @@ __device__ __forceinline__ bool inactive_cell(const DGrid &g, int i, int j, int 
            (g.tz == OCN_BOUNDED && (k < 1 || k > g.Nz));
 }
 
+// x_f_cross_U at (f, c, c) and y_f_cross_U at (c, f, c)
+__device__ __forceinline__ double x_f_cross_U(const DGrid &g, double f, const FView &v, int i, int j, int k) {
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
+    // ℑxyᶠᶜᵃ = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ ·): X(jj) = 0.5 (q[i-1, jj] + q[i, jj]); 0.5 (X(j) + X(j+1)); not_peripheral at (c, f, c)
+    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii, jj - 1, k)) ? 1.0 : 0.0; };
+    auto Xq = [&](int jj) { return fx ? v.at(i, jj, k) : 0.5 * (v.at(i - 1, jj, k) + v.at(i, jj, k)); };
+    auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i - 1, jj) + np(i, jj)); };
+    const double qa = fy ? Xq(j) : 0.5 * (Xq(j) + Xq(j + 1));
+    const double an = fy ? Xn(j) : 0.5 * (Xn(j) + Xn(j + 1));
+    const double aw = an == 0 ? 0.0 : qa / an;
+    return -f * aw;
+}
+__device__ __forceinline__ double y_f_cross_U(const DGrid &g, double f, const FView &u, int i, int j, int k) {
+    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
+    // ℑxyᶜᶠᵃ = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ ·): X(jj) = 0.5 (q[i, jj] + q[i+1, jj]); 0.5 (X(j-1) + X(j)); not_peripheral at (f, c, c)
+    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii - 1, jj, k)) ? 1.0 : 0.0; };
+    auto Xq = [&](int jj) { return fx ? u.at(i, jj, k) : 0.5 * (u.at(i, jj, k) + u.at(i + 1, jj, k)); };
+    auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i, jj) + np(i + 1, jj)); };
+    const double qa = fy ? Xq(j) : 0.5 * (Xq(j - 1) + Xq(j));
+    const double an = fy ? Xn(j) : 0.5 * (Xn(j - 1) + Xn(j));
+    const double aw = an == 0 ? 0.0 : qa / an;
+    return f * aw;
+}
+
 __global__ void __launch_bounds__(256) fplane_coriolis_kernel(DGrid g, double f, FView u, FView v, FView Gu, FView Gv, Range6 ru, Range6 rv) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
-    const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
-    if (i >= ru.i0 && i <= ru.i1 && j >= ru.j0 && j <= ru.j1 && k >= ru.k0 && k <= ru.k1) {
-        // ℑxyᶠᶜᵃ = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ ·): X(jj) = 0.5 (q[i-1, jj] + q[i, jj]); 0.5 (X(j) + X(j+1)); not_peripheral at (c, f, c)
-        auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii, jj - 1, k)) ? 1.0 : 0.0; };
-        auto Xq = [&](int jj) { return fx ? v.at(i, jj, k) : 0.5 * (v.at(i - 1, jj, k) + v.at(i, jj, k)); };
-        auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i - 1, jj) + np(i, jj)); };
-        const double qa = fy ? Xq(j) : 0.5 * (Xq(j) + Xq(j + 1));
-        const double an = fy ? Xn(j) : 0.5 * (Xn(j) + Xn(j + 1));
-        const double aw = an == 0 ? 0.0 : qa / an;
-        Gu.at(i, j, k) = Gu.at(i, j, k) - (-f * aw);
+    if (i >= ru.i0 && i <= ru.i1 && j >= ru.j0 && j <= ru.j1 && k >= ru.k0 && k <= ru.k1)
+        Gu.at(i, j, k) = Gu.at(i, j, k) - x_f_cross_U(g, f, v, i, j, k);
+    if (i >= rv.i0 && i <= rv.i1 && j >= rv.j0 && j <= rv.j1 && k >= rv.k0 && k <= rv.k1)
+        Gv.at(i, j, k) = Gv.at(i, j, k) - y_f_cross_U(g, f, u, i, j, k);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One pass for everything that follows the advective part of the tendencies (nonhydrostatic_tendency_kernel_functions.jl:91-100,
+// 153-162,216-229,286-297): G = (((A - f×U) - ∇pHY′) - ∂ⱼτᵢⱼ) + 0 for every prognostic field, and -- optionally -- the RK3 substep
+// of the NEXT stage into the second set of prognostic arrays (the viscous stencils of neighbouring cells still read U). The
+// terms are the device functions of the stand-alone kernels above, evaluated in the reference's order => identical bits.
+// ---------------------------------------------------------------------------------------------------------------------
+struct EpilogueArgs {
+    int n, ntr;
+    FView u, v, w, c[OCN_MAX_FIELDS], pHY;      // .p of the views = the live fields
+    double *Gn[OCN_MAX_FIELDS];
+    const double *Gm[OCN_MAX_FIELDS];
+    double *Un[OCN_MAX_FIELDS];
+    Range6 r[OCN_MAX_FIELDS];
+    bool has_coriolis, has_buoyancy, substep, has_zeta;
+    double fcor, nu, kappa[OCN_MAX_FIELDS], dt, gamma, zeta;
+    // valued Flux boundary conditions (compute_flux_bcs.jl:57-163), applied after the interior terms: [field][side]
+    bool any_flux;
+    bool has_flux[OCN_MAX_FIELDS][6];
+    double flux[OCN_MAX_FIELDS][6];
+    int loc[OCN_MAX_FIELDS][3];
+};
+
+__global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
+    const int f = blockIdx.z % a.n;
+    const Range6 r = a.r[f];
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z / a.n;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const FView &fv = f == 0 ? a.u : (f == 1 ? a.v : (f == 2 ? a.w : a.c[f - 3]));
+    const long q = fv.lin(i, j, k);
+    double G = a.Gn[f][q];
+    if (f == 0) {
+        if (a.has_coriolis) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
+        if (a.has_buoyancy) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
+        if (a.nu != 0.0) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+    } else if (f == 1) {
+        if (a.has_coriolis) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
+        if (a.has_buoyancy) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
+        if (a.nu != 0.0) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+    } else if (f == 2) {
+        if (a.nu != 0.0) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+    } else {
+        const double kap = a.kappa[f - 3];
+        if (kap != 0.0) G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k)) + 0.0;
     }
-    if (i >= rv.i0 && i <= rv.i1 && j >= rv.j0 && j <= rv.j1 && k >= rv.k0 && k <= rv.k1) {
-        // ℑxyᶜᶠᵃ = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ ·): X(jj) = 0.5 (q[i, jj] + q[i+1, jj]); 0.5 (X(j-1) + X(j)); not_peripheral at (f, c, c)
-        auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii - 1, jj, k)) ? 1.0 : 0.0; };
-        auto Xq = [&](int jj) { return fx ? u.at(i, jj, k) : 0.5 * (u.at(i, jj, k) + u.at(i + 1, jj, k)); };
-        auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i, jj) + np(i + 1, jj)); };
-        const double qa = fy ? Xq(j) : 0.5 * (Xq(j - 1) + Xq(j));
-        const double an = fy ? Xn(j) : 0.5 * (Xn(j - 1) + Xn(j));
-        const double aw = an == 0 ? 0.0 : qa / an;
-        Gv.at(i, j, k) = Gv.at(i, j, k) - (f * aw);
+    if (a.any_flux) {
+        // compute_x/y/z_bcs!: G[1] += flux A / V, G[N] -= flux A / V (x, then y, then z as the reference launches them)
+        const double dz = a.loc[f][2] == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
+        const double vol = (g.dx * g.dy) * dz;
+        const int N[3] = {g.Nx, g.Ny, g.Nz}, idx[3] = {i, j, k};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double area = d == 0 ? g.dy * dz : (d == 1 ? g.dx * dz : g.dx * g.dy);
+            if (a.has_flux[f][2 * d] && idx[d] == 1) G += a.flux[f][2 * d] * area / vol;
+            if (a.has_flux[f][2 * d + 1] && idx[d] == N[d]) G -= a.flux[f][2 * d + 1] * area / vol;
+        }
+    }
+    a.Gn[f][q] = G;
+    if (a.substep) {
+        double Uv = fv.p[q];
+        if (a.has_zeta) Uv += a.dt * (a.gamma * G + a.zeta * a.Gm[f][q]);
+        else            Uv += a.dt * a.gamma * G;
+        a.Un[f][q] = Uv;
     }
 }
 

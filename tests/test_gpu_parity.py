@@ -359,7 +359,7 @@ def test_scalar_diffusivity_matches_oracle(ocn, oracle, arch, topology, size, st
     g_cpu = oracle.Grid(size, topology=tuple({"Periodic": 0, "Bounded": 1, "Flat": 3}[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=zc)
     closure = ocn.ScalarDiffusivity(ν=2e-3, κ={"T": 1e-3, "S": 5e-4})
     m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, advection=ocn.WENO(), tracers=("T", "S"), closure=closure)
-    assert m_gpu.get_option("fuse_substep_active") == 0
+    assert m_gpu.get_option("fuse_substep_active") == 1          # the substep rides in the epilogue pass that adds the closure
     m_cpu = oracle.Model(g_cpu, 2)
     m_cpu.set_closure(nu=2e-3, kappa=[1e-3, 5e-4])
     # tendencies (advection + closure) on identical random inputs: bit-identical
@@ -427,7 +427,7 @@ def test_buoyancy_matches_oracle(ocn, oracle, arch, kind, topology, size):
         m_cpu.set_buoyancy_tracer(0)
     else:
         m_cpu.set_seawater_buoyancy(0, 1)
-    assert m_gpu.get_option("fuse_substep_active") == 0
+    assert m_gpu.get_option("fuse_substep_active") == 1
     rng = np.random.default_rng(4)
     vals = {n: rng.standard_normal(g_gpu.interior_size(f.loc)) for n, f in m_gpu.fields().items()}
     ocn.set_model(m_gpu, enforce_incompressibility=False, **vals)
@@ -483,3 +483,32 @@ def test_fplane_coriolis_matches_oracle(ocn, oracle, arch, topology, size):
     for name, a, b in field_pairs(m_gpu, m_cpu):
         assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
     assert ocn.FPlane(latitude=45).f == 2 * 7.292115e-5 * np.sin(np.pi / 4)
+
+
+@pytest.mark.parametrize("topology,size", [(("Periodic", "Periodic", "Bounded"), (64, 12, 10)), (("Bounded", "Bounded", "Bounded"), (9, 8, 7))])
+def test_fused_epilogue_is_bit_identical_to_separate_kernels(ocn, arch, topology, size):
+    """Coriolis + hydrostatic pressure gradient + closure + next-stage substep as ONE pass (tendency_epilogue_kernel) against the
+    stand-alone kernels and a separate rk3_substep!: identical bits after full time-steps"""
+    z = tanh_faces(size[2])
+    out = []
+    for fused in (1, 0):
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        F = ocn.FieldBoundaryConditions
+        bcs = {"T": F(top=ocn.FluxBoundaryCondition(5e-3), bottom=ocn.GradientBoundaryCondition(0.1)),
+               "u": F(top=ocn.FluxBoundaryCondition(-1e-3), bottom=ocn.ValueBoundaryCondition(0.0))}
+        model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), coriolis=ocn.FPlane(f=0.3), buoyancy=ocn.SeawaterBuoyancy(),
+                                        closure=ocn.ScalarDiffusivity(ν=1e-3, κ={"T": 1e-3, "S": 0.0}), boundary_conditions=bcs)
+        model.set_option("fused_epilogue", fused)
+        model.set_option("fuse_substep", fused)
+        assert model.get_option("fuse_substep_active") == fused
+        ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=9))
+        for _ in range(3):
+            ocn.time_step(model, 0.05 * grid.Δxᶜᵃᵃ / 0.6)
+        out.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent(), "pHY": model.pressures.pHY.parent(),
+                                                                    "Gu": model.tendency("u").parent(), "GT": model.tendency("T").parent()})
+        model.close()
+    for n in out[0]:
+        # tendencies: cells the substep reads (the stand-alone Flux-condition kernel also touches wall faces excluded by
+        # exclude_periphery, like the reference; nothing reads them)
+        core = (slice(4, -3), slice(3, -3), slice(3, -3)) if n == "Gu" else (slice(None),) * 3
+        assert np.array_equal(out[0][n][core], out[1][n][core]), n
