@@ -208,6 +208,16 @@ int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t solver, double *send_complex
 /* compute_source_term! (solve_for_pressure.jl:12-84) into the solver's own storage */
 int ocn_dist_poisson_source_term(ocn_dist_poisson_t solver, const double *u, const double *v, const double *w);
 int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver);
+/* z Periodic and option "dist_substructured" = 1 (default): after the local (y, z) transform every mode is a periodic constant-
+ * coefficient tridiagonal system along the partitioned x direction; it is solved by substructuring -- Thomas sweeps on the slab, an
+ * ALL-GATHER of 2 values per mode (payload_size complex elements per rank, ~1 MB at 256^3) instead of the two all-to-alls of the
+ * whole spectrum, a 2x2 solve per mode and rank-DFT index, a slab correction:
+ *   source_term -> forward_local -> [all_gather(gathered, payload)] -> backward_local -> phi.
+ * Same solution as the transposed FFT solve to round-off. payload_size = 0: the solver transposes (stages above). */
+int ocn_dist_poisson_payload_size(ocn_dist_poisson_t solver, size_t *complex_elements);
+int ocn_dist_poisson_set_gather_buffers(ocn_dist_poisson_t solver, double *payload_complex, double *gathered_complex);
+int ocn_dist_poisson_forward_local(ocn_dist_poisson_t solver);
+int ocn_dist_poisson_backward_local(ocn_dist_poisson_t solver, double *phi);
 int ocn_dist_poisson_solve_x(ocn_dist_poisson_t solver);
 int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t solver, double *phi);
 

@@ -70,6 +70,10 @@ SYMBOLS = {
     "ocn_dist_poisson_buffer_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
     "ocn_dist_poisson_source_term": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ocn_dist_poisson_forward_yz": (C.c_int, [_vp]),
+    "ocn_dist_poisson_payload_size": (C.c_int, [_vp, C.POINTER(C.c_size_t)]),
+    "ocn_dist_poisson_set_gather_buffers": (C.c_int, [_vp, _vp, _vp]),
+    "ocn_dist_poisson_forward_local": (C.c_int, [_vp]),
+    "ocn_dist_poisson_backward_local": (C.c_int, [_vp, _vp]),
     "ocn_dist_poisson_solve_x": (C.c_int, [_vp]),
     "ocn_dist_poisson_backward_yz": (C.c_int, [_vp, _vp]),
     "ocn_grid_create": (C.c_int, [_pp, _ip, _ip, _ip, _dp, C.c_double, C.c_double, C.c_double, _dp, _dp]),

@@ -717,7 +717,8 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 // Poisson solvers
 // ---------------------------------------------------------------------------------------------------------------------
 static int g_real_fft = 1, g_c2r_strided = 1;
-static int g_fused_zfft = 1;    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
+static int g_fused_zfft = 1;
+static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
 
 struct ocn_poisson_s {
     ocn_grid_t grid;
@@ -1257,6 +1258,12 @@ struct ocn_dist_poisson_s {
     bool xfused = false;
     int logn_x = 0, xlines = 1;
     double2 *xtw = nullptr;
+    // substructured x solve (see ocn_kernels.h): modes M = Nyh*Nz, spectral slab Y (M, Nxl), Thomas factors, s = T⁻¹e₀
+    bool sub = false;
+    long M = 0;
+    double2 *Y = nullptr, *iface = nullptr;
+    double *rden = nullptr, *cpf = nullptr, *svec = nullptr;
+    double2 *payload = nullptr, *gathered = nullptr;     // borrowed (host layer: torch tensors): 2M+1 and R*(2M+1) complex
 };
 
 extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
@@ -1264,6 +1271,7 @@ extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     if (s->has_loc) hipfftDestroy(s->plan_loc);
     if (s->has_x) hipfftDestroy(s->plan_x);
     hipFree(s->zfield); hipFree(s->xfield); hipFree(s->xsol); hipFree(s->xtw);
+    hipFree(s->Y); hipFree(s->iface); hipFree(s->rden); hipFree(s->cpf); hipFree(s->svec);
     hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
     delete s;
@@ -1344,7 +1352,21 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         }
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(local y/z) failed (%d)", (int)r); goto bad; }
         s->has_loc = true;
-        if (zmode == 0 && g_fused_zfft && s->Nxg >= 8 && s->Nxg <= 4096 && (s->Nxg & (s->Nxg - 1)) == 0) {
+        if (zmode == 0 && g_dist_substructured) {
+            s->sub = true;
+            s->M = (long)s->Nyh * s->Nz;
+            const size_t slab = (size_t)s->M * s->Nxl;
+            TRY_OR_FREE(dev_alloc((void **)&s->Y, slab * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->rden, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->cpf, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->svec, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->iface, (2 * (size_t)s->M + 1) * sizeof(double2)));
+            const double a = 1.0 / (g.dx * g.dx);
+            hipLaunchKernelGGL(sub_setup_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, (int)s->M, s->Nyh, s->Nxl, a,
+                               s->lam[1], s->lam[2], s->rden, s->cpf, s->svec);
+            TRY_OR_FREE(hipGetLastError());
+        }
+        if (!s->sub && zmode == 0 && g_fused_zfft && s->Nxg >= 8 && s->Nxg <= 4096 && (s->Nxg & (s->Nxg - 1)) == 0) {
             s->xfused = true;
             while ((1 << s->logn_x) < s->Nxg) ++s->logn_x;
             s->xlines = std::max(1, 4096 / s->Nxg);           // 64 KB of LDS per workgroup
@@ -1359,7 +1381,7 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if ((rc = plan_set_stream(s->plan_loc))) goto bad;
         const double sc = zmode == 0 ? 1.0 / ((double)s->Ny * s->Nz) : 1.0 / (double)s->Ny;
         if ((rc = verify_complex_plan(s->plan_loc, s->zfield, (long)s->nz_c, sc, "distributed local (y, z)"))) goto bad;
-        if (!s->xfused) {
+        if (!s->xfused && !s->sub) {
             int nx[1] = {s->Nxg};
             r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyc * s->Nz);
             if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(x) failed (%d)", (int)r); goto bad; }
@@ -1379,6 +1401,59 @@ bad:
 extern "C" int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t s, size_t *complex_elements) {
     if (!s || !complex_elements) return fail(OCN_EINVAL, "NULL argument");
     *complex_elements = s->nbuf;
+    return OCN_OK;
+}
+
+// substructured mode: complex elements of the per-rank payload (first / last value per mode + the null mode's sum); 0 otherwise
+extern "C" int ocn_dist_poisson_payload_size(ocn_dist_poisson_t s, size_t *complex_elements) {
+    if (!s || !complex_elements) return fail(OCN_EINVAL, "NULL argument");
+    *complex_elements = s->sub ? 2 * (size_t)s->M + 1 : 0;
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_poisson_set_gather_buffers(ocn_dist_poisson_t s, double *payload_complex, double *gathered_complex) {
+    if (!s || !payload_complex || !gathered_complex) return fail(OCN_EINVAL, "NULL argument");
+    if (!s->sub) return fail(OCN_ESTATE, "this solver transposes (all-to-all); it has no gather buffers");
+    s->payload = (double2 *)payload_complex; s->gathered = (double2 *)gathered_complex;
+    return OCN_OK;
+}
+
+// substructured mode, stage 1: local (y, z) transform, column separation, Thomas sweeps along x, payload. Afterwards the host layer
+// runs all_gather(gathered, payload).
+extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
+    NEED_INIT();
+    if (!s || !s->sub || !s->payload) return fail(OCN_EINVAL, "substructured solver / gather buffers not set");
+    int rc;
+    if ((rc = plan_set_stream(s->plan_loc))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
+    const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
+    hipLaunchKernelGGL(sub_separate_kernel, grd, blk, 0, g_stream, s->zfield, s->Y, s->Nxl, s->Nxh, s->Ny, s->Nyh, s->Nz);
+    const double a = 1.0 / (s->grid->d.dx * s->grid->d.dx);
+    hipLaunchKernelGGL(sub_thomas_kernel, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf, s->Y,
+                       s->payload);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// substructured mode, stage 2: interface unknowns from the gathered payloads, slab correction, rebuild the paired spectrum,
+// inverse local transform, copy into the haloed pressure
+extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi) {
+    NEED_INIT();
+    if (!s || !s->sub || !s->gathered || !phi) return fail(OCN_EINVAL, "substructured solver / gather buffers not set");
+    const DGrid &g = s->grid->d;
+    const double a = 1.0 / (g.dx * g.dx);
+    hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Nyh, s->Nxl, s->R, s->rank,
+                       a, s->lam[1], s->lam[2], s->svec, s->gathered, s->iface);
+    const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
+    const double scale = 1.0 / ((double)s->Ny * (double)s->Nz);
+    hipLaunchKernelGGL(sub_correct_combine_kernel, grd, blk, 0, g_stream, s->Y, s->svec, s->iface, s->zfield, s->Nxl, s->Nxh, s->Ny, s->Nyh,
+                       s->Nz, a, scale);
+    int rc;
+    if ((rc = plan_set_stream(s->plan_loc))) return rc;
+    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
+                       (const double *)s->zfield, s->Nxe);
+    KERNEL_CHECK();
     return OCN_OK;
 }
 
@@ -1605,6 +1680,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
     if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
     if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
+    if (!strcmp(key, "dist_substructured")) { g_dist_substructured = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

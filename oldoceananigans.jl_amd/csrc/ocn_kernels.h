@@ -978,6 +978,213 @@ __global__ void __launch_bounds__(256) xline_solve_kernel(const double2 *recv, d
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Substructured x solve of the distributed FFT Poisson solver (z Periodic): after the local (y, z) transform every (ky, kz) mode
+// is an independent PERIODIC CONSTANT-COEFFICIENT TRIDIAGONAL system along the partitioned x direction,
+//     a (p[i-1] - 2 p[i] + p[i+1]) - (λy + λz) p[i] = r[i],   a = 1/Δx².
+// Instead of transposing the whole spectrum twice (2 all-to-alls of ~140 MB per rank -- one xGMI link per peer) each rank solves
+// its slab with Dirichlet ends (Thomas, real coefficients precomputed once), the ranks exchange TWO numbers per mode (first and
+// last value: an all-gather of ~1 MB), the 2R interface unknowns per mode follow from a system that is block-circulant in the
+// rank index (constant coefficients => diagonalised by an R-point DFT: 2x2 solves), and the slab solution is corrected with
+// p = y - a gL s - a gR s[reversed], s = T⁻¹ e₀. The null mode (ky = kz = 0) is pinned and shifted to zero mean like the
+// reference's ϕ̂[1,1,1] = 0. Same solution as the transposed FFT solve to round-off (tested at 1e-12).
+// Spectral layout here: Y[m + M*i], m = ky + Nyh*kz fastest (coalesced sweeps along x), i = local x index.
+// ---------------------------------------------------------------------------------------------------------------------
+// setup, one thread per mode: rden[i] = 1 / (b - a cp[i-1]), cp[i] = a rden[i], s = T⁻¹ e₀ (T = tridiag(a, b, a), b = -2a - λ)
+__global__ void __launch_bounds__(256) sub_setup_kernel(int M, int Nyh, int N, double a, const double *ly, const double *lz, double *rden,
+                                                        double *cp, double *svec) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int jy = m % Nyh, k = m / Nyh;
+    const double b = -2.0 * a - (ly[jy] + lz[k]);
+    double c = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double rd = 1.0 / (b - a * c);
+        c = a * rd;
+        rden[m + (long)M * i] = rd;
+        cp[m + (long)M * i] = c;
+    }
+    double y = rden[m];                       // forward sweep of e₀: y[0] = 1/den[0], y[i] = -a y[i-1] / den[i]
+    svec[m] = y;
+    for (int i = 1; i < N; ++i) { y = (-a * y) * rden[m + (long)M * i]; svec[m + (long)M * i] = y; }
+    for (int i = N - 2; i >= 0; --i) svec[m + (long)M * i] -= cp[m + (long)M * i] * svec[m + (long)M * (i + 1)];
+}
+
+// separate the paired columns (see dist_pack_forward_kernel) and transpose (ih, k, j) -> (m, i) through an LDS tile
+__global__ void __launch_bounds__(256) sub_separate_kernel(const double2 *Z, double2 *Y, int Nxl, int Nxh, int Ny, int Nyh, int Nz) {
+    __shared__ double2 tA[16][17], tB[16][17];
+    const int k = blockIdx.z, tx = threadIdx.x, ty = threadIdx.y;
+    const long M = (long)Nyh * Nz;
+    {
+        const int ih = blockIdx.x * 16 + tx, j = blockIdx.y * 16 + ty;
+        if (ih < Nxh && j < Nyh) {
+            const int jm = j == 0 ? 0 : Ny - j, km = k == 0 ? 0 : Nz - k;
+            const double2 z1 = Z[ih + (long)Nxh * (k + (long)Nz * j)], z2 = Z[ih + (long)Nxh * (km + (long)Nz * jm)];
+            tA[ty][tx] = make_double2(0.5 * (z1.x + z2.x), 0.5 * (z1.y - z2.y));
+            tB[ty][tx] = make_double2(0.5 * (z1.y + z2.y), 0.5 * (z2.x - z1.x));
+        }
+    }
+    __syncthreads();
+    {
+        const int j = blockIdx.y * 16 + tx, ih = blockIdx.x * 16 + ty;
+        if (ih < Nxh && j < Nyh) {
+            const long m = j + (long)Nyh * k;
+            Y[m + M * (2 * ih)] = tA[tx][ty];
+            if (2 * ih + 1 < Nxl) Y[m + M * (2 * ih + 1)] = tB[tx][ty];
+        }
+    }
+}
+
+// Thomas sweeps along x for every mode (in place), then the payload: first / last value per mode and, for mode 0, the sum
+__global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a, const double *__restrict__ rden, const double *__restrict__ cp,
+                                                        double2 *__restrict__ Y, double2 *__restrict__ payload) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    constexpr int TB = 8;
+    double2 prev = make_double2(0.0, 0.0);
+    for (int i0 = 0; i0 < N; i0 += TB) {
+        double2 r[TB];
+        double d[TB];
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+            if (i0 + n < N) { r[n] = Y[m + M * (i0 + n)]; d[n] = rden[m + M * (i0 + n)]; }
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+            if (i0 + n < N) {
+                prev = make_double2((r[n].x - a * prev.x) * d[n], (r[n].y - a * prev.y) * d[n]);
+                Y[m + M * (i0 + n)] = prev;
+            }
+    }
+    double2 sum = prev;                           // prev = y[N-1] is final already
+    const double2 last = prev;
+    for (int i0 = N - 2; i0 >= 0; i0 -= TB) {
+        double2 y[TB];
+        double c[TB];
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+            if (i0 - n >= 0) { y[n] = Y[m + M * (i0 - n)]; c[n] = cp[m + M * (i0 - n)]; }
+#pragma unroll
+        for (int n = 0; n < TB; ++n)
+            if (i0 - n >= 0) {
+                prev = make_double2(y[n].x - c[n] * prev.x, y[n].y - c[n] * prev.y);
+                Y[m + M * (i0 - n)] = prev;
+                sum.x += prev.x; sum.y += prev.y;
+            }
+    }
+    payload[m] = prev;                            // y[0]
+    payload[M + m] = last;                        // y[N-1]
+    if (m == 0) payload[2 * M] = sum;
+}
+
+// interface unknowns from the gathered payloads (R ranks x (2M + 1)): per mode an R-point DFT over the rank index, 2x2 solves, and
+// the two values this rank needs: gL = l[rank-1], gR = f[rank+1]. out[m] = gL, out[M+m] = gR, out[2M] = mean of mode 0
+__global__ void __launch_bounds__(256) sub_interface_kernel(long M, int Nyh, int N, int R, int rank, double a, const double *ly,
+                                                            const double *lz, const double *svec, const double2 *gathered, double2 *out) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const long stride = 2 * M + 1;
+    const double alpha = a * svec[m], beta = a * svec[m + M * (N - 1)];
+    const bool null_mode = m == 0 && (ly[0] + lz[0]) == 0.0;
+    double2 gl = make_double2(0.0, 0.0), gr = gl;
+    double2 mean = gl;
+    const int rl = (rank + R - 1) % R, rr = (rank + 1) % R;
+    for (int q = 0; q < R; ++q) {
+        double2 yF = make_double2(0.0, 0.0), yL = yF;           // DFT over the rank index: Σ_r y_r e^{-2πi q r / R}
+        for (int r = 0; r < R; ++r) {
+            double sn, cs;
+            sincospi(-2.0 * (double)((q * r) % R) / (double)R, &sn, &cs);
+            const double2 f = gathered[r * stride + m], l = gathered[r * stride + M + m];
+            yF.x += f.x * cs - f.y * sn; yF.y += f.x * sn + f.y * cs;
+            yL.x += l.x * cs - l.y * sn; yL.y += l.x * sn + l.y * cs;
+        }
+        double so, co;
+        sincospi(2.0 * (double)q / (double)R, &so, &co);        // ω = e^{2πi q / R}
+        // [1 + β ω,  α ω⁻¹; α ω,  1 + β ω⁻¹] [f̂; l̂] = [ŷF; ŷL]
+        const double2 A11 = make_double2(1.0 + beta * co, beta * so), A22 = make_double2(1.0 + beta * co, -beta * so);
+        const double2 A12 = make_double2(alpha * co, -alpha * so), A21 = make_double2(alpha * co, alpha * so);
+        double2 fh, lh;
+        if (null_mode && q == 0) {                               // singular: pin l̂ = 0 (compatibility: Σ rhs = 0), shift to zero mean below
+            const double d2 = A11.x * A11.x + A11.y * A11.y;
+            fh = make_double2((yF.x * A11.x + yF.y * A11.y) / d2, (yF.y * A11.x - yF.x * A11.y) / d2);
+            lh = make_double2(0.0, 0.0);
+        } else {
+            const double2 det = make_double2((A11.x * A22.x - A11.y * A22.y) - (A12.x * A21.x - A12.y * A21.y),
+                                             (A11.x * A22.y + A11.y * A22.x) - (A12.x * A21.y + A12.y * A21.x));
+            const double d2 = det.x * det.x + det.y * det.y;
+            const double2 nf = make_double2((A22.x * yF.x - A22.y * yF.y) - (A12.x * yL.x - A12.y * yL.y),
+                                            (A22.x * yF.y + A22.y * yF.x) - (A12.x * yL.y + A12.y * yL.x));
+            const double2 nl = make_double2((A11.x * yL.x - A11.y * yL.y) - (A21.x * yF.x - A21.y * yF.y),
+                                            (A11.x * yL.y + A11.y * yL.x) - (A21.x * yF.y + A21.y * yF.x));
+            fh = make_double2((nf.x * det.x + nf.y * det.y) / d2, (nf.y * det.x - nf.x * det.y) / d2);
+            lh = make_double2((nl.x * det.x + nl.y * det.y) / d2, (nl.y * det.x - nl.x * det.y) / d2);
+        }
+        // inverse DFT at the two rank indices this rank needs
+        double s1, c1, s2, c2;
+        sincospi(2.0 * (double)((q * rl) % R) / (double)R, &s1, &c1);
+        sincospi(2.0 * (double)((q * rr) % R) / (double)R, &s2, &c2);
+        gl.x += (lh.x * c1 - lh.y * s1) / R; gl.y += (lh.x * s1 + lh.y * c1) / R;
+        gr.x += (fh.x * c2 - fh.y * s2) / R; gr.y += (fh.x * s2 + fh.y * c2) / R;
+        if (null_mode) {
+            // Σ_r (gL_r + gR_r) = R (l̂_0 + f̂_0): only q = 0 survives the sum over ranks
+            if (q == 0) { mean.x = fh.x + lh.x; mean.y = fh.y + lh.y; }
+        }
+    }
+    out[m] = gl;
+    out[M + m] = gr;
+    if (m == 0) {
+        double2 mu = make_double2(0.0, 0.0);
+        if (null_mode) {
+            // global sum of p = Σ_r Σ_i y_r[i] - a (Σ_r gL_r + Σ_r gR_r) Σ_i s[i];  Σ_r gL_r = l̂_0, Σ_r gR_r = f̂_0 (q = 0 of the DFT)
+            double2 ysum = make_double2(0.0, 0.0);
+            for (int r = 0; r < R; ++r) { ysum.x += gathered[r * stride + 2 * M].x; ysum.y += gathered[r * stride + 2 * M].y; }
+            double ssum = 0.0;
+            for (int i = 0; i < N; ++i) ssum += svec[M * i];
+            const double cnt = (double)R * (double)N;
+            mu = make_double2((ysum.x - a * mean.x * ssum) / cnt, (ysum.y - a * mean.y * ssum) / cnt);
+        }
+        out[2 * M] = mu;
+    }
+}
+
+// p = (y - a gL s - a gR s[N-1-i] - mean[mode 0]) * scale, transposed back to the paired (ih, k, j) layout with the upper half of
+// the spectrum rebuilt from the conjugate symmetry (see dist_combine_backward_kernel)
+__global__ void __launch_bounds__(256) sub_correct_combine_kernel(const double2 *Y, const double *svec, const double2 *iface, double2 *Z,
+                                                                  int Nxl, int Nxh, int Ny, int Nyh, int Nz, double a, double scale) {
+    __shared__ double2 tA[16][17], tB[16][17];
+    const int k = blockIdx.z, tx = threadIdx.x, ty = threadIdx.y;
+    const long M = (long)Nyh * Nz;
+    {
+        const int j = blockIdx.y * 16 + tx, ih = blockIdx.x * 16 + ty;
+        if (ih < Nxh && j < Nyh) {
+            const long m = j + (long)Nyh * k;
+            const double2 gl = iface[m], gr = iface[M + m];
+            const double2 mu = m == 0 ? iface[2 * M] : make_double2(0.0, 0.0);
+            double2 v[2];
+#pragma unroll
+            for (int o = 0; o < 2; ++o) {
+                const int i = 2 * ih + o;
+                if (i < Nxl) {
+                    const double2 y = Y[m + M * i];
+                    const double s0 = svec[m + M * i], s1 = svec[m + M * (Nxl - 1 - i)];
+                    v[o] = make_double2((y.x - a * gl.x * s0 - a * gr.x * s1 - mu.x) * scale, (y.y - a * gl.y * s0 - a * gr.y * s1 - mu.y) * scale);
+                } else v[o] = make_double2(0.0, 0.0);
+            }
+            tA[tx][ty] = v[0];
+            tB[tx][ty] = v[1];
+        }
+    }
+    __syncthreads();
+    {
+        const int ih = blockIdx.x * 16 + tx, j = blockIdx.y * 16 + ty;
+        if (ih < Nxh && j < Nyh) {
+            const double2 A = tA[ty][tx], B = tB[ty][tx];
+            Z[ih + (long)Nxh * (k + (long)Nz * j)] = make_double2(A.x - B.y, A.y + B.x);
+            const int jm = Ny - j, km = k == 0 ? 0 : Nz - k;
+            if (j != 0 && jm >= Nyh) Z[ih + (long)Nxh * (km + (long)Nz * jm)] = make_double2(A.x + B.y, B.x - A.y);
+        }
+    }
+}
+
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.
 __global__ void __launch_bounds__(256) sum_partial_kernel(const double2 *x, long n, double2 *partial) {
     __shared__ double sx[256], sy[256];

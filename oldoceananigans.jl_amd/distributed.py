@@ -77,6 +77,10 @@ class DistributedContext:
         """MPI.Alltoallv! with equal counts (distributed_transpose.jl:185-191)"""
         self.dist.all_to_all_single(recv, send)
 
+    def all_gather(self, gathered, payload):
+        """MPI.Allgather of equal pieces: rank r's payload lands at gathered[r * n : (r + 1) * n] on every rank"""
+        self.dist.all_gather_into_tensor(gathered, payload)
+
     def allreduce_max(self, value):
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self.device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
@@ -183,11 +187,18 @@ class DeviceBackend:
         _lib.check(L.ocn_dist_poisson_create(C.byref(h), g.handle, ctx.world, ctx.rank, grid.Lx_global))
         self.solver = h
         n = C.c_size_t()
-        _lib.check(L.ocn_dist_poisson_buffer_size(h, C.byref(n)))
-        self.send = torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
-        # one rank: the "transposes" are the identity -- alias the buffers instead of copying
-        self.recv = self.send if ctx.world == 1 else torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
-        _lib.check(L.ocn_dist_poisson_set_buffers(h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
+        _lib.check(L.ocn_dist_poisson_payload_size(h, C.byref(n)))
+        if n.value:
+            # substructured x solve: one small all-gather (2 values per mode) replaces the two all-to-alls
+            self.payload = torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
+            self.gathered = torch.zeros(2 * n.value * ctx.world, dtype=torch.float64, device=ctx.device)
+            _lib.check(L.ocn_dist_poisson_set_gather_buffers(h, C.c_void_p(self.payload.data_ptr()), C.c_void_p(self.gathered.data_ptr())))
+        else:
+            _lib.check(L.ocn_dist_poisson_buffer_size(h, C.byref(n)))
+            self.send = torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
+            # one rank: the "transposes" are the identity -- alias the buffers instead of copying
+            self.recv = self.send if ctx.world == 1 else torch.zeros(2 * n.value, dtype=torch.float64, device=ctx.device)
+            _lib.check(L.ocn_dist_poisson_set_buffers(h, C.c_void_p(self.send.data_ptr()), C.c_void_p(self.recv.data_ptr())))
         self.profile, self.events, self.n_evals = False, [], 0
 
     # -- halos ---------------------------------------------------------------------------------------------------
@@ -295,6 +306,12 @@ class DeviceBackend:
         U = self.U
         _lib.check(_lib.lib().ocn_dist_poisson_source_term(self.solver, U[0].data, U[1].data, U[2].data))
 
+    def poisson_forward_local(self):
+        _lib.check(_lib.lib().ocn_dist_poisson_forward_local(self.solver))
+
+    def poisson_backward_local(self):
+        _lib.check(_lib.lib().ocn_dist_poisson_backward_local(self.solver, self.p.data))
+
     def poisson_forward_yz(self):
         _lib.check(_lib.lib().ocn_dist_poisson_forward_yz(self.solver))
 
@@ -400,6 +417,15 @@ def solve_for_pressure(model):
     """solve_for_pressure! + solve!(::DistributedFFTBasedPoissonSolver) (distributed_fft_based_poisson_solver.jl:141-178)"""
     b, ctx = model.backend, model.ctx
     b.source_term()
+    if getattr(b, "payload", None) is not None:
+        # z Periodic: substructured solve along the partitioned direction -- local transforms and sweeps, one small all-gather
+        b.poisson_forward_local()
+        if ctx.world > 1:
+            ctx.all_gather(b.gathered, b.payload)
+        else:
+            b.gathered.copy_(b.payload)
+        b.poisson_backward_local()
+        return
     b.poisson_forward_yz()
     if b.recv is not b.send:
         ctx.all_to_all(b.recv, b.send)    # transpose_y_to_x!

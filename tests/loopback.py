@@ -49,6 +49,15 @@ class LoopbackContext:
             recv[s * n:(s + 1) * n].copy_(w.slots[s][self.rank * n:(self.rank + 1) * n])
         w.barrier_obj.wait()
 
+    def all_gather(self, gathered, payload):
+        w = self.w
+        w.slots[self.rank] = payload
+        w.barrier_obj.wait()
+        n = payload.numel()
+        for s in range(self.world):
+            gathered[s * n:(s + 1) * n].copy_(w.slots[s])
+        w.barrier_obj.wait()
+
     def allreduce_max(self, value):
         w = self.w
         w.vals[self.rank] = float(value)

@@ -86,6 +86,21 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
     (4, True, (28, 8, 12), "stretched"),       # stretched z, odd local Nx (7)
 ])
 def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_halos, size, zkind):
+    _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind)
+
+
+@pytest.mark.parametrize("R,size", [(2, (32, 16, 8)), (4, (36, 12, 10))])
+def test_transposing_solver_still_matches(ocn, oracle, arch, R, size):
+    """the all-to-all (transposed FFT) form of the distributed solver -- the reference's algorithm, kept behind the option
+    dist_substructured = 0 and used whenever z is Bounded -- on the periodic cases the substructured solve takes by default"""
+    ocn.set_option("dist_substructured", 0)
+    try:
+        _virtual_rank_case(ocn, oracle, arch, R, True, size, "periodic")
+    finally:
+        ocn.set_option("dist_substructured", 1)
+
+
+def _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind):
     import ctypes as C
     import torch
     from oldoceananigans_jl_amd import _lib
