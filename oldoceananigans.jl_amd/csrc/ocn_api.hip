@@ -1360,10 +1360,10 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
             TRY_OR_FREE(dev_alloc((void **)&s->rden, slab * sizeof(double)));
             TRY_OR_FREE(dev_alloc((void **)&s->cpf, slab * sizeof(double)));
             TRY_OR_FREE(dev_alloc((void **)&s->svec, slab * sizeof(double)));
-            TRY_OR_FREE(dev_alloc((void **)&s->iface, (2 * (size_t)s->M + 1) * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->iface, (2 * (size_t)s->M + 2) * sizeof(double2)));      // + one slot: Σ s of the null mode
             const double a = 1.0 / (g.dx * g.dx);
             hipLaunchKernelGGL(sub_setup_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, (int)s->M, s->Nyh, s->Nxl, a,
-                               s->lam[1], s->lam[2], s->rden, s->cpf, s->svec);
+                               s->lam[1], s->lam[2], s->rden, s->cpf, s->svec, (double *)(s->iface + 2 * s->M + 1));
             TRY_OR_FREE(hipGetLastError());
         }
         if (!s->sub && zmode == 0 && g_fused_zfft && s->Nxg >= 8 && s->Nxg <= 4096 && (s->Nxg & (s->Nxg - 1)) == 0) {
@@ -1443,7 +1443,7 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
     const DGrid &g = s->grid->d;
     const double a = 1.0 / (g.dx * g.dx);
     hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Nyh, s->Nxl, s->R, s->rank,
-                       a, s->lam[1], s->lam[2], s->svec, s->gathered, s->iface);
+                       a, s->lam[1], s->lam[2], s->svec, (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
     const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
     const double scale = 1.0 / ((double)s->Ny * (double)s->Nz);
     hipLaunchKernelGGL(sub_correct_combine_kernel, grd, blk, 0, g_stream, s->Y, s->svec, s->iface, s->zfield, s->Nxl, s->Nxh, s->Ny, s->Nyh,

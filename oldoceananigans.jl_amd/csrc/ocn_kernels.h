@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(256) xline_solve_kernel(const double2 *recv, d
 // ---------------------------------------------------------------------------------------------------------------------
 // setup, one thread per mode: rden[i] = 1 / (b - a cp[i-1]), cp[i] = a rden[i], s = T⁻¹ e₀ (T = tridiag(a, b, a), b = -2a - λ)
 __global__ void __launch_bounds__(256) sub_setup_kernel(int M, int Nyh, int N, double a, const double *ly, const double *lz, double *rden,
-                                                        double *cp, double *svec) {
+                                                        double *cp, double *svec, double *ssum0) {
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const int jy = m % Nyh, k = m / Nyh;
@@ -1008,6 +1008,11 @@ __global__ void __launch_bounds__(256) sub_setup_kernel(int M, int Nyh, int N, d
     svec[m] = y;
     for (int i = 1; i < N; ++i) { y = (-a * y) * rden[m + (long)M * i]; svec[m + (long)M * i] = y; }
     for (int i = N - 2; i >= 0; --i) svec[m + (long)M * i] -= cp[m + (long)M * i] * svec[m + (long)M * (i + 1)];
+    if (m == 0) {                             // Σ_i s[i] of the null mode (its global mean needs it at every solve)
+        double t = 0.0;
+        for (int i = 0; i < N; ++i) t += svec[(long)M * i];
+        *ssum0 = t;
+    }
 }
 
 // separate the paired columns (see dist_pack_forward_kernel) and transpose (ih, k, j) -> (m, i) through an LDS tile
@@ -1079,7 +1084,8 @@ __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a,
 // interface unknowns from the gathered payloads (R ranks x (2M + 1)): per mode an R-point DFT over the rank index, 2x2 solves, and
 // the two values this rank needs: gL = l[rank-1], gR = f[rank+1]. out[m] = gL, out[M+m] = gR, out[2M] = mean of mode 0
 __global__ void __launch_bounds__(256) sub_interface_kernel(long M, int Nyh, int N, int R, int rank, double a, const double *ly,
-                                                            const double *lz, const double *svec, const double2 *gathered, double2 *out) {
+                                                            const double *lz, const double *svec, const double *ssum0,
+                                                            const double2 *gathered, double2 *out) {
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const long stride = 2 * M + 1;
@@ -1137,8 +1143,7 @@ __global__ void __launch_bounds__(256) sub_interface_kernel(long M, int Nyh, int
             // global sum of p = Σ_r Σ_i y_r[i] - a (Σ_r gL_r + Σ_r gR_r) Σ_i s[i];  Σ_r gL_r = l̂_0, Σ_r gR_r = f̂_0 (q = 0 of the DFT)
             double2 ysum = make_double2(0.0, 0.0);
             for (int r = 0; r < R; ++r) { ysum.x += gathered[r * stride + 2 * M].x; ysum.y += gathered[r * stride + 2 * M].y; }
-            double ssum = 0.0;
-            for (int i = 0; i < N; ++i) ssum += svec[M * i];
+            const double ssum = *ssum0;
             const double cnt = (double)R * (double)N;
             mu = make_double2((ysum.x - a * mean.x * ssum) / cnt, (ysum.y - a * mean.y * ssum) / cnt);
         }

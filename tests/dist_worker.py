@@ -38,7 +38,13 @@ def main():
     div = dist.max_abs_divergence(model)
     out = {n: f.parent() for n, f in flds.items()}
     out["p"] = backend.p.parent()
-    np.savez(os.path.join(outdir, f"rank{ctx.rank}.npz"), div=div, time=model.time, iteration=model.iteration, **out)
+    # the collective of the substructured pressure solve (DistributedContext.all_gather): rank r's piece lands at slot r everywhere
+    import torch
+    piece = torch.full((5,), float(ctx.rank + 1), dtype=torch.float64)
+    gathered = torch.zeros(5 * ctx.world, dtype=torch.float64)
+    ctx.all_gather(gathered, piece)
+    gather_ok = bool(all(torch.all(gathered[r * 5:(r + 1) * 5] == r + 1) for r in range(ctx.world)))
+    np.savez(os.path.join(outdir, f"rank{ctx.rank}.npz"), div=div, time=model.time, iteration=model.iteration, gather_ok=gather_ok, **out)
     ctx.barrier()
 
 
