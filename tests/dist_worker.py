@@ -44,7 +44,15 @@ def main():
     gathered = torch.zeros(5 * ctx.world, dtype=torch.float64)
     ctx.all_gather(gathered, piece)
     gather_ok = bool(all(torch.all(gathered[r * 5:(r + 1) * 5] == r + 1) for r in range(ctx.world)))
-    np.savez(os.path.join(outdir, f"rank{ctx.rank}.npz"), div=div, time=model.time, iteration=model.iteration, gather_ok=gather_ok, **out)
+    # test/test_distributed_models.jl:334-404: fields filled with the rank id; after the exchange the x halos hold the neighbours' ids
+    for n, f in enumerate(backend.U):
+        f.a[...] = 100 * n + ctx.rank
+    dist.fill_halo_regions(model, backend.U, fill_open_bcs=False)
+    west, east = (ctx.rank - 1) % ctx.world, (ctx.rank + 1) % ctx.world
+    ids_ok = all(bool(np.all(f.a[:3] == 100 * n + west) and np.all(f.a[-3:] == 100 * n + east) and np.all(f.a[3:-3] == 100 * n + ctx.rank))
+                 for n, f in enumerate(backend.U))
+    np.savez(os.path.join(outdir, f"rank{ctx.rank}.npz"), div=div, time=model.time, iteration=model.iteration, gather_ok=gather_ok,
+             ids_ok=ids_ok, **out)
     ctx.barrier()
 
 

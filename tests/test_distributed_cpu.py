@@ -54,7 +54,7 @@ def test_two_rank_model_matches_serial_oracle(oracle, tmp_path, async_halos):
     nxl = size[0] // 2
     for r, data in enumerate(ranks):
         assert int(data["iteration"]) == nsteps and float(data["time"]) == m.time
-        assert float(data["div"]) < 5e-8 and bool(data["gather_ok"])
+        assert float(data["div"]) < 5e-8 and bool(data["gather_ok"]) and bool(data["ids_ok"])
         for name, cn in (("u", "u"), ("v", "v"), ("w", "w"), ("T", "c0"), ("S", "c1"), ("p", "p")):
             glob = m.field(cn)
             mine = data[name]

@@ -138,3 +138,90 @@ def _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind):
                 lo = 3 + r * nxl - 3
                 west = glob[name][lo:lo + 3, 3:-3, 3:-3] if r > 0 else glob[name][size[0]:size[0] + 3, 3:-3, 3:-3]
                 assert rel_err(a[:3, 3:-3, 3:-3], west) <= 1e-12
+
+
+def _in_virtual_ranks(arch, R, fn):
+    """run fn(ctx, dist) on R virtual ranks (threads) and return the per-rank results"""
+    import torch
+    from oldoceananigans_jl_amd import distributed as dist
+    from loopback import LoopbackWorld
+    world = LoopbackWorld(R, torch, arch)
+    results, errors = [None] * R, []
+
+    def worker(rank):
+        try:
+            results[rank] = fn(world.context(rank), dist)
+        except BaseException as e:          # noqa: BLE001
+            errors.append((rank, repr(e)))
+            world.barrier_obj.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("R", [2, 4])
+def test_halo_exchange_with_rank_ids_is_exact(ocn, arch, R):
+    """test/test_distributed_models.jl:334-404: every rank fills its fields with its rank id; after fill_halo_regions! the west /
+    east halos hold the neighbours' ids exactly (`==`), corners included, y / z halos the own id"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    def fn(ctx, dist):
+        grid = dist.DistributedRectilinearGrid(ctx, size=(8 * R, 8, 5), x=(0.0, 1.0), y=(0.0, 1.0), z=(-1.0, 0.0),
+                                               topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
+        b = model.backend
+        for n, f in enumerate(b.U):
+            f.set_parent(np.full(f.shape, float(100 * n + ctx.rank)))
+        dist.fill_halo_regions(model, b.U, fill_open_bcs=False)
+        return [f.parent() for f in b.U]
+    out = _in_virtual_ranks(arch, R, fn)
+    for r in range(R):
+        for n, a in enumerate(out[r]):
+            west, east = 100 * n + (r - 1) % R, 100 * n + (r + 1) % R
+            assert np.all(a[:3, :, :] == west) and np.all(a[-3:, :, :] == east), (r, n)       # whole y / z extent: corners ride along
+            assert np.all(a[3:-3, :, :] == 100 * n + r)
+
+
+@pytest.mark.parametrize("R,size", [(2, (16, 8, 6)), (4, (36, 12, 10))])
+def test_transposes_round_trip(ocn, arch, R, size):
+    """test/test_distributed_transpose.jl:13-54: y -> x -> y transposes return the original field. Here: the transposing solver's
+    forward stage (local transform, separation, pack), all-to-all, all-to-all back, backward stage (rebuild, inverse transform) with
+    NO solve in between returns the source term times Ny Nz -- the index algebra of pack / unpack / Hermitian rebuild is the identity"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ocn.set_option("dist_substructured", 0)
+
+    def fn(ctx, dist):
+        grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0))
+        model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=())
+        b = model.backend
+        rng = np.random.default_rng(ctx.rank)
+        for f in b.U[:3]:
+            f.set_parent(rng.standard_normal(f.shape))
+        dist.fill_halo_regions(model, b.U[:3])
+        b.source_term()
+        g = grid.local
+        u, v, w = (f.parent() for f in b.U[:3])
+        div = ((u[4:-2, 3:-3, 3:-3] - u[3:-3, 3:-3, 3:-3]) / g.Δxᶜᵃᵃ + (v[3:-3, 4:-2, 3:-3] - v[3:-3, 3:-3, 3:-3]) / g.Δyᵃᶜᵃ +
+               (w[3:-3, 3:-3, 4:-2] - w[3:-3, 3:-3, 3:-3]) / g.Δzᵃᵃᶜ[3])
+        b.poisson_forward_yz()
+        ctx.all_to_all(b.recv, b.send)          # transpose_y_to_x!
+        b.send.copy_(b.recv)                    # (no x stage)
+        ctx.all_to_all(b.recv, b.send)          # transpose_x_to_y!
+        b.poisson_backward_yz()
+        return b.p.parent()[3:-3, 3:-3, 3:-3] / (size[1] * size[2]), div
+    try:
+        out = _in_virtual_ranks(arch, R, fn)
+    finally:
+        ocn.set_option("dist_substructured", 1)
+    for back, div in out:
+        assert np.abs(back - div).max() < 1e-12 * np.abs(div).max()

@@ -624,3 +624,36 @@ def test_internal_wave_dynamics(oracle, f, ytopo):
     ue = u_exact(m.time)
     assert np.mean((u - ue) ** 2) / np.mean(ue ** 2) < 1e-4
     assert np.mean((u - u_exact(0.0)) ** 2) / np.mean(ue ** 2) > 1e-4        # the wave did propagate
+
+
+def test_passive_tracer_advection_as_the_reference_runs_it(oracle):
+    """passive_tracer_advection_test (test/test_dynamics.jl:177-208): Gaussian of width L/15 carried by (U, V) = (0.5, 0.8), N = 128,
+    100 steps of Δt = 0.05 (L/N) / |U|, ScalarDiffusivity(ν = κ = 1e-12), SeawaterBuoyancy, tracers (T, S): mean-square relative error
+    of T below 1e-4. (Nz = 4 instead of the reference's 2: this implementation wants N >= halo in non-Flat directions.)"""
+    N, L, U, V, Nt = 128, 1.0, 0.5, 0.8, 100
+    d, x0, y0 = L / 15, L / 2, L / 2
+    dt = 0.05 * L / N / np.sqrt(U ** 2 + V ** 2)
+    g = oracle.Grid((N, N, 4), x=(0.0, L), y=(0.0, L), z=(-L, 0.0))
+    m = oracle.Model(g, 2)
+    m.set_closure(nu=1e-12, kappa=1e-12)
+    m.set_seawater_buoyancy(0, 1)
+    xc = ((np.arange(N) + 0.5) * L / N).reshape(N, 1, 1)
+    yc = xc.reshape(1, N, 1)
+
+    def T(t):
+        return np.exp(-((xc - U * t - x0) ** 2 + (yc - V * t - y0) ** 2) / (2 * d ** 2)) * np.ones((N, N, 4))
+    one = np.ones((N, N, 4))
+    m.set(u=U * one, v=V * one, w=0 * one, c0=T(0.0), c1=0 * one)
+    for _ in range(Nt):
+        m.time_step(dt)
+    Tn, Te = g.interior_cells(m.field("c0")), T(m.time)
+    assert np.mean((Tn - Te) ** 2) / np.mean(Te ** 2) < 1e-4
+
+
+def test_incompressibility_after_100_rk3_steps(oracle):
+    """test/test_time_stepping.jl:124-160: 32^3, random velocities, max|div u| < 5e-8 after 100 steps too"""
+    g = oracle.Grid((32, 32, 32))
+    m = _random_model(oracle, g, seed=11)
+    for _ in range(100):
+        m.time_step(1e-4)
+    assert m.iteration == 100 and m.max_abs_divergence() < 5e-8
