@@ -36,8 +36,8 @@ def main():
     for _ in range(nsteps):
         dist.time_step(model, dt)
     div = dist.max_abs_divergence(model)
-    out = {n: f.parent() for n, f in flds.items()}
-    out["p"] = backend.p.parent()
+    out = {n: np.array(f.parent(), copy=True) for n, f in flds.items()}
+    out["p"] = np.array(backend.p.parent(), copy=True)
     # the collective of the substructured pressure solve (DistributedContext.all_gather): rank r's piece lands at slot r everywhere
     import torch
     piece = torch.full((5,), float(ctx.rank + 1), dtype=torch.float64)
