@@ -244,6 +244,10 @@ int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *st
                     double *last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */
 int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
+/* cell_advection_timescale(grid, velocities) (Advection/cell_advection_timescale.jl:13-34): min over cells of
+ * 1 / (|u|/Δx + |v|/Δy + |w|/Δz) -- what TimeStepWizard multiplies by the CFL number. Synchronous. */
+int ocn_cell_advection_timescale(ocn_grid_t grid, const double *u, const double *v, const double *w, double *tau);
+int ocn_model_cell_advection_timescale(ocn_model_t model, double *tau);
 int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value);
 /* options: "tendency_impl" 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel;
  * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "fuse_substep" 1 = fuse the

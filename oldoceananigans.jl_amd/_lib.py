@@ -62,6 +62,8 @@ SYMBOLS = {
     "ocn_model_set_buoyancy": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double]),
     "ocn_add_fplane_coriolis": (C.c_int, [_vp, C.c_double, _vp, _vp, _vp, _vp, _ip]),
     "ocn_model_set_coriolis": (C.c_int, [_vp, C.c_int, C.c_double]),
+    "ocn_cell_advection_timescale": (C.c_int, [_vp, _vp, _vp, _vp, _dp]),
+    "ocn_model_cell_advection_timescale": (C.c_int, [_vp, _dp]),
     "ocn_model_get_option": (C.c_int, [_vp, C.c_char_p, _ip]),
     "ocn_model_set_boundary_condition": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),

@@ -2033,6 +2033,28 @@ extern "C" int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, in
     return OCN_OK;
 }
 
+extern "C" int ocn_cell_advection_timescale(ocn_grid_t grid, const double *u, const double *v, const double *w, double *tau) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !tau) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = grid->d;
+    const int nb = 1024;
+    double *blockmax;
+    HIP_TRY(dev_alloc((void **)&blockmax, nb * sizeof(double)));
+    hipLaunchKernelGGL(advection_timescale_kernel, dim3(nb), dim3(256), 0, g_stream, g, make_view(g, u, LOC_U), make_view(g, v, LOC_V),
+                       make_view(g, w, LOC_W), blockmax);
+    double m = 0;
+    int rc = reduce_blockmax(blockmax, nb, &m);
+    hipFree(blockmax);
+    if (rc) return rc;
+    *tau = 1.0 / m;              // Inf for a fluid at rest, like the reference's 1 / 0
+    return OCN_OK;
+}
+
+extern "C" int ocn_model_cell_advection_timescale(ocn_model_t m, double *tau) {
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    return ocn_cell_advection_timescale(m->grid, m->U[0], m->U[1], m->U[2], tau);
+}
+
 extern "C" int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !value) return fail(OCN_EINVAL, "NULL argument");

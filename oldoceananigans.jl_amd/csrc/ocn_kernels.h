@@ -1241,6 +1241,29 @@ __global__ void __launch_bounds__(256) max_abs_div_kernel(DGrid g, FView u, FVie
     if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
 }
 
+// cell_advection_timescale (Advection/cell_advection_timescale.jl:13-34): per-block maximum of the inverse timescale
+// |u| Δx⁻¹ + |v| Δy⁻¹ + |w| Δzᶠ⁻¹ (min of 1/x = 1 / max of x: the division is monotone, the result has the reference's bits)
+__global__ void __launch_bounds__(256) advection_timescale_kernel(DGrid g, FView u, FView v, FView w, double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    const long total = (long)g.Nx * g.Ny * g.Nz;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int i = 1 + q % g.Nx, j = 1 + (q / g.Nx) % g.Ny, k = 1 + q / ((long)g.Nx * g.Ny);
+        const double ix = g.tx == OCN_FLAT ? 0.0 : fabs(u.at(i, j, k)) * (1.0 / g.dx);
+        const double iy = g.ty == OCN_FLAT ? 0.0 : fabs(v.at(i, j, k)) * (1.0 / g.dy);
+        const double iz = g.tz == OCN_FLAT ? 0.0 : fabs(w.at(i, j, k)) * (1.0 / g.dzf[k - 1 + g.Hz]);
+        const double d = (ix + iy) + iz;
+        m = d > m ? d : m;
+    }
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}
+
 // exhaustive check of rcp_rn_f32<VARIANT> against the compiler's correctly rounded divide over one binade
 template <int VARIANT>
 __global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsigned long long *mismatches) {

@@ -1272,6 +1272,24 @@ void oro_model_time_step_ab2(oro_model *m, double dt, double chi, int euler) {
     oro_model_update_state(m, 1);
 }
 
+/* Advection/cell_advection_timescale.jl:13-34: minimum over cells of 1 / (|u|/Δxᶠ + |v|/Δyᶠ + |w|/Δzᶠ) with Δ⁻¹ = 1/Δ; a Flat
+ * direction contributes 0 */
+double oro_cell_advection_timescale(const oro_grid *g, const double *u, const double *v, const double *w) {
+    fld U = mkfld(g, u, LOC_U), V = mkfld(g, v, LOC_V), W = mkfld(g, w, LOC_W);
+    double tau = INFINITY;
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) {
+                const double ix = g->topo[0] == ORO_FLAT ? 0.0 : fabs(AT(U, i, j, k)) * (1.0 / DF(g, 0, i));
+                const double iy = g->topo[1] == ORO_FLAT ? 0.0 : fabs(AT(V, i, j, k)) * (1.0 / DF(g, 1, j));
+                const double iz = g->topo[2] == ORO_FLAT ? 0.0 : fabs(AT(W, i, j, k)) * (1.0 / DF(g, 2, k));
+                const double t = 1.0 / ((ix + iy) + iz);
+                if (t < tau) tau = t;
+            }
+    return tau;
+}
+double oro_model_cell_advection_timescale(oro_model *m) { return oro_cell_advection_timescale(m->g, m->U[0], m->U[1], m->U[2]); }
+
 double oro_model_time(const oro_model *m) { return m->time; }
 int oro_model_iteration(const oro_model *m) { return m->iteration; }
 

@@ -125,6 +125,9 @@ void oro_model_time_step(oro_model *m, double dt);
 /* QuasiAdamsBashforth2TimeStepper (TimeSteppers/quasi_adams_bashforth_2.jl:74-175), χ default 0.1 */
 void oro_model_time_step_ab2(oro_model *m, double dt, double chi, int euler);
 void oro_ab2_step_field(const oro_grid *g, double *U, const int loc[3], double dt, double chi, const double *Gn, const double *Gm);
+/* cell_advection_timescale(grid, velocities) (Advection/cell_advection_timescale.jl:13-34) */
+double oro_cell_advection_timescale(const oro_grid *g, const double *u, const double *v, const double *w);
+double oro_model_cell_advection_timescale(oro_model *m);
 double oro_model_time(const oro_model *m);
 int oro_model_iteration(const oro_model *m);
 double oro_model_max_abs_divergence(oro_model *m);

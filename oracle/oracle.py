@@ -107,6 +107,8 @@ def lib():
         L.oro_model_update_state.argtypes = [vp, C.c_int]
         L.oro_model_set_finalize.argtypes = [vp, C.c_int]
         L.oro_model_time_step.argtypes = [vp, C.c_double]
+        L.oro_model_cell_advection_timescale.restype = C.c_double
+        L.oro_model_cell_advection_timescale.argtypes = [vp]
         L.oro_model_time_step_ab2.argtypes = [vp, C.c_double, C.c_double, C.c_int]
         L.oro_model_time.restype = C.c_double
         L.oro_model_time.argtypes = [vp]
@@ -355,6 +357,9 @@ class Model:
 
     def time_step(self, dt):
         lib().oro_model_time_step(self.handle, float(dt))
+
+    def cell_advection_timescale(self):
+        return lib().oro_model_cell_advection_timescale(self.handle)
 
     def time_step_ab2(self, dt, chi=0.1, euler=False):
         """time_step!(model::AbstractModel{<:QuasiAdamsBashforth2TimeStepper}, Δt; euler)"""

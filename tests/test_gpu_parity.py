@@ -512,3 +512,32 @@ def test_fused_epilogue_is_bit_identical_to_separate_kernels(ocn, arch, topology
         # exclude_periphery, like the reference; nothing reads them)
         core = (slice(4, -3), slice(3, -3), slice(3, -3)) if n == "Gu" else (slice(None),) * 3
         assert np.array_equal(out[0][n][core], out[1][n][core]), n
+
+
+def test_time_step_wizard_and_advection_timescale(ocn, oracle, arch):
+    """wall_time_step_wizard_tests (test/test_simulations.jl:14-75) -- a single moving cell of u -- and cell_advection_timescale
+    (Advection/cell_advection_timescale.jl:13-34) bit-identical to the oracle on random velocities over a stretched grid"""
+    grid = ocn.RectilinearGrid(arch, size=(4, 4, 4), extent=(1, 1, 1))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=())
+    dx, CFL, u0 = grid.Δxᶜᵃᵃ, 0.45, 7.0
+    u = np.zeros(grid.interior_size(model.velocities.u.loc))
+    u[0, 0, 0] = u0
+    model.velocities.u.set(u)
+    W = ocn.TimeStepWizard
+    dt = ocn.new_time_step(2.5, W(cfl=CFL, max_change=np.inf, min_change=0), model)
+    assert np.isclose(dt, CFL * dx / u0, rtol=1e-15)
+    assert np.isclose(ocn.new_time_step(1.0, W(cfl=CFL, max_change=np.inf, min_change=0.75), model), 0.75)
+    assert np.isclose(ocn.new_time_step(dt, W(cfl=CFL, max_change=np.inf, min_change=0, min_Δt=1.99), model), 1.99)
+    u[0, 0, 0] = u0 / 100
+    model.velocities.u.set(u)
+    assert np.isclose(ocn.new_time_step(1.0, W(cfl=CFL, max_change=1.1, min_change=0), model), 1.1)
+    free = CFL * dx / (u0 / 100)                     # (the reference's grid has Δx = 1; here Δx = 1/4)
+    assert np.isclose(ocn.new_time_step(1.99, W(cfl=CFL, max_change=np.inf, min_change=0, max_Δt=0.5 * free), model), 0.5 * free)
+    m2 = ocn.NonhydrostaticModel(grid=grid, tracers=(), closure=ocn.ScalarDiffusivity(ν=1.0))
+    assert np.isclose(ocn.new_time_step(1.0, W(cfl=np.inf, diffusive_cfl=0.45, max_change=np.inf, min_change=0), m2), 0.45 * dx ** 2 / 1.0)
+    with pytest.raises(ValueError):
+        W(min_change=1.5)
+    # against the oracle
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, (12, 10, 9), ("Periodic", "Bounded", "Bounded"), z=tanh_faces(9))
+    set_both(ocn, m_gpu, m_cpu, seed=2, enforce_incompressibility=False)       # identical inputs (no projection round-off)
+    assert ocn.cell_advection_timescale(m_gpu) == m_cpu.cell_advection_timescale()

@@ -657,3 +657,22 @@ def test_incompressibility_after_100_rk3_steps(oracle):
     for _ in range(100):
         m.time_step(1e-4)
     assert m.iteration == 100 and m.max_abs_divergence() < 5e-8
+
+
+def test_cell_advection_timescale(oracle):
+    """Advection/cell_advection_timescale.jl:13-34 with the values of wall_time_step_wizard_tests (test/test_simulations.jl:14-75):
+    one moving cell of u gives Δx / u₀; at rest the time-scale is infinite; on a stretched grid w uses Δzᵃᵃᶠ"""
+    g = oracle.Grid((4, 4, 4))
+    m = oracle.Model(g, 0)
+    z = np.zeros((4, 4, 4))
+    m.set(u=z, v=z, w=z, enforce_incompressibility=False)
+    assert m.cell_advection_timescale() == np.inf
+    u = z.copy(); u[1, 2, 3] = -7.0
+    m.set(u=u, v=z, w=z, enforce_incompressibility=False)
+    assert m.cell_advection_timescale() == 0.25 / 7.0
+    zf = np.array([0.0, 0.1, 0.3, 0.6, 1.0])
+    g = oracle.Grid((4, 4, 4), topology=(oracle.PERIODIC, oracle.PERIODIC, oracle.BOUNDED), z=zf)
+    m = oracle.Model(g, 0)
+    w = np.zeros((4, 4, 5)); w[0, 0, 2] = 2.0        # face k = 3 (1-based): Δzᵃᵃᶠ = zc[3] - zc[2] = 0.45 - 0.2
+    m.set(u=z, v=z, w=w, enforce_incompressibility=False)
+    assert np.isclose(m.cell_advection_timescale(), 0.25 / 2.0, rtol=1e-15)
