@@ -143,7 +143,10 @@ def main():
     distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1"
     if distributed:
         from oldoceananigans_jl_amd import distributed as dist
-        ctx = dist.init_process_group(local_rank)
+        # OCN_REHEARSE_ON_ONE_GPU=1: all ranks share card 0, collectives staged through the host over gloo -- exercises this
+        # script's N > 1 path on a one-GPU box; the numbers it prints are not measurements
+        rehearsal = os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1"
+        ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=rehearsal)
         arch = ctx.arch
         grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
         model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
@@ -219,7 +222,7 @@ def main():
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
-    fused_substep = (not distributed) and model.get_option("fuse_substep_active") == 1
+    fused_substep = (model.fuse_substep_active() if distributed else model.get_option("fuse_substep_active") == 1)
     bytes_per_cell = TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * fused_substep
     cells_per_gpu = cells / world
     achieved = bytes_per_cell * cells_per_gpu / t_launch / 1e9 if tend_n else None
@@ -227,7 +230,8 @@ def main():
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" else None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
+        else "synthetic; REHEARSAL on one card over gloo + host staging: not a measurement",
         "config": {"workload": (f"{N * world}x{N}x{N} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
                                 "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])")
                    if args.workload == "ppp" else
@@ -235,7 +239,8 @@ def main():
                     "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +
                     ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
                      if args.workload == "ppb_physics" else "")),
-                   "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}), RCCL halo + all-to-all transposes",
+                   "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}): RCCL send/recv halos, substructured x solve "
+                                                                     "(one all-gather of 2 complex per mode per solve)",
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
                                        "benchmarks.md:128); older version without RK3/2 tracers -- context only"},

@@ -90,8 +90,65 @@ class DistributedContext:
         self.dist.barrier()
 
 
-def init_process_group(local_rank=0, backend=None):
-    """one process per GPU; MASTER_ADDR/PORT, RANK, WORLD_SIZE come from torch.distributed.run"""
+class HostStagedContext(DistributedContext):
+    """REHEARSAL ONLY (never selected by default): the same ranks, buffers and call order as DistributedContext, but every
+    collective is staged through host memory and run over gloo, so that N processes can share ONE card (RCCL refuses two
+    ranks on one device). It exists to run the real multi-process DeviceBackend + bench.py path on a one-GPU box; its
+    timings mean nothing."""
+
+    def _host(self, t):
+        self.torch.cuda.current_stream().synchronize()
+        return t.cpu()
+
+    def exchange_start(self, west_send, east_send, west_recv, east_recv):
+        d = self.dist
+        ws, es = self._host(west_send), self._host(east_send)
+        wr, er = self.torch.empty_like(ws), self.torch.empty_like(es)
+        ops = [d.P2POp(d.isend, ws, self.west, tag=1), d.P2POp(d.irecv, er, self.east, tag=1),
+               d.P2POp(d.isend, es, self.east, tag=2), d.P2POp(d.irecv, wr, self.west, tag=2)]
+        for req in d.batch_isend_irecv(ops):
+            req.wait()
+        west_recv.copy_(wr)
+        east_recv.copy_(er)
+        return []
+
+    def all_to_all(self, recv, send):
+        # gloo has no all_to_all_single: equal pieces, piece r of `send` goes to rank r
+        d, R = self.dist, self.world
+        h = self._host(send).reshape(R, -1)
+        out = self.torch.empty_like(h)
+        reqs = []
+        for r in range(R):
+            if r == self.rank:
+                out[r].copy_(h[r])
+            else:
+                reqs.append(d.isend(h[r].contiguous(), r, tag=10 + self.rank))
+        bufs = {}
+        for r in range(R):
+            if r != self.rank:
+                bufs[r] = self.torch.empty_like(h[r])
+                reqs.append(d.irecv(bufs[r], r, tag=10 + r))
+        for req in reqs:
+            req.wait()
+        for r, b in bufs.items():
+            out[r].copy_(b)
+        recv.copy_(out.reshape(recv.shape))
+
+    def all_gather(self, gathered, payload):
+        h = self._host(payload)
+        out = self.torch.empty(self.world * h.numel(), dtype=h.dtype)
+        self.dist.all_gather_into_tensor(out, h.reshape(-1))
+        gathered.copy_(out.reshape(gathered.shape))
+
+    def allreduce_max(self, value):
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False):
+    """one process per GPU; MASTER_ADDR/PORT, RANK, WORLD_SIZE come from torch.distributed.run.
+    rehearse_on_one_gpu: all ranks on card 0, collectives staged through the host over gloo (HostStagedContext)"""
     if _lib._lib is not None and _lib.LOADED_BEFORE_TORCH:
         raise _lib.OcnError("libocn_mi355x.so was loaded before torch: torch bundles its own ROCm runtime under the same "
                             "sonames and cannot initialise on top of the system one. Import torch (or this module) and call "
@@ -100,6 +157,15 @@ def init_process_group(local_rank=0, backend=None):
     import torch.distributed as dist
     from .architectures import GPU
     use_gpu = torch.cuda.is_available()
+    if rehearse_on_one_gpu:
+        if not use_gpu:
+            raise _lib.OcnError("rehearse_on_one_gpu needs a GPU")
+        torch.cuda.set_device(0)
+        if not dist.is_initialized():
+            dist.init_process_group("gloo")
+        arch = GPU(0)
+        _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return HostStagedContext(dist.get_rank(), dist.get_world_size(), torch.device("cuda", 0), torch, dist, arch)
     if backend is None:
         backend = "nccl" if use_gpu else "gloo"
     if not dist.is_initialized():
@@ -401,6 +467,11 @@ class DistributedNonhydrostaticModel:
     def profile_read(self):
         return self.backend.profile_read()
 
+    def fuse_substep_active(self):
+        """whether time_step fuses rk3_substep! of stages 2 and 3 into the preceding tendency evaluation"""
+        b = self.backend
+        return bool(getattr(self, "fuse_substep", True) and hasattr(b, "can_fuse_substep") and b.can_fuse_substep())
+
 
 def fill_halo_regions(model, fields, fill_open_bcs=True):
     """fill_halo_regions! of partitioned fields (halo_communication.jl:87-110): local boundary conditions first
@@ -518,7 +589,7 @@ def time_step(model, Δt):
     stage_dt = (Δt * γ[0], Δt * (γ[1] + ζ[1]), Δt * (γ[2] + ζ[2]))
     tn1 = model.time + Δt
     # stages 2 and 3: rk3_substep! is fused into the tendency evaluation that precedes it (backend permitting)
-    fuse = getattr(model, "fuse_substep", True) and hasattr(b, "can_fuse_substep") and b.can_fuse_substep()
+    fuse = model.fuse_substep_active()
     substep_done = False
     for s in range(3):
         if not substep_done:

@@ -225,3 +225,38 @@ def test_transposes_round_trip(ocn, arch, R, size):
         ocn.set_option("dist_substructured", 1)
     for back, div in out:
         assert np.abs(back - div).max() < 1e-12 * np.abs(div).max()
+
+
+@pytest.mark.parametrize("R,size,zkind,substructured", [(2, (32, 16, 8), "periodic", 1), (4, (32, 16, 8), "periodic", 1),
+                                                        (2, (32, 16, 8), "periodic", 0), (2, (32, 16, 12), "stretched", 1)])
+def test_separate_processes_match_single_gpu(ocn, arch, tmp_path, R, size, zkind, substructured):
+    """the N > 1 product path as the driver launches it -- torch.distributed.run, one process per rank, DeviceBackend, rank-local
+    coordinates from the environment -- except that the R processes share this box's one card and stage their collectives
+    through the host (HostStagedContext). Fields after 3 RK3 steps against the single-GPU model on the global grid."""
+    import subprocess
+    import sys
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    nsteps = 3
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={R}", "--master-addr", "127.0.0.1",
+           "--master-port", str(29530 + R + 10 * substructured), os.path.join(here, "gpu_dist_worker.py"), str(tmp_path),
+           str(size[0]), str(size[1]), str(size[2]), str(nsteps), zkind, str(substructured)]
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
+    z, topo = _z_and_topology(ocn, zkind, size[2])
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+    ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
+    dt = 0.1 * grid.Δxᶜᵃᵃ / 0.6
+    for _ in range(nsteps):
+        ocn.time_step(model, dt)
+    glob = {n: f.parent() for n, f in model.fields().items()}
+    glob["p"] = model.pressures.pNHS.parent()
+    nxl = size[0] // R
+    for r in range(R):
+        out = np.load(tmp_path / f"rank{r}.npz")
+        assert float(out["div"]) < 5e-8 and float(out["time"]) == model.clock.time
+        for name, ref in glob.items():
+            a = out[name]
+            err = np.abs(a[3:-3, 3:-3, 3:-3] - ref[3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]).max() / np.abs(ref).max()
+            assert err <= 1e-12, (r, name, err)
