@@ -506,6 +506,19 @@ def solve_for_pressure(model):
     b.poisson_backward_yz()
 
 
+def buffer_strip_width(model, Nx, Hx):
+    """width of the two x strips that wait for the halos. The reference uses Hx (interleave_communication_and_computation.jl:
+    69-119); any width >= Hx gives the same tendencies. The fused kernel works on 64-lane-wide tiles, so an Hx-wide strip costs
+    as much as a 64-wide one (measured at 256^3: interior + two 3-wide strips 2.49 ms, interior + two 64-wide strips 1.51 ms,
+    one launch 1.42 ms): strips are one whole tile wide whenever that leaves an interior of at least one tile."""
+    W = getattr(model, "strip_width", None)
+    if W is None:
+        W = 64 if Nx >= 3 * 64 else Hx
+    if not (Hx <= W and 2 * W < Nx):
+        raise ValueError(f"strip width {W} must satisfy Hx <= W < Nx / 2")
+    return W
+
+
 def update_state(model, compute_tendencies=True):
     """update_state! (update_nonhydrostatic_model_state.jl:20-56) + compute_tendencies! with the interior / buffer split of
     interleave_communication_and_computation.jl:9-67 when halos are exchanged asynchronously."""
@@ -528,12 +541,13 @@ def update_state(model, compute_tendencies=True):
     b.fill_local_halos(b.U, False)
     ws, es, wr, er = b.pack_x(b.U)
     Nx, Ny, Nz, Hx = g.Nx, g.Ny, g.Nz, g.Hx
+    W = buffer_strip_width(model, Nx, Hx)
     reqs = ctx.exchange_start(ws, es, wr, er)                         # halos fly ...
-    b.compute_tendencies((Hx + 1, Nx - Hx, 1, Ny, 1, Nz))            # ... while the interior is computed (:27-67)
+    b.compute_tendencies((W + 1, Nx - W, 1, Ny, 1, Nz))              # ... while the interior is computed (:27-67)
     ctx.exchange_wait(reqs)                                           # synchronize_communication! (distributed_fields.jl:71-88)
     b.unpack_x(b.U)                                                   # complete_communication_and_compute_buffer! (:9-20)
-    b.compute_tendencies((1, Hx, 1, Ny, 1, Nz))                       # compute_buffer_tendencies! west strip
-    b.compute_tendencies((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))             # east strip
+    b.compute_tendencies((1, W, 1, Ny, 1, Nz))                        # compute_buffer_tendencies! west strip
+    b.compute_tendencies((Nx - W + 1, Nx, 1, Ny, 1, Nz))              # east strip
     if hasattr(b, "flux_bc_tendencies"):
         b.flux_bc_tendencies()
 

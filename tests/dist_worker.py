@@ -24,6 +24,8 @@ def main():
     backend = CpuBackend(ctx, grid, 2, ocn)
     model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"), backend=backend)
     model.async_halos = bool(async_halos)
+    if async_halos > 1:
+        model.strip_width = async_halos          # wider-than-Hx buffer strips (the product uses one 64-lane tile at 256^3)
     flds = model.fields()
     vals = smooth_state({n: grid.local.nodes(f.loc) for n, f in flds.items()}, 1234 + ctx.rank)
     # deterministic global noise: regenerate from the global coordinates instead of a per-rank rng

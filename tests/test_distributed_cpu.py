@@ -46,9 +46,10 @@ def _serial(oracle, size, nsteps):
     return m
 
 
-@pytest.mark.parametrize("async_halos", [False, True])
+@pytest.mark.parametrize("async_halos", [False, True, 5])
 def test_two_rank_model_matches_serial_oracle(oracle, tmp_path, async_halos):
-    size, nsteps = (16, 8, 8), 3
+    """async_halos = 5: asynchronous exchange with 5-wide (wider than Hx) buffer strips, local Nx = 12"""
+    size, nsteps = ((24, 8, 8) if async_halos == 5 else (16, 8, 8)), 3
     ranks = _run_workers(tmp_path, nsteps, async_halos, size, 29533 + int(async_halos))
     m = _serial(oracle, size, nsteps)
     nxl = size[0] // 2

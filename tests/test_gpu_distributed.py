@@ -82,6 +82,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
 @pytest.mark.parametrize("R,async_halos,size,zkind", [
     (2, False, (32, 16, 8), "periodic"), (2, True, (32, 16, 8), "periodic"), (4, True, (32, 16, 8), "periodic"),
     (4, True, (36, 12, 10), "periodic"),       # odd local Nx (9): padded column pair; Ny/2+1 = 7 modes over 4 ranks
+    (2, True, (384, 8, 8), "periodic"),        # local Nx = 192: buffer strips one 64-lane tile wide (buffer_strip_width)
     (2, True, (32, 16, 8), "bounded"),         # z Bounded: distributed Fourier-tridiagonal solver
     (4, True, (28, 8, 12), "stretched"),       # stretched z, odd local Nx (7)
 ])
