@@ -193,6 +193,14 @@ int ocn_pack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3
                      double *east_send);
 int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, const double *west_recv,
                        const double *east_recv);
+/* the same with only the `depth` (1 <= depth <= Hx) columns next to each side: buffers of depth x Py x Pz doubles per field.
+ * The pressure solve reads one column of x halo (u[Nx+1] in the divergence, p[0] in the correction): the host layer exchanges
+ * exactly that between the full fills of update_state!, where the reference's generic fill moves Hx columns of u, v, w
+ * (pressure_correction.jl:8-20) that nothing reads before they are filled again. */
+int ocn_pack_x_halos_depth(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int depth,
+                           double *west_send, double *east_send);
+int ocn_unpack_x_halos_depth(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int depth,
+                             const double *west_recv, const double *east_recv);
 /* DistributedFFTBasedPoissonSolver (distributed_fft_based_poisson_solver.jl:92-188; z Periodic) and
  * DistributedFourierTridiagonalPoissonSolver (distributed_fft_tridiagonal_solver.jl:153-293; z Bounded, regular or
  * stretched) for Partition(R,1,1), split at the two transposes (MPI.Alltoallv!, distributed_transpose.jl:185-191) which

@@ -48,6 +48,8 @@ SYMBOLS = {
     "ocn_set_stream": (C.c_int, [_vp]),
     "ocn_pack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
+    "ocn_pack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "ocn_unpack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ocn_fill_halo_regions_bcs": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),
     "ocn_compute_flux_bcs": (C.c_int, [_vp, _vp, _ip, _vp]),
     "ocn_compute_tendencies_and_substep": (C.c_int, [_vp, _vp, C.c_int, _vp, _ip, _vp, _vp, C.c_double, C.c_double, C.c_double,

@@ -1194,8 +1194,11 @@ extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const dou
 // distributed x-slab pieces (src/DistributedComputations): the collectives themselves (RCCL send/recv, all-to-all) are
 // issued by the host layer through torch.distributed on buffers it owns; the library packs / unpacks / transforms.
 // ---------------------------------------------------------------------------------------------------------------------
-static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east, bool pack) {
+static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east, bool pack,
+                          int depth = 0) {
     if (n <= 0) return OCN_OK;
+    if (depth <= 0) depth = g.Hx;
+    if (depth > g.Hx || depth > g.Nx) return fail(OCN_EINVAL, "exchange depth %d exceeds the halo (%d) or the local interior (%d)", depth, g.Hx, g.Nx);
     if (n > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
     FieldList fl;
     SlabList sl;
@@ -1210,13 +1213,13 @@ static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*loc
         fl.p[f] = fields[f];
         sl.off[f] = off;
         sl.rows[f] = (long)P[1] * P[2];
-        off += (long)g.Hx * sl.rows[f];
+        off += (long)depth * sl.rows[f];
         maxrows = std::max(maxrows, sl.rows[f]);
     }
-    const long threads = (long)g.Hx * maxrows;
+    const long threads = (long)depth * maxrows;
     const int nb = (int)((threads + 255) / 256);
-    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, west, east);
-    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, west, east);
+    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, depth, west, east);
+    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, depth, west, east);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -1233,6 +1236,22 @@ extern "C" int ocn_unpack_x_halos(ocn_grid_t grid, double *const *fields, const 
     NEED_INIT();
     if (!grid || !fields || !locs || !west_recv || !east_recv) return fail(OCN_EINVAL, "NULL argument");
     return x_halo_buffers(grid->d, fields, locs, nfields, const_cast<double *>(west_recv), const_cast<double *>(east_recv), false);
+}
+
+extern "C" int ocn_pack_x_halos_depth(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int depth,
+                                      double *west_send, double *east_send) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || !west_send || !east_send) return fail(OCN_EINVAL, "NULL argument");
+    if (depth < 1) return fail(OCN_EINVAL, "depth must be >= 1");
+    return x_halo_buffers(grid->d, fields, locs, nfields, west_send, east_send, true, depth);
+}
+
+extern "C" int ocn_unpack_x_halos_depth(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields, int depth,
+                                        const double *west_recv, const double *east_recv) {
+    NEED_INIT();
+    if (!grid || !fields || !locs || !west_recv || !east_recv) return fail(OCN_EINVAL, "NULL argument");
+    if (depth < 1) return fail(OCN_EINVAL, "depth must be >= 1");
+    return x_halo_buffers(grid->d, fields, locs, nfields, const_cast<double *>(west_recv), const_cast<double *>(east_recv), false, depth);
 }
 
 // DistributedFFTBasedPoissonSolver (distributed_fft_based_poisson_solver.jl:92-188) and

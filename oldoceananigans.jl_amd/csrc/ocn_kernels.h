@@ -1301,7 +1301,7 @@ struct SlabList {
     long rows[OCN_MAX_FIELDS];
 };
 template <bool PACK>
-__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabList sl, int P0, int N, int H, double *west, double *east) {
+__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabList sl, int P0, int N, int HX, int H, double *west, double *east) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int h = t % H;
     const long r = t / H;                      // j + P1 * k
@@ -1310,12 +1310,13 @@ __global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabLi
         if (r >= sl.rows[f]) continue;
         double *p = fl.p[f];
         const long b = sl.off[f] + t;
+        // H = exchanged depth (<= Hx = HX): the depth interior columns next to each side <-> the depth halo columns nearest to it
         if (PACK) {
-            west[b] = p[row + H + h];
-            east[b] = p[row + N + h];
+            west[b] = p[row + HX + h];
+            east[b] = p[row + HX + N - H + h];
         } else {
-            p[row + h] = west[b];
-            p[row + N + H + h] = east[b];
+            p[row + HX - H + h] = west[b];
+            p[row + N + HX + h] = east[b];
         }
     }
 }

@@ -95,24 +95,28 @@ class CpuBackend:
         for f in fields:
             self.grid.local.o.fill_halo_regions(f.a, f.codes, fill_open_bcs)
 
-    def pack_x(self, fields):
+    def pack_x(self, fields, depth=None):
         g = self.grid.local
         H, N = g.Hx, g.Nx
-        n = len(fields) * self.slab
+        d = H if depth is None else depth
+        slab = self.slab // H * d
+        n = len(fields) * slab
         ws, es, wr, er = (b[:n] for b in self.bufs)
         for q, f in enumerate(fields):
-            ws[q * self.slab:(q + 1) * self.slab] = self.ctx.torch.from_numpy(f.a[H:2 * H].ravel(order="F").copy())
-            es[q * self.slab:(q + 1) * self.slab] = self.ctx.torch.from_numpy(f.a[N:N + H].ravel(order="F").copy())
+            ws[q * slab:(q + 1) * slab] = self.ctx.torch.from_numpy(f.a[H:H + d].ravel(order="F").copy())
+            es[q * slab:(q + 1) * slab] = self.ctx.torch.from_numpy(f.a[H + N - d:H + N].ravel(order="F").copy())
         return ws, es, wr, er
 
-    def unpack_x(self, fields):
+    def unpack_x(self, fields, depth=None):
         g = self.grid.local
         H, N = g.Hx, g.Nx
+        d = H if depth is None else depth
+        slab = self.slab // H * d
         wr, er = self.bufs[2], self.bufs[3]
         for q, f in enumerate(fields):
-            shape = (H,) + f.a.shape[1:]
-            f.a[:H] = wr[q * self.slab:(q + 1) * self.slab].numpy().reshape(shape, order="F")
-            f.a[N + H:N + 2 * H] = er[q * self.slab:(q + 1) * self.slab].numpy().reshape(shape, order="F")
+            shape = (d,) + f.a.shape[1:]
+            f.a[H - d:H] = wr[q * slab:(q + 1) * slab].numpy().reshape(shape, order="F")
+            f.a[N + H:N + H + d] = er[q * slab:(q + 1) * slab].numpy().reshape(shape, order="F")
 
     # kernels ----------------------------------------------------------------------------------------------------
     def rk3_substep(self, dt, γ, ζ):

@@ -40,7 +40,7 @@ def _closure(ocn, zkind):
     return ocn.ScalarDiffusivity(ν=2e-3, κ={"T": 1e-3, "S": 5e-4}) if zkind == "bounded" else None
 
 
-def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"):
+def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic", thin_halos=True):
     import torch
     from oldoceananigans_jl_amd import distributed as dist
     from loopback import LoopbackWorld
@@ -56,6 +56,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
                                                         closure=_closure(ocn, zkind), buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
                                                         coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
             model.async_halos = async_halos
+            model.thin_halos = thin_halos
             flds = model.fields()
             vals = {n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()}
             dist.set_model(model, **vals)
@@ -99,6 +100,24 @@ def test_transposing_solver_still_matches(ocn, oracle, arch, R, size):
         _virtual_rank_case(ocn, oracle, arch, R, True, size, "periodic")
     finally:
         ocn.set_option("dist_substructured", 1)
+
+
+def test_one_column_exchanges_equal_the_full_fills(ocn, arch):
+    """compute_pressure_correction exchanges one column of u and of p (thin_halos) where the reference's generic fills move Hx
+    columns of u, v, w and p: every field, halos included, is bit-identical after 3 steps (the deeper columns are never read
+    before update_state! fills them again); p's own x halos are compared one column deep"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    thin = _run_virtual_ranks(ocn, arch, 2, (32, 16, 8), 3, True, "bounded", thin_halos=True)
+    full = _run_virtual_ranks(ocn, arch, 2, (32, 16, 8), 3, True, "bounded", thin_halos=False)
+    for (a, _, _), (b, _, _) in zip(thin, full):
+        for name in a:
+            if name == "p":
+                assert np.array_equal(a[name][2:-2], b[name][2:-2])
+            else:
+                assert np.array_equal(a[name], b[name]), name
 
 
 def _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind):
