@@ -15,6 +15,7 @@ reference calls `sync_device!` before every MPI call (halo_communication.jl:181,
     (tests/cpu_backend.py, built on the oracle) into the SAME orchestration and run it over gloo.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so in this process (see init_process_group)
@@ -153,6 +154,8 @@ def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False):
         raise _lib.OcnError("libocn_mi355x.so was loaded before torch: torch bundles its own ROCm runtime under the same "
                             "sonames and cannot initialise on top of the system one. Import torch (or this module) and call "
                             "init_process_group() before creating any ocn.GPU().")
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL fails with hipIpcGetMemHandle: invalid argument
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     from .architectures import GPU
