@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--size", type=int, default=256, help="cells per side per GPU")
+    ap.add_argument("--global-size", type=int, default=0,
+                    help="fixed GLOBAL grid G^3 split into x-slabs over the ranks (strong scaling; 512 = BASELINE.json configs[3] at "
+                         "--gpus 8). Default 0: weak scaling, --size^3 cells per GPU, global (size*N) x size x size")
     ap.add_argument("--tendency-impl", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched", "ppb_physics"],
@@ -140,7 +143,7 @@ def main():
     if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":
         import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so (see distributed.init_process_group)
     import oldoceananigans_jl_amd as ocn
-    N = args.size
+    N = args.global_size if (args.global_size and world == 1) else args.size
     distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1"
     if distributed:
         from oldoceananigans_jl_amd import distributed as dist
@@ -149,7 +152,11 @@ def main():
         rehearsal = os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1"
         ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=rehearsal)
         arch = ctx.arch
-        grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
+        if args.global_size:
+            G = args.global_size
+            grid = dist.DistributedRectilinearGrid(ctx, size=(G, G, G), extent=(1.0, 1.0, 1.0))
+        else:
+            grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
         model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
         model.fuse_substep = os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"
         step = lambda dt: dist.time_step(model, dt)          # noqa: E731
@@ -175,7 +182,7 @@ def main():
         barrier = lambda: None                                # noqa: E731
         ocn.set_model(model, **initial_state(ocn, model))
     model.set_option("tendency_impl", args.tendency_impl)
-    dt = 0.1 * (1.0 / N) / 0.6                                # Δt = 0.1 Δx / max|u|
+    dt = 0.1 * (1.0 / (args.global_size or N)) / 0.6                                # Δt = 0.1 Δx / max|u|
 
     for _ in range(args.warmup):
         step(dt)
@@ -220,6 +227,9 @@ def main():
     if rank != 0:
         return
     cells = float(N) ** 3 * world * (1.0 if args.workload == "ppp" else 0.5)
+    gshape = f"{N * world}x{N}x{N}"
+    if args.global_size:
+        cells, gshape = float(args.global_size) ** 3, f"{args.global_size}x{args.global_size}x{args.global_size}"
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
@@ -229,12 +239,16 @@ def main():
     achieved = bytes_per_cell * cells_per_gpu / t_launch / 1e9 if tend_n else None
     out = {
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_size else "weak",
         "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" else None,
         "dtype": "f64", "data": "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
         else "synthetic; REHEARSAL on one card over gloo + host staging: not a measurement",
-        "config": {"workload": (f"{N * world}x{N}x{N} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
-                                "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing (BASELINE.json configs[1])")
+        "config": {"workload": (f"{gshape} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
+                                "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing " +
+                                ("(BASELINE.json configs[3] grid)" if args.global_size == 512 else
+                                 "(fixed global grid)" if args.global_size else
+                                 "(BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU: {N}^3 cells on each of {world} x-slabs; "
+                                                                "at 8 GPUs the cell count of configs[3]'s 512^3") + ")"))
                    if args.workload == "ppp" else
                    (f"{N}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
                     "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +

@@ -436,7 +436,10 @@ class DistributedNonhydrostaticModel:
         self.backend = backend if backend is not None else DeviceBackend(grid.ctx, grid, len(self.tracer_names))
         self.time, self.iteration, self.stage = 0.0, 0, 1
         self.last_Δt = self.last_stage_Δt = float("inf")
-        self.async_halos = True          # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)
+        # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)? None = automatic: only when the slab
+        # is wide enough for whole-tile buffer strips (buffer_strip_width) -- on a thinner slab the two Hx-wide strips cost two
+        # extra tile columns of the fused kernel, more than the exposed exchange; True / False force it
+        self.async_halos = None
         if closure is not None:
             self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
         if coriolis is not None:
@@ -536,7 +539,8 @@ def update_state(model, compute_tendencies=True):
     if compute_tendencies and hasattr(b, "n_evals"):
         b.n_evals += 1
     # with buoyancy, pHY′ in the x-halo columns needs the exchanged tracers: fill, integrate, then evaluate (no overlap)
-    if (not compute_tendencies or ctx.world == 1 or not model.async_halos or g.Nx <= 2 * g.Hx or
+    overlap = model.async_halos if model.async_halos is not None else g.Nx >= 3 * 64
+    if (not compute_tendencies or ctx.world == 1 or not overlap or g.Nx <= 2 * g.Hx or
             getattr(b, "buoyancy", None) is not None):
         fill_halo_regions(model, b.U, fill_open_bcs=False)
         if hasattr(b, "update_hydrostatic_pressure"):
