@@ -256,6 +256,9 @@ int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
  * 1 / (|u|/Δx + |v|/Δy + |w|/Δz) -- what TimeStepWizard multiplies by the CFL number. Synchronous. */
 int ocn_cell_advection_timescale(ocn_grid_t grid, const double *u, const double *v, const double *w, double *tau);
 int ocn_model_cell_advection_timescale(ocn_model_t model, double *tau);
+/* hasnan(field) = any(isnan, parent(field)) (Diagnostics/nan_checker.jl:32): `n` doubles starting at `data` (the whole parent
+ * array, halos included); *result = 1 if any is NaN */
+int ocn_hasnan(const double *data, size_t n, int *result);
 int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value);
 /* options: "tendency_impl" 0 = per-field kernels as the reference launches them, 1 = fused flux-sharing kernel;
  * "swap_tendencies" 1 = cache_previous_tendencies! by pointer swap, 0 = by copy kernel; "fuse_substep" 1 = fuse the

@@ -15,7 +15,8 @@ from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, Rectil
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
 from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
                       solve_for_pressure)
-from .simulations import TimeStepWizard, cell_advection_timescale, cell_diffusion_timescale, new_time_step
+from .simulations import (NaNChecker, TimeStepWizard, cell_advection_timescale, cell_diffusion_timescale, default_nan_checker, hasnan,
+                          new_time_step)
 from . import kernels
 
 __all__ = [n for n in dir() if not n.startswith("_")]

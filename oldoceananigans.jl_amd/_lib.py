@@ -48,6 +48,7 @@ SYMBOLS = {
     "ocn_set_stream": (C.c_int, [_vp]),
     "ocn_pack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
+    "ocn_hasnan": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int)]),
     "ocn_pack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ocn_fill_halo_regions_bcs": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, C.c_int]),

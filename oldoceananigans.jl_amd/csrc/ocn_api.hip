@@ -2074,6 +2074,26 @@ extern "C" int ocn_model_cell_advection_timescale(ocn_model_t m, double *tau) {
     return ocn_cell_advection_timescale(m->grid, m->U[0], m->U[1], m->U[2], tau);
 }
 
+extern "C" int ocn_hasnan(const double *data, size_t n, int *result) {
+    NEED_INIT();
+    if (!data || !result) return fail(OCN_EINVAL, "NULL argument");
+    int *flag;
+    HIP_TRY(dev_alloc((void **)&flag, sizeof(int)));
+    hipError_t e = hipMemsetAsync(flag, 0, sizeof(int), g_stream);
+    if (e == hipSuccess && n) {
+        const int nb = (int)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(hasnan_kernel, dim3(nb), dim3(256), 0, g_stream, data, (long)n, flag);
+        e = hipGetLastError();
+    }
+    int h = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, g_stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(g_stream);
+    hipFree(flag);
+    if (e != hipSuccess) return fail((int)e, "hasnan: %s", hipGetErrorString(e));
+    *result = h;
+    return OCN_OK;
+}
+
 extern "C" int ocn_max_abs_divergence(ocn_grid_t grid, const double *u, const double *v, const double *w, double *value) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !value) return fail(OCN_EINVAL, "NULL argument");

@@ -1264,6 +1264,13 @@ __global__ void __launch_bounds__(256) advection_timescale_kernel(DGrid g, FView
     if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
 }
 
+// hasnan(field) = any(isnan, parent(field)) (Diagnostics/nan_checker.jl:32)
+__global__ void __launch_bounds__(256) hasnan_kernel(const double *a, long n, int *flag) {
+    bool found = false;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) found |= a[q] != a[q];
+    if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 // exhaustive check of rcp_rn_f32<VARIANT> against the compiler's correctly rounded divide over one binade
 template <int VARIANT>
 __global__ void __launch_bounds__(256) rcp_check_kernel(int exponent_bits, unsigned long long *mismatches) {

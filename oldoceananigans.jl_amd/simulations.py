@@ -1,6 +1,6 @@
 """Simulation-level pieces that touch the hot path: cell_advection_timescale (Advection/cell_advection_timescale.jl:
 13-34), cell_diffusion_timescale (TurbulenceClosures/turbulence_closure_diagnostics.jl:7-47) and TimeStepWizard / new_time_step
-(Simulations/time_step_wizard.jl:5-115)."""
+(Simulations/time_step_wizard.jl:5-115); hasnan / NaNChecker (Diagnostics/nan_checker.jl)."""
 import ctypes as C
 import math
 
@@ -55,3 +55,41 @@ def new_time_step(old_Δt, wizard, model):
     new = min(wizard.max_change * old_Δt, new)
     new = max(wizard.min_change * old_Δt, new)
     return min(max(new, wizard.min_Δt), wizard.max_Δt)
+
+
+def hasnan(obj):
+    """hasnan(field) = any(isnan, parent(field)); hasnan(model) checks the first prognostic field (nan_checker.jl:32-33)"""
+    field = obj
+    if hasattr(obj, "backend"):
+        field = obj.backend.U[0]
+    elif hasattr(obj, "velocities"):
+        field = obj.velocities.u
+    r = C.c_int()
+    _lib.check(_lib.lib().ocn_hasnan(field.data, field.nbytes // 8, C.byref(r)))
+    found = bool(r.value)
+    if hasattr(obj, "ctx") and obj.ctx.world > 1:
+        found = obj.ctx.allreduce_max(float(found)) > 0
+    return found
+
+
+class NaNChecker:
+    """NaNChecker(; fields, erroring = false): called with a simulation (any object with `.running` and `.model.clock`), stops
+    it -- or raises when erroring -- if one of the fields holds a NaN (nan_checker.jl:35-53)"""
+
+    def __init__(self, fields, erroring=False):
+        self.fields, self.erroring = dict(fields), bool(erroring)
+
+    def __call__(self, simulation):
+        for name, field in self.fields.items():
+            if hasnan(field):
+                simulation.running = False
+                clock = simulation.model.clock
+                msg = f"time = {clock.time}, iteration = {clock.iteration}: NaN found in field {name}."
+                if self.erroring:
+                    raise RuntimeError(msg + " Aborting simulation.")
+                print("[ Info: " + msg + " Stopping simulation.")
+
+
+def default_nan_checker(model):
+    """NaNChecker on the first prognostic field, u (Models/Models.jl:173-184)"""
+    return NaNChecker({"u": model.velocities.u if hasattr(model, "velocities") else model.backend.U[0]})

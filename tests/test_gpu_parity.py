@@ -541,3 +541,24 @@ def test_time_step_wizard_and_advection_timescale(ocn, oracle, arch):
     g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, (12, 10, 9), ("Periodic", "Bounded", "Bounded"), z=tanh_faces(9))
     set_both(ocn, m_gpu, m_cpu, seed=2, enforce_incompressibility=False)       # identical inputs (no projection round-off)
     assert ocn.cell_advection_timescale(m_gpu) == m_cpu.cell_advection_timescale()
+
+
+def test_nan_checker(ocn, arch):
+    """NaNChecker / hasnan (Diagnostics/nan_checker.jl:32-53; test/test_diagnostics.jl nan_checker_aborts_simulation): a NaN anywhere
+    in parent(u) -- halo cells included -- stops the simulation, or raises when erroring"""
+    from types import SimpleNamespace
+    grid = ocn.RectilinearGrid(arch, size=(8, 6, 4), extent=(1, 1, 1))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=())
+    sim = SimpleNamespace(running=True, model=model)
+    checker = ocn.default_nan_checker(model)
+    checker(sim)
+    assert sim.running and not ocn.hasnan(model) and not ocn.hasnan(model.velocities.w)
+    a = model.velocities.u.parent()
+    a[0, 0, 0] = np.nan                                  # a halo corner: parent(field) is what the reference scans
+    model.velocities.u.set_parent(a)
+    assert ocn.hasnan(model) and ocn.hasnan(model.velocities.u) and not ocn.hasnan(model.velocities.v)
+    checker(sim)
+    assert not sim.running
+    checker.erroring = True
+    with pytest.raises(RuntimeError, match="NaN found in field u"):
+        checker(sim)
