@@ -473,7 +473,7 @@ void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const d
  * Added to a tendency that already holds the advective part: G = (G - ∂ⱼτᵢⱼ) + 0.0, the order of the terms in
  * nonhydrostatic_tendency_kernel_functions.jl:91-100.
  * ------------------------------------------------------------------------------------------------------------------ */
-typedef struct { const oro_grid *g; fld u, v, w; double nu; } visc;
+typedef struct { const oro_grid *g; fld u, v, w; double nu; int var; fld K; } visc;   /* var: coefficient = the ccc array K */
 #define FLATD(g, d) ((g)->topo[d] == ORO_FLAT)
 /* ∂ along d of a field: (f[idx] - f[idx-1]) at Face-in-d results, (f[idx+1] - f[idx]) at Center-in-d results */
 static inline double ddx_c(const oro_grid *g, const fld *f, int i, int j, int k) { return FLATD(g, 0) ? 0.0 : (AT(*f, i + 1, j, k) - AT(*f, i, j, k)) * (1.0 / DC(g, 0, i)); }
@@ -490,25 +490,48 @@ static inline double S12(const visc *V, int i, int j, int k) { return 0.5 * (ddy
 static inline double S13(const visc *V, int i, int j, int k) { return 0.5 * (ddz_f(V->g, &V->u, i, j, k) + ddx_f(V->g, &V->w, i, j, k)); }   /* fcf */
 static inline double S23(const visc *V, int i, int j, int k) { return 0.5 * (ddz_f(V->g, &V->v, i, j, k) + ddy_f(V->g, &V->w, i, j, k)); }   /* cff */
 /* A * viscous_flux: Ax_qᶜᶜᶜ(viscous_flux_ux) etc.; areas Ax = Δy Δz, Ay = Δx Δz, Az = Δx Δy at the flux location */
-#define VF(S) (-(2 * (V->nu * (S))))
-static inline double AxFux(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DC(V->g, 2, k)) * VF(S11(V, i, j, k)); }   /* ccc */
-static inline double AyFuy(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 2, k)) * VF(S12(V, i, j, k)); }   /* ffc */
-static inline double AzFuz(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 1, j)) * VF(S13(V, i, j, k)); }   /* fcf */
-static inline double AxFvx(const visc *V, int i, int j, int k) { return (DF(V->g, 1, j) * DC(V->g, 2, k)) * VF(S12(V, i, j, k)); }   /* ffc */
-static inline double AyFvy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 2, k)) * VF(S22(V, i, j, k)); }   /* ccc */
-static inline double AzFvz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 1, j)) * VF(S23(V, i, j, k)); }   /* cff */
-static inline double AxFwx(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DF(V->g, 2, k)) * VF(S13(V, i, j, k)); }   /* fcf */
-static inline double AyFwy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 2, k)) * VF(S23(V, i, j, k)); }   /* cff */
-static inline double AzFwz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 1, j)) * VF(S33(V, i, j, k)); }   /* ccc */
+/* the coefficient at the flux location: a number, or a ccc array interpolated there (abstract_scalar_diffusivity_closure.jl:
+ * 310-330: νᶜᶜᶜ = ν[i,j,k], νᶠᶠᶜ = ℑxyᶠᶠᵃ, νᶠᶜᶠ = ℑxzᶠᵃᶠ, νᶜᶠᶠ = ℑyzᵃᶠᶠ, κᶠᶜᶜ = ℑxᶠᵃᵃ, κᶜᶠᶜ = ℑyᵃᶠᵃ, κᶜᶜᶠ = ℑzᵃᵃᶠ; interpolation_operators.jl:8-48) */
+static inline double K_ccc(const visc *V, int i, int j, int k) { return V->var ? AT(V->K, i, j, k) : V->nu; }
+static inline double K_fcc(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (AT(V->K, i - 1, j, k) + AT(V->K, i, j, k)) : V->nu; }
+static inline double K_cfc(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (AT(V->K, i, j - 1, k) + AT(V->K, i, j, k)) : V->nu; }
+static inline double K_ccf(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (AT(V->K, i, j, k - 1) + AT(V->K, i, j, k)) : V->nu; }
+static inline double K_ffc(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (K_fcc(V, i, j - 1, k) + K_fcc(V, i, j, k)) : V->nu; }   /* ℑy(ℑx) */
+static inline double K_fcf(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (K_fcc(V, i, j, k - 1) + K_fcc(V, i, j, k)) : V->nu; }   /* ℑz(ℑx) */
+static inline double K_cff(const visc *V, int i, int j, int k) { return V->var ? 0.5 * (K_cfc(V, i, j, k - 1) + K_cfc(V, i, j, k)) : V->nu; }   /* ℑz(ℑy) */
+#define VF(L, S) (-(2 * (K_##L(V, i, j, k) * (S))))
+static inline double AxFux(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DC(V->g, 2, k)) * VF(ccc, S11(V, i, j, k)); }   /* ccc */
+static inline double AyFuy(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 2, k)) * VF(ffc, S12(V, i, j, k)); }   /* ffc */
+static inline double AzFuz(const visc *V, int i, int j, int k) { return (DF(V->g, 0, i) * DC(V->g, 1, j)) * VF(fcf, S13(V, i, j, k)); }   /* fcf */
+static inline double AxFvx(const visc *V, int i, int j, int k) { return (DF(V->g, 1, j) * DC(V->g, 2, k)) * VF(ffc, S12(V, i, j, k)); }   /* ffc */
+static inline double AyFvy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 2, k)) * VF(ccc, S22(V, i, j, k)); }   /* ccc */
+static inline double AzFvz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 1, j)) * VF(cff, S23(V, i, j, k)); }   /* cff */
+static inline double AxFwx(const visc *V, int i, int j, int k) { return (DC(V->g, 1, j) * DF(V->g, 2, k)) * VF(fcf, S13(V, i, j, k)); }   /* fcf */
+static inline double AyFwy(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DF(V->g, 2, k)) * VF(cff, S23(V, i, j, k)); }   /* cff */
+static inline double AzFwz(const visc *V, int i, int j, int k) { return (DC(V->g, 0, i) * DC(V->g, 1, j)) * VF(ccc, S33(V, i, j, k)); }   /* ccc */
 #undef VF
 
 /* which: 0 u, 1 v, 2 w (coef = ν), 3 tracer c (coef = κ) */
+static void add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                                 double coef, const double *coef_ccc, double *Gp, const int *range);
+
 void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
                               double coef, double *Gp, const int *range) {
+    add_closure_tendency(g, which, u, v, w, c, coef, NULL, Gp, range);
+}
+
+/* the same with the coefficient read from a ccc array with filled halos (eddy viscosity / diffusivity of an LES closure) */
+void oro_add_closure_tendency_field(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                                    const double *coef_ccc, double *Gp, const int *range) {
+    add_closure_tendency(g, which, u, v, w, c, 0.0, coef_ccc, Gp, range);
+}
+
+static void add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                                 double coef, const double *coef_ccc, double *Gp, const int *range) {
     static const int *LOCS[4] = {LOC_U, LOC_V, LOC_W, LOC_C};
     int r[6];
     if (range) memcpy(r, range, sizeof r); else default_range(g, LOCS[which], which < 3, r);
-    visc Vs = {g, mkfld(g, u, LOC_U), mkfld(g, v, LOC_V), mkfld(g, w, LOC_W), coef};
+    visc Vs = {g, mkfld(g, u, LOC_U), mkfld(g, v, LOC_V), mkfld(g, w, LOC_W), coef, coef_ccc != NULL, mkfld(g, coef_ccc ? coef_ccc : u, LOC_C)};
     const visc *V = &Vs;
     fld C = mkfld(g, c ? c : u, LOC_C);
     fld G = mkfld(g, Gp, LOCS[which]);
@@ -536,13 +559,139 @@ void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, con
                 } else {                     /* ∇_dot_qᶜ at ccc: A * (-(κ ∂c)) */
                     Vinv = 1.0 / ((DC(g, 0, i) * DC(g, 1, j)) * DC(g, 2, k));
                     const double ax = DC(g, 1, j) * DC(g, 2, k), ay = DC(g, 0, i) * DC(g, 2, k), az = DC(g, 0, i) * DC(g, 1, j);
-                    dx = fx ? 0.0 : ax * -(coef * ddx_f(g, &C, i + 1, j, k)) - ax * -(coef * ddx_f(g, &C, i, j, k));
-                    dy = fy ? 0.0 : ay * -(coef * ddy_f(g, &C, i, j + 1, k)) - ay * -(coef * ddy_f(g, &C, i, j, k));
-                    dz = fz ? 0.0 : az * -(coef * ddz_f(g, &C, i, j, k + 1)) - az * -(coef * ddz_f(g, &C, i, j, k));
+                    dx = fx ? 0.0 : ax * -(K_fcc(V, i + 1, j, k) * ddx_f(g, &C, i + 1, j, k)) - ax * -(K_fcc(V, i, j, k) * ddx_f(g, &C, i, j, k));
+                    dy = fy ? 0.0 : ay * -(K_cfc(V, i, j + 1, k) * ddy_f(g, &C, i, j + 1, k)) - ay * -(K_cfc(V, i, j, k) * ddy_f(g, &C, i, j, k));
+                    dz = fz ? 0.0 : az * -(K_ccf(V, i, j, k + 1) * ddz_f(g, &C, i, j, k + 1)) - az * -(K_ccf(V, i, j, k) * ddz_f(g, &C, i, j, k));
                 }
                 const double div = Vinv * ((dx + dy) + dz);
                 AT(G, i, j, k) = (AT(G, i, j, k) - div) + 0.0;
             }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * AnisotropicMinimumDissipation(C, Cν, Cκ; Cb = nothing) -- the eddy viscosity νₑ and the eddy diffusivities κₑ
+ * at ccc: turbulence_closure_implementations/anisotropic_minimum_dissipation.jl:152-196 (the two kernels), :226-357 (filter
+ * widths = 2Δ at the CALLING index, "the 30 terms", tr ∇u, the tracer terms -- including the ℑxzᶜᵃᶜ of norm_∂y_w at :323, kept
+ * as written) and velocity_tracer_gradients.jl:116-250 (norm_∂x_u = ∂x_u unscaled, norm_∂x_v = Δᶠx/Δᶠy ∂x_v, ...).
+ * n-ary + and * fold left to right, x^2 is x*x, unary minus binds before *, Cb = nothing makes (r - Cb_ζ) = r - 0.
+ * PARITY UNPINNED by reference data: the reference's tests only check that a model with this closure time-steps
+ * (test_time_stepping.jl:257,400); tests/test_oracle_kats.py pins the restatement on flows with known answers instead
+ * (laminar shear -> 0; u = (x, y, -2z) -> νₑ = Cν δ², κₑ = 2 Cκ δ² for c = z).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct { const oro_grid *g; fld u, v, w, c; } amd;
+typedef double (*amd_op)(const amd *, int, int, int);
+#define FX(A, i) (2 * DC((A)->g, 0, i))     /* Δᶠx = 2 Δxᶜᶜᶜ(i, j, k); _ffc, _fcf, ... are aliases evaluated at the same index */
+#define FY(A, j) (2 * DC((A)->g, 1, j))
+#define FZ(A, k) (2 * DC((A)->g, 2, k))
+static double n_dxu(const amd *A, int i, int j, int k) { return ddx_c(A->g, &A->u, i, j, k); }
+static double n_dyv(const amd *A, int i, int j, int k) { return ddy_c(A->g, &A->v, i, j, k); }
+static double n_dzw(const amd *A, int i, int j, int k) { return ddz_c(A->g, &A->w, i, j, k); }
+static double n_dxv(const amd *A, int i, int j, int k) { return FX(A, i) / FY(A, j) * ddx_f(A->g, &A->v, i, j, k); }   /* ffc */
+static double n_dyu(const amd *A, int i, int j, int k) { return FY(A, j) / FX(A, i) * ddy_f(A->g, &A->u, i, j, k); }   /* ffc */
+static double n_dxw(const amd *A, int i, int j, int k) { return FX(A, i) / FZ(A, k) * ddx_f(A->g, &A->w, i, j, k); }   /* fcf */
+static double n_dzu(const amd *A, int i, int j, int k) { return FZ(A, k) / FX(A, i) * ddz_f(A->g, &A->u, i, j, k); }   /* fcf */
+static double n_dyw(const amd *A, int i, int j, int k) { return FY(A, j) / FZ(A, k) * ddy_f(A->g, &A->w, i, j, k); }   /* cff */
+static double n_dzv(const amd *A, int i, int j, int k) { return FZ(A, k) / FY(A, j) * ddz_f(A->g, &A->v, i, j, k); }   /* cff */
+static double n_S12(const amd *A, int i, int j, int k) { return 0.5 * (n_dyu(A, i, j, k) + n_dxv(A, i, j, k)); }
+static double n_S13(const amd *A, int i, int j, int k) { return 0.5 * (n_dzu(A, i, j, k) + n_dxw(A, i, j, k)); }
+static double n_S23(const amd *A, int i, int j, int k) { return 0.5 * (n_dzv(A, i, j, k) + n_dyw(A, i, j, k)); }
+#define SQ(name, f) static double name(const amd *A, int i, int j, int k) { const double x = f(A, i, j, k); return x * x; }
+#define PR(name, f, h) static double name(const amd *A, int i, int j, int k) { return f(A, i, j, k) * h(A, i, j, k); }
+SQ(n_dxv2, n_dxv) SQ(n_dyu2, n_dyu) SQ(n_dxw2, n_dxw) SQ(n_dzu2, n_dzu) SQ(n_dyw2, n_dyw) SQ(n_dzv2, n_dzv)
+PR(n_dxv_S12, n_dxv, n_S12) PR(n_dyu_S12, n_dyu, n_S12) PR(n_dxw_S13, n_dxw, n_S13) PR(n_dzu_S13, n_dzu, n_S13)
+PR(n_dzv_S23, n_dzv, n_S23) PR(n_dyw_S23, n_dyw, n_S23)
+static double n_dxc(const amd *A, int i, int j, int k) { return FX(A, i) * ddx_f(A->g, &A->c, i, j, k); }   /* fcc */
+static double n_dyc(const amd *A, int i, int j, int k) { return FY(A, j) * ddy_f(A->g, &A->c, i, j, k); }   /* cfc */
+static double n_dzc(const amd *A, int i, int j, int k) { return FZ(A, k) * ddz_f(A->g, &A->c, i, j, k); }   /* ccf */
+SQ(n_dxc2, n_dxc) SQ(n_dyc2, n_dyc) SQ(n_dzc2, n_dzc)
+#undef SQ
+#undef PR
+/* ℑxᶜᵃᵃ, ℑyᵃᶜᵃ, ℑzᵃᵃᶜ of a function and the double interpolations built from them (interpolation_operators.jl:20-48) */
+static inline double Ix(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i + 1, j, k)); }
+static inline double Iy(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i, j + 1, k)); }
+static inline double Iz(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (f(A, i, j, k) + f(A, i, j, k + 1)); }
+static inline double Ixy(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (Ix(A, f, i, j, k) + Ix(A, f, i, j + 1, k)); }
+static inline double Ixz(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (Ix(A, f, i, j, k) + Ix(A, f, i, j, k + 1)); }
+static inline double Iyz(const amd *A, amd_op f, int i, int j, int k) { return 0.5 * (Iy(A, f, i, j, k) + Iy(A, f, i, j, k + 1)); }
+
+static double amd_delta2(const amd *A, int i, int j, int k) {
+    const double fx = FX(A, i), fy = FY(A, j), fz = FZ(A, k);
+    return 3 / ((1 / (fx * fx) + 1 / (fy * fy)) + 1 / (fz * fz));
+}
+
+static double amd_viscosity(const amd *A, double Cnu, int i, int j, int k) {
+    const double dxu = n_dxu(A, i, j, k), dyv = n_dyv(A, i, j, k), dzw = n_dzw(A, i, j, k);
+    /* norm_tr_∇uᶜᶜᶜ (:275-297) */
+    double q = dxu * dxu + dyv * dyv;
+    q = q + dzw * dzw;
+    q = q + Ixy(A, n_dxv2, i, j, k);
+    q = q + Ixy(A, n_dyu2, i, j, k);
+    q = q + Ixz(A, n_dxw2, i, j, k);
+    q = q + Ixz(A, n_dzu2, i, j, k);
+    q = q + Iyz(A, n_dyw2, i, j, k);
+    q = q + Iyz(A, n_dzv2, i, j, k);
+    if (q == 0) return fmax(0.0, 0.0);
+    /* norm_uᵢₐ_uⱼₐ_Σᵢⱼᶜᶜᶜ (:226-269); norm_Σ₁₁ = norm_∂x_u etc. */
+    double b1 = dxu * (dxu * dxu) + dyv * Ixy(A, n_dxv2, i, j, k);
+    b1 = b1 + dzw * Ixz(A, n_dxw2, i, j, k);
+    b1 = b1 + 2 * dxu * Ixy(A, n_dxv_S12, i, j, k);
+    b1 = b1 + 2 * dxu * Ixz(A, n_dxw_S13, i, j, k);
+    b1 = b1 + 2 * Ixy(A, n_dxv, i, j, k) * Ixz(A, n_dxw, i, j, k) * Iyz(A, n_S23, i, j, k);
+    double b2 = dxu * Ixy(A, n_dyu2, i, j, k) + dyv * (dyv * dyv);
+    b2 = b2 + dzw * Iyz(A, n_dyw2, i, j, k);
+    b2 = b2 + 2 * dyv * Ixy(A, n_dyu_S12, i, j, k);
+    b2 = b2 + 2 * Ixy(A, n_dyu, i, j, k) * Iyz(A, n_dyw, i, j, k) * Ixz(A, n_S13, i, j, k);
+    b2 = b2 + 2 * dyv * Iyz(A, n_dyw_S23, i, j, k);
+    double b3 = dxu * Ixz(A, n_dzu2, i, j, k) + dyv * Iyz(A, n_dzv2, i, j, k);
+    b3 = b3 + dzw * (dzw * dzw);
+    b3 = b3 + 2 * Ixz(A, n_dzu, i, j, k) * Iyz(A, n_dzv, i, j, k) * Ixy(A, n_S12, i, j, k);
+    b3 = b3 + 2 * dzw * Ixz(A, n_dzu_S13, i, j, k);
+    b3 = b3 + 2 * dzw * Iyz(A, n_dzv_S23, i, j, k);
+    const double r = (b1 + b2) + b3;
+    const double Cb_zeta = 0.0 / FZ(A, k);                              /* Cb = nothing */
+    const double nu = -Cnu * amd_delta2(A, i, j, k) * (r - Cb_zeta) / q;
+    return fmax(0.0, nu);
+}
+
+static double amd_diffusivity(const amd *A, double Ck, int i, int j, int k) {
+    const double sigma = (Ix(A, n_dxc2, i, j, k) + Iy(A, n_dyc2, i, j, k)) + Iz(A, n_dzc2, i, j, k);   /* norm_θᵢ²ᶜᶜᶜ (:331-333) */
+    if (sigma == 0) return fmax(0.0, 0.0);
+    const double dxu = n_dxu(A, i, j, k), dyv = n_dyv(A, i, j, k), dzw = n_dzw(A, i, j, k);
+    const double cx = Ix(A, n_dxc, i, j, k), cy = Iy(A, n_dyc, i, j, k), cz = Iz(A, n_dzc, i, j, k);
+    /* norm_uᵢⱼ_cⱼ_cᵢᶜᶜᶜ (:306-329) */
+    double t1 = dxu * Ix(A, n_dxc2, i, j, k) + Ixy(A, n_dxv, i, j, k) * cx * cy;
+    t1 = t1 + Ixz(A, n_dxw, i, j, k) * cx * cz;
+    double t2 = Ixy(A, n_dyu, i, j, k) * cy * cx + dyv * Iy(A, n_dyc2, i, j, k);
+    t2 = t2 + Ixz(A, n_dyw, i, j, k) * cy * cz;                        /* ℑxzᶜᵃᶜ of a cff quantity: as the reference has it */
+    double t3 = Ixz(A, n_dzu, i, j, k) * cz * cx + Iyz(A, n_dzv, i, j, k) * cz * cy;
+    t3 = t3 + dzw * Iz(A, n_dzc2, i, j, k);
+    const double theta = (t1 + t2) + t3;
+    const double kap = -Ck * amd_delta2(A, i, j, k) * theta / sigma;
+    return fmax(0.0, kap);
+}
+#undef FX
+#undef FY
+#undef FZ
+
+/* compute_diffusivities!(..., closure::AMD, model; parameters = :xyz) (:199-216): νₑ and one κₑ per tracer over the interior.
+ * The caller fills their halos (fill_halo_regions!(diffusivity_fields; only_local_halos = true), default ccc conditions). */
+void oro_compute_amd_diffusivities(const oro_grid *g, double Cnu, const double *Ckappa, const double *u, const double *v,
+                                   const double *w, const double *const *tracers, int ntracers, double *nu_e, double *const *kappa_e) {
+    amd As = {g, mkfld(g, u, LOC_U), mkfld(g, v, LOC_V), mkfld(g, w, LOC_W), mkfld(g, u, LOC_C)};
+    fld NU = mkfld(g, nu_e, LOC_C);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int k = 1; k <= g->N[2]; ++k)
+        for (int j = 1; j <= g->N[1]; ++j)
+            for (int i = 1; i <= g->N[0]; ++i) AT(NU, i, j, k) = amd_viscosity(&As, Cnu, i, j, k);
+    for (int t = 0; t < ntracers; ++t) {
+        amd At = As;
+        At.c = mkfld(g, tracers[t], LOC_C);
+        fld KA = mkfld(g, kappa_e[t], LOC_C);
+#pragma omp parallel for collapse(2) schedule(static)
+        for (int k = 1; k <= g->N[2]; ++k)
+            for (int j = 1; j <= g->N[1]; ++j)
+                for (int i = 1; i <= g->N[0]; ++i) AT(KA, i, j, k) = amd_diffusivity(&At, Ckappa[t], i, j, k);
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -1010,6 +1159,9 @@ struct oro_model {
     int any_flux_bc;
     int has_closure;
     double nu, kappa[ORO_MAXTR];
+    int has_amd;                                    /* closure = AnisotropicMinimumDissipation(Cν, Cκ) */
+    double Cnu, Ckappa[ORO_MAXTR];
+    double *nu_e, *kappa_e[ORO_MAXTR];              /* diffusivity_fields.νₑ, .κₑ (ccc, with halos) */
     int has_coriolis;
     double fcor;
     int buoyancy_kind, b_index, T_index, S_index;   /* 0 none, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy */
@@ -1058,6 +1210,8 @@ void oro_model_destroy(oro_model *m) {
     for (int f = 0; f < 3 + m->ntr; ++f) { free(m->U[f]); free(m->Gn[f]); free(m->Gm[f]); }
     free(m->p);
     free(m->pHY);
+    free(m->nu_e);
+    for (int t = 0; t < m->ntr; ++t) free(m->kappa_e[t]);
     oro_poisson_destroy(m->solver);
     free(m);
 }
@@ -1079,6 +1233,8 @@ double *oro_model_field(oro_model *m, const char *name) {
     char kind;
     int f = field_index(m, name, &kind);
     if (!strcmp(name, "pHY")) return m->pHY;
+    if (!strcmp(name, "nu_e")) return m->nu_e;
+    if (!strncmp(name, "kappa_e", 7) && name[7] >= '0' && name[7] - '0' < m->ntr) return m->kappa_e[name[7] - '0'];
     if (f < 0) return NULL;
     if (kind == 'p') return m->p;
     return kind == 'U' ? m->U[f] : kind == 'G' ? m->Gn[f] : m->Gm[f];
@@ -1133,11 +1289,33 @@ void oro_model_set_closure(oro_model *m, double nu, const double *kappa) {
     }
 }
 
+/* closure = AnisotropicMinimumDissipation(Cν = Cnu, Cκ = Ckappa[tracer]; Cb = nothing); replaces a ScalarDiffusivity */
+int oro_model_set_amd(oro_model *m, double Cnu, const double *Ckappa) {
+    for (int d = 0; d < 3; ++d)
+        if (m->g->topo[d] == ORO_FLAT) return -1;
+    m->has_amd = 1; m->has_closure = 0; m->nu = 0.0;
+    m->Cnu = Cnu;
+    if (!m->nu_e) m->nu_e = (double *)calloc(parent_len(m->g, LOC_C), sizeof(double));
+    for (int t = 0; t < m->ntr; ++t) {
+        m->kappa[t] = 0.0;
+        m->Ckappa[t] = Ckappa[t];
+        if (!m->kappa_e[t]) m->kappa_e[t] = (double *)calloc(parent_len(m->g, LOC_C), sizeof(double));
+    }
+    return 0;
+}
+
 /* update_nonhydrostatic_model_state.jl:20-56 with buoyancy = nothing */
 void oro_model_update_state(oro_model *m, int compute_tendencies) {
     const oro_grid *g = m->g;
     for (int f = 0; f < 3 + m->ntr; ++f) oro_fill_halo_regions_bcs(g, m->U[f], m->loc[f], m->bcs[f], /*fill_open_bcs=*/0);
-    /* compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69) */
+    /* compute_auxiliaries!: compute_diffusivities! over :xyz, update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:
+     * 58-69); then fill_halo_regions!(model.diffusivity_fields; only_local_halos = true) (:44) with the default ccc conditions */
+    if (m->has_amd) {
+        oro_compute_amd_diffusivities(g, m->Cnu, m->Ckappa, m->U[0], m->U[1], m->U[2], (const double *const *)(m->U + 3), m->ntr,
+                                      m->nu_e, m->kappa_e);
+        oro_fill_halo_regions(g, m->nu_e, LOC_C, 1);
+        for (int t = 0; t < m->ntr; ++t) oro_fill_halo_regions(g, m->kappa_e[t], LOC_C, 1);
+    }
     if (m->buoyancy_kind == 1)
         oro_update_hydrostatic_pressure(g, 1, m->U[3 + m->b_index], NULL, 0, 0, 0, m->pHY);
     else if (m->buoyancy_kind == 2)
@@ -1153,6 +1331,11 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
             for (int f = 0; f < 3; ++f) oro_add_closure_tendency(g, f, m->U[0], m->U[1], m->U[2], NULL, m->nu, m->Gn[f], NULL);
             for (int t = 0; t < m->ntr; ++t)
                 oro_add_closure_tendency(g, 3, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->kappa[t], m->Gn[3 + t], NULL);
+        }
+        if (m->has_amd) {
+            for (int f = 0; f < 3; ++f) oro_add_closure_tendency_field(g, f, m->U[0], m->U[1], m->U[2], NULL, m->nu_e, m->Gn[f], NULL);
+            for (int t = 0; t < m->ntr; ++t)
+                oro_add_closure_tendency_field(g, 3, m->U[0], m->U[1], m->U[2], m->U[3 + t], m->kappa_e[t], m->Gn[3 + t], NULL);
         }
     }
 }

@@ -71,6 +71,12 @@ void oro_compute_Gc(const oro_grid *g, const double *u, const double *v, const d
  * coef = ν) or -∇·q (which = 3: tracer c with coef = κ) to a tendency that already holds the advective part */
 void oro_add_closure_tendency(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
                               double coef, double *G, const int *range);
+/* the same with the coefficient read from a ccc array with filled halos (eddy viscosity / diffusivity) */
+void oro_add_closure_tendency_field(const oro_grid *g, int which, const double *u, const double *v, const double *w, const double *c,
+                                    const double *coef_ccc, double *G, const int *range);
+/* AnisotropicMinimumDissipation: νₑ and κₑ[t] over the interior (anisotropic_minimum_dissipation.jl:152-216); halos are the caller's */
+void oro_compute_amd_diffusivities(const oro_grid *g, double Cnu, const double *Ckappa, const double *u, const double *v,
+                                   const double *w, const double *const *tracers, int ntracers, double *nu_e, double *const *kappa_e);
 
 /* single-point WENO kernels exported for KATs */
 double oro_weno5_biased(const double S[6], int left);
@@ -119,6 +125,8 @@ void oro_model_set_coriolis(oro_model *m, int has, double f);
 void oro_add_fplane_coriolis(const oro_grid *g, double f, const double *u, const double *v, double *Gu, double *Gv);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) ; nu = 0 and kappa = NULL/0 -> closure = nothing */
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
+/* closure = AnisotropicMinimumDissipation(Cν, Cκ per tracer; Cb = nothing); fields "nu_e", "kappa_e<t>". -1 on Flat grids */
+int oro_model_set_amd(oro_model *m, double Cnu, const double *Ckappa);
 void oro_model_update_state(oro_model *m, int compute_tendencies);
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
 void oro_model_time_step(oro_model *m, double dt);

@@ -75,6 +75,9 @@ def lib():
         L.oro_update_hydrostatic_pressure.argtypes = [vp, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, dp]
         L.oro_add_hydrostatic_pressure_gradient.argtypes = [vp, dp, dp, dp]
         L.oro_add_closure_tendency.argtypes = [vp, C.c_int, dp, dp, dp, dp, C.c_double, dp, ip]
+        L.oro_add_closure_tendency_field.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, ip]
+        L.oro_compute_amd_diffusivities.argtypes = [vp, C.c_double, dp, dp, dp, dp, C.POINTER(dp), C.c_int, dp, C.POINTER(dp)]
+        L.oro_model_set_amd.argtypes = [vp, C.c_double, dp]
         for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
             getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
         L.oro_compute_Gc.argtypes = [vp, dp, dp, dp, dp, dp, ip]
@@ -341,6 +344,18 @@ class Model:
         k = np.ascontiguousarray(k)
         lib().oro_model_set_closure(self.handle, float(nu), k.ctypes.data_as(C.POINTER(C.c_double)))
 
+    def set_amd(self, C=1 / 3, Cnu=None, Ckappa=None):
+        """closure = AnisotropicMinimumDissipation(C = C, Cν = Cnu, Cκ = Ckappa): Ckappa a number or one value per tracer.
+        The eddy coefficients are the fields "nu_e", "kappa_e0", ..."""
+        Cnu = C if Cnu is None else Cnu
+        k = np.atleast_1d(np.asarray(C if Ckappa is None else Ckappa, dtype=np.float64))
+        if k.size == 1:
+            k = np.full(max(self.ntracers, 1), float(k[0]))
+        k = np.ascontiguousarray(k)
+        import ctypes                      # the keyword `C` (the reference's name) shadows the module alias here
+        if lib().oro_model_set_amd(self.handle, float(Cnu), k.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) != 0:
+            raise ValueError("AnisotropicMinimumDissipation needs a grid without Flat directions")
+
     def set_bc(self, name, side, kind, value=0.0):
         """field boundary condition with a constant value: kind in flux | value | gradient | open | default"""
         if lib().oro_model_set_bc(self.handle, name.encode(), SIDES[side], BC_KINDS[kind], float(value)) != 0:
@@ -381,3 +396,20 @@ class Model:
             lib().oro_model_destroy(self.handle)
         except Exception:
             pass
+
+
+def compute_amd_diffusivities(grid, Cnu, Ckappa, u, v, w, tracers):
+    """νₑ and κₑ[t] (parent arrays with halos, interiors filled) from parent arrays u, v, w, tracers with filled halos"""
+    dp = C.POINTER(C.c_double)
+    arr = lambda a: np.asfortranarray(a, dtype=np.float64)          # noqa: E731
+    u, v, w = arr(u), arr(v), arr(w)
+    tracers = [arr(t) for t in tracers]
+    shape = grid.parent_size((CENTER, CENTER, CENTER))
+    nu = np.zeros(shape, order="F")
+    kap = [np.zeros(shape, order="F") for _ in tracers]
+    ck = np.ascontiguousarray(np.asarray(Ckappa, dtype=np.float64).reshape(-1)) if tracers else np.zeros(1)
+    tp = (dp * max(len(tracers), 1))(*[t.ctypes.data_as(dp) for t in tracers])
+    kp = (dp * max(len(tracers), 1))(*[k.ctypes.data_as(dp) for k in kap])
+    lib().oro_compute_amd_diffusivities(grid.handle, float(Cnu), ck.ctypes.data_as(dp), u.ctypes.data_as(dp), v.ctypes.data_as(dp),
+                                        w.ctypes.data_as(dp), tp, len(tracers), nu.ctypes.data_as(dp), kp)
+    return nu, kap

@@ -676,3 +676,92 @@ def test_cell_advection_timescale(oracle):
     w = np.zeros((4, 4, 5)); w[0, 0, 2] = 2.0        # face k = 3 (1-based): Δzᵃᵃᶠ = zc[3] - zc[2] = 0.45 - 0.2
     m.set(u=z, v=z, w=w, enforce_incompressibility=False)
     assert np.isclose(m.cell_advection_timescale(), 0.25 / 2.0, rtol=1e-15)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# AnisotropicMinimumDissipation. The reference's tests only time-step a model with it (test_time_stepping.jl:257,
+# 400), so the restatement is pinned on flows whose eddy coefficients follow from the closure's definition
+# (anisotropic_minimum_dissipation.jl:152-196): νₑ = max(0, -Cν δ² r / q), κₑ = max(0, -Cκ δ² ϑ / σ), δ² = 3 / Σ 1/(2Δ)².
+# ----------------------------------------------------------------------------------------------------------------------
+def _linear_fields(oracle, g, a, b, c, grad_c):
+    """parent arrays (halos included) of u = a x, v = b y, w = c z and of a tracer with constant gradient grad_c"""
+    out = []
+    for loc, fn in (((1, 0, 0), lambda x, y, z: a * x + 0 * y + 0 * z), ((0, 1, 0), lambda x, y, z: b * y + 0 * x + 0 * z),
+                    ((0, 0, 1), lambda x, y, z: c * z + 0 * x + 0 * y),
+                    ((0, 0, 0), lambda x, y, z: grad_c[0] * x + grad_c[1] * y + grad_c[2] * z)):
+        shape = g.parent_size(loc)
+        ax = []
+        for d in range(3):
+            n = shape[d]
+            d0 = g.dc[d][0]                                 # regular spacing in these tests
+            idx = np.arange(n) - g.H[d]
+            coord = (idx + (0.0 if loc[d] else 0.5)) * d0
+            s = [1, 1, 1]; s[d] = n
+            ax.append(coord.reshape(s))
+        out.append(np.asfortranarray(fn(*ax) * np.ones(shape)))
+    return out
+
+
+@pytest.mark.parametrize("spacing", [(0.25, 0.25, 0.25), (0.5, 0.25, 0.125)])
+def test_amd_known_answers(oracle, spacing):
+    N = (6, 6, 6)
+    topo = (oracle.BOUNDED,) * 3
+    g = oracle.Grid(N, topology=topo, x=(0.0, N[0] * spacing[0]), y=(0.0, N[1] * spacing[1]), z=(0.0, N[2] * spacing[2]))
+    delta2 = 3.0 / sum(1.0 / (2 * d) ** 2 for d in spacing)
+    inner = (slice(4, -4),) * 3
+    # 1. axisymmetric strain u = (x, y, -2z): r = a³ + b³ + c³ = -6, q = 6  =>  νₑ = Cν δ²; tracer c = z: ϑ/σ = c  =>  κₑ = 2 Cκ δ²
+    u, v, w, c = _linear_fields(oracle, g, 1.0, 1.0, -2.0, (0.0, 0.0, 1.0))
+    nu, (kap,) = oracle.compute_amd_diffusivities(g, 1 / 3, [1 / 12], u, v, w, [c])
+    assert np.allclose(nu[inner], delta2 / 3, rtol=1e-13, atol=0)
+    assert np.allclose(kap[inner], 2 * delta2 / 12, rtol=1e-13, atol=0)
+    # the same strain, tracer gradient along x: ϑ/σ = a = 1 > 0  =>  κₑ clipped to zero
+    _, _, _, cx = _linear_fields(oracle, g, 1.0, 1.0, -2.0, (1.0, 0.0, 0.0))
+    _, (kap,) = oracle.compute_amd_diffusivities(g, 1 / 3, [1 / 3], u, v, w, [cx])
+    assert np.all(kap[inner] == 0.0)
+    # 2. reversed strain (-x, -y, 2z): r = +6  =>  clipped to zero (no backscatter)
+    u2, v2, w2, _ = _linear_fields(oracle, g, -1.0, -1.0, 2.0, (0.0, 0.0, 1.0))
+    nu, _ = oracle.compute_amd_diffusivities(g, 1 / 3, [], u2, v2, w2, [])
+    assert np.all(nu[inner] == 0.0)
+    # 3. laminar shear u = S z: the minimum-dissipation property -- no eddy viscosity
+    shape = g.parent_size((1, 0, 0))
+    zc = ((np.arange(shape[2]) - g.H[2] + 0.5) * spacing[2]).reshape(1, 1, -1)
+    ush = np.asfortranarray(3.0 * zc * np.ones(shape))
+    nu, _ = oracle.compute_amd_diffusivities(g, 1 / 3, [], ush, 0 * v, 0 * w, [])
+    assert np.all(nu[inner] == 0.0)
+    # 5. symmetric gradient tensor with off-diagonal terms, u = (x + a y, a x + y, -2z) on isotropic cells: r = tr S³ = 6a² - 6,
+    #    q = 6 + 2a²  =>  νₑ = Cν δ² (6 - 6a²) / (6 + 2a²)   (exercises the interpolated ffc terms)
+    if spacing[0] == spacing[1] == spacing[2]:
+        a = 0.5
+        shp_u, shp_v = g.parent_size((1, 0, 0)), g.parent_size((0, 1, 0))
+        xs = lambda n, face: ((np.arange(n) - 3 + (0.0 if face else 0.5)) * spacing[0])          # noqa: E731
+        uo = np.asfortranarray(xs(shp_u[0], 1).reshape(-1, 1, 1) + a * xs(shp_u[1], 0).reshape(1, -1, 1) + np.zeros(shp_u))
+        vo = np.asfortranarray(a * xs(shp_v[0], 0).reshape(-1, 1, 1) + xs(shp_v[1], 1).reshape(1, -1, 1) + np.zeros(shp_v))
+        nu, _ = oracle.compute_amd_diffusivities(g, 1 / 3, [], uo, vo, w, [])
+        assert np.allclose(nu[inner], (delta2 / 3) * (6 - 6 * a * a) / (6 + 2 * a * a), rtol=1e-13, atol=0)
+    # 4. fluid at rest: q = 0 and σ = 0 short-circuits
+    nu, (kap,) = oracle.compute_amd_diffusivities(g, 1 / 3, [1 / 3], 0 * u, 0 * v, 0 * w, [0 * c])
+    assert np.all(nu == 0.0) and np.all(kap == 0.0)
+
+
+def test_amd_model_time_steps_and_dissipates(oracle):
+    """time_stepping_works_with_closure (test_time_stepping.jl:41-57, 400) + what an LES closure is for: with the eddy viscosity
+    a random flow loses kinetic energy faster than without, and νₑ, κₑ are nonnegative with filled halos"""
+    g = oracle.Grid((12, 12, 12), topology=(oracle.PERIODIC, oracle.PERIODIC, oracle.BOUNDED))
+    rng = np.random.default_rng(5)
+    init = {n: rng.standard_normal(s) for n, s in (("u", (12, 12, 12)), ("v", (12, 12, 12)), ("w", (12, 12, 13)), ("c0", (12, 12, 12)))}
+    init["w"][:, :, 0] = init["w"][:, :, -1] = 0.0
+    ke = []
+    for amd in (False, True):
+        m = oracle.Model(g, 1)
+        if amd:
+            m.set_amd(C=1 / 3)
+        m.set(**init)
+        for _ in range(5):
+            m.time_step(2e-3)
+        assert m.iteration == 5 and all(np.isfinite(m.field(n)).all() for n in ("u", "v", "w", "c0"))
+        ke.append(sum(float((g.interior(m.field(n), m.loc(n)) ** 2).sum()) for n in ("u", "v", "w")))
+        if amd:
+            nu, ka = m.field("nu_e"), m.field("kappa_e0")
+            assert nu.min() >= 0 and ka.min() >= 0 and nu.max() > 0 and ka.max() > 0
+            assert np.array_equal(nu[:3], nu[-6:-3]) and np.array_equal(nu[:, :, 2], nu[:, :, 3])     # periodic x; zero-gradient bottom
+    assert ke[1] < ke[0]
