@@ -141,6 +141,18 @@ int ocn_add_fplane_coriolis(ocn_grid_t grid, double f, const double *u, const do
 int ocn_compute_closure_tendencies(ocn_grid_t grid, const double *u, const double *v, const double *w,
                                    const double *const *tracers, int ntracers, double nu, const double *kappa,
                                    double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range);
+/* the same with the coefficients read from ccc arrays with filled halos -- the eddy viscosity / diffusivities of an LES closure,
+ * interpolated to the flux locations (abstract_scalar_diffusivity_closure.jl:310-330: ν[i,j,k], ℑxyᶠᶠᵃ, ℑxzᶠᵃᶠ, ℑyzᵃᶠᶠ, ℑxᶠᵃᵃ, ...) */
+int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                                         const double *const *tracers, int ntracers, const double *nu_e,
+                                         const double *const *kappa_e, double *Gu, double *Gv, double *Gw, double *const *Gc,
+                                         const int *range);
+/* compute_diffusivities!(diffusivity_fields, closure::AnisotropicMinimumDissipation, model; parameters = :xyz)
+ * (turbulence_closure_implementations/anisotropic_minimum_dissipation.jl:152-216; Cb = nothing): νₑ and κₑ[t] over the interior from
+ * fields with filled halos; the caller fills the halos of the results (ocn_fill_halo_regions, default conditions). */
+int ocn_compute_amd_diffusivities(ocn_grid_t grid, double Cnu, const double *Ckappa, const double *u, const double *v,
+                                  const double *w, const double *const *tracers, int ntracers, double *nu_e,
+                                  double *const *kappa_e);
 
 /* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
 /* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage
@@ -281,6 +293,9 @@ int ocn_model_set_buoyancy(ocn_model_t model, int kind, int b_or_T_index, int S_
 int ocn_model_set_coriolis(ocn_model_t model, int enabled, double f);
 /* closure = ScalarDiffusivity(ν = nu, κ = kappa[tracer]) of the model constructor; all zeros / NULL: closure = nothing */
 int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
+/* closure = AnisotropicMinimumDissipation(Cν = Cnu, Cκ = Ckappa[tracer]) (replaces a ScalarDiffusivity). update_state! then
+ * computes the model fields "nu_e", "kappa_e0", ... and fills their halos before the tendencies. */
+int ocn_model_set_amd(ocn_model_t model, double Cnu, const double *Ckappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
 /* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
  * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */

@@ -9,7 +9,7 @@ from .architectures import GPU, architecture, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
-from .closures import ScalarDiffusivity
+from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
 from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state

@@ -548,10 +548,13 @@ extern "C" int ocn_add_fplane_coriolis(ocn_grid_t grid, double f, const double *
 }
 
 static int closure_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr, int ntr,
-                              double nu, const double *kappa, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range) {
+                              double nu, const double *kappa, double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range,
+                              const double *nu_e = nullptr, const double *const *kappa_e = nullptr) {
     const FView vu = make_view(g, u, LOC_U), vv = make_view(g, v, LOC_V), vw = make_view(g, w, LOC_W);
-    auto launch = [&](int F, const double *c, double *G, const int loc[3], double coef) -> int {
-        if (coef == 0.0) return OCN_OK;
+    auto launch = [&](int F, const double *c, double *G, const int loc[3], double coef, const double *K) -> int {
+        if (coef == 0.0 && !K) return OCN_OK;
+        const bool var = K != nullptr;
+        const FView vK = make_view(g, K ? K : u, LOC_C);
         Range6 r;
         int rc = check_range(g, range, &r, loc, F != F_C);
         if (rc) return rc;
@@ -559,17 +562,18 @@ static int closure_tendencies(const DGrid &g, const double *u, const double *v, 
         if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
         const FView vc = make_view(g, c ? c : u, LOC_C), vG = make_view(g, G, loc);
         const dim3 grd = grid3(nx, ny, nz, BLK);
-        if (F == F_U) hipLaunchKernelGGL(closure_tendency_kernel<F_U>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
-        if (F == F_V) hipLaunchKernelGGL(closure_tendency_kernel<F_V>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
-        if (F == F_W) hipLaunchKernelGGL(closure_tendency_kernel<F_W>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
-        if (F == F_C) hipLaunchKernelGGL(closure_tendency_kernel<F_C>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r);
+        if (F == F_U) hipLaunchKernelGGL(closure_tendency_kernel<F_U>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r, var, vK);
+        if (F == F_V) hipLaunchKernelGGL(closure_tendency_kernel<F_V>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r, var, vK);
+        if (F == F_W) hipLaunchKernelGGL(closure_tendency_kernel<F_W>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r, var, vK);
+        if (F == F_C) hipLaunchKernelGGL(closure_tendency_kernel<F_C>, grd, BLK, 0, g_stream, g, vu, vv, vw, vc, vG, coef, r, var, vK);
         return OCN_OK;
     };
     int rc;
-    if ((rc = launch(F_U, nullptr, Gu, LOC_U, nu)) || (rc = launch(F_V, nullptr, Gv, LOC_V, nu)) || (rc = launch(F_W, nullptr, Gw, LOC_W, nu)))
+    if ((rc = launch(F_U, nullptr, Gu, LOC_U, nu, nu_e)) || (rc = launch(F_V, nullptr, Gv, LOC_V, nu, nu_e)) ||
+        (rc = launch(F_W, nullptr, Gw, LOC_W, nu, nu_e)))
         return rc;
     for (int t = 0; t < ntr; ++t)
-        if ((rc = launch(F_C, tr[t], Gc[t], LOC_C, kappa ? kappa[t] : 0.0))) return rc;
+        if ((rc = launch(F_C, tr[t], Gc[t], LOC_C, kappa ? kappa[t] : 0.0, kappa_e ? kappa_e[t] : nullptr))) return rc;
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -583,6 +587,44 @@ extern "C" int ocn_compute_closure_tendencies(ocn_grid_t grid, const double *u, 
         return fail(OCN_EINVAL, "invalid argument");
     if (nu < 0) return fail(OCN_EINVAL, "viscosity must be non-negative");
     return closure_tendencies(grid->d, u, v, w, tracers, ntracers, nu, kappa, Gu, Gv, Gw, Gc, range);
+}
+
+extern "C" int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const double *u, const double *v, const double *w,
+                                                    const double *const *tracers, int ntracers, const double *nu_e,
+                                                    const double *const *kappa_e, double *Gu, double *Gv, double *Gw, double *const *Gc,
+                                                    const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !nu_e || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
+        (ntracers > 0 && (!tracers || !Gc || !kappa_e)))
+        return fail(OCN_EINVAL, "invalid argument");
+    return closure_tendencies(grid->d, u, v, w, tracers, ntracers, 0.0, nullptr, Gu, Gv, Gw, Gc, range, nu_e, kappa_e);
+}
+
+static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, const double *u, const double *v, const double *w,
+                             const double *const *tr, int ntr, double *nu_e, double *const *kappa_e) {
+    if (g.tx == OCN_FLAT || g.ty == OCN_FLAT || g.tz == OCN_FLAT)
+        return fail(OCN_ENOTSUP, "AnisotropicMinimumDissipation needs a grid without Flat directions");
+    AmdArgs a;
+    a.ntr = ntr; a.Cnu = Cnu;
+    a.u = make_view(g, u, LOC_U); a.v = make_view(g, v, LOC_V); a.w = make_view(g, w, LOC_W);
+    a.nu_e = make_view(g, nu_e, LOC_C);
+    for (int t = 0; t < ntr; ++t) {
+        a.c[t] = make_view(g, tr[t], LOC_C);
+        a.kappa_e[t] = make_view(g, kappa_e[t], LOC_C);
+        a.Ck[t] = Ckappa[t];
+    }
+    hipLaunchKernelGGL(amd_diffusivities_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, a);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_amd_diffusivities(ocn_grid_t grid, double Cnu, const double *Ckappa, const double *u, const double *v,
+                                             const double *w, const double *const *tracers, int ntracers, double *nu_e,
+                                             double *const *kappa_e) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !nu_e || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 || (ntracers > 0 && (!tracers || !kappa_e || !Ckappa)))
+        return fail(OCN_EINVAL, "invalid argument");
+    return amd_diffusivities(grid->d, Cnu, Ckappa, u, v, w, tracers, ntracers, nu_e, kappa_e);
 }
 
 extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fields, int ntracers, double *const *Gn,
@@ -1586,6 +1628,9 @@ struct ocn_model_s {
     bool any_bc = false, any_flux_bc = false;
     bool has_closure = false;               // closure = ScalarDiffusivity(ν, κ)
     double nu = 0.0, kappa[OCN_MAX_FIELDS] = {};
+    bool has_amd = false;                   // closure = AnisotropicMinimumDissipation(Cν, Cκ)
+    double Cnu = 0.0, Ckappa[OCN_MAX_FIELDS] = {};
+    double *nu_e = nullptr, *kappa_e[OCN_MAX_FIELDS] = {};   // diffusivity_fields.νₑ, .κₑ (ccc, with halos)
     bool has_coriolis = false;              // coriolis = FPlane(f)
     double fcor = 0.0;
     int buoyancy_kind = 0, bT_index = 0, S_index = 0;    // 0 nothing, 1 BuoyancyTracer, 2 linear SeawaterBuoyancy
@@ -1612,6 +1657,8 @@ extern "C" int ocn_model_destroy(ocn_model_t m) {
     for (auto &e : m->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->U2[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
     hipFree(m->pHY);
+    hipFree(m->nu_e);
+    for (int t = 0; t < OCN_MAX_FIELDS; ++t) hipFree(m->kappa_e[t]);
     hipFree(m->p); hipFree(m->blockmax);
     ocn_poisson_destroy(m->solver);
     delete m;
@@ -1665,6 +1712,15 @@ static int field_lookup(ocn_model_s *m, const char *name, double ***slot, int **
         if (!m->pHY) return fail(OCN_ESTATE, "the model has no hydrostatic pressure anomaly (buoyancy = nothing)");
         *slot = &m->pHY; *loc = const_cast<int *>(LOC_C); return OCN_OK;
     }
+    if (!strcmp(name, "nu_e") || !strncmp(name, "kappa_e", 7)) {
+        if (!m->has_amd) return fail(OCN_ESTATE, "the model has no eddy diffusivity fields (closure is not AnisotropicMinimumDissipation)");
+        *loc = const_cast<int *>(LOC_C);
+        if (!strcmp(name, "nu_e")) { *slot = &m->nu_e; return OCN_OK; }
+        const int t = name[7] - '0';
+        if (name[7] < '0' || name[7] > '9' || name[8] || t >= m->ntr) return fail(OCN_EINVAL, "no eddy diffusivity field %s", name);
+        *slot = &m->kappa_e[t];
+        return OCN_OK;
+    }
     if (q[0] == 'G' || q[0] == 'M') { kind = q[0]; ++q; }
     int f = -1;
     if (!strcmp(q, "u")) f = 0;
@@ -1714,7 +1770,7 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     return ocn_set_option(key, value);
 }
 
-static bool has_physics(const ocn_model_s *m) { return m->has_coriolis || m->buoyancy_kind != 0 || m->has_closure; }
+static bool has_physics(const ocn_model_s *m) { return m->has_coriolis || m->buoyancy_kind != 0 || m->has_closure || m->has_amd; }
 
 // Coriolis, hydrostatic pressure gradient and closure terms of every field -- and, when `sub` is given, the RK3 substep of the next
 // stage -- in one launch (tendency_epilogue_kernel)
@@ -1735,6 +1791,11 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     a.has_buoyancy = m->buoyancy_kind != 0;
     a.nu = m->nu;
     for (int t = 0; t < OCN_MAX_FIELDS; ++t) a.kappa[t] = t < m->ntr ? m->kappa[t] : 0.0;
+    a.amd = m->has_amd;
+    if (m->has_amd) {
+        a.nu_e = make_view(g, m->nu_e, LOC_C);
+        for (int t = 0; t < m->ntr; ++t) a.kappa_e[t] = make_view(g, m->kappa_e[t], LOC_C);
+    }
     a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
     a.any_flux = m->any_flux_bc;
@@ -1774,6 +1835,17 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
     const DGrid &g = m->grid->d;
     int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, /*fill_open_bcs=*/false, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
+    // compute_auxiliaries!: compute_diffusivities! over :xyz (update_nonhydrostatic_model_state.jl:58-69), then
+    // fill_halo_regions!(model.diffusivity_fields; only_local_halos = true) (:44) with the default ccc conditions
+    if (m->has_amd) {
+        if ((rc = amd_diffusivities(g, m->Cnu, m->Ckappa, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu_e, m->kappa_e))) return rc;
+        double *K[OCN_MAX_FIELDS];
+        int kl[OCN_MAX_FIELDS][3];
+        K[0] = m->nu_e;
+        for (int t = 0; t < m->ntr; ++t) K[1 + t] = m->kappa_e[t];
+        for (int q = 0; q < 1 + m->ntr; ++q) memcpy(kl[q], LOC_C, sizeof(int) * 3);
+        if ((rc = fill_halo_regions(m->grid, K, kl, 1 + m->ntr, true))) return rc;
+    }
     // compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69)
     if (m->buoyancy_kind &&
         (rc = update_hydrostatic_pressure(g, m->buoyancy_kind, m->U[3 + m->bT_index], m->U[3 + m->S_index], m->grav, m->alpha, m->beta, m->pHY)))
@@ -1803,6 +1875,9 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
                 if (!rc && m->has_closure)
                     rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu, m->kappa, m->Gn[0], m->Gn[1],
                                             m->Gn[2], m->Gn + 3, nullptr);
+                if (!rc && m->has_amd)
+                    rc = closure_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, 0.0, nullptr, m->Gn[0], m->Gn[1],
+                                            m->Gn[2], m->Gn + 3, nullptr, m->nu_e, m->kappa_e);
             }
         }
         // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) -- inside the epilogue pass when that runs
@@ -1868,6 +1943,31 @@ extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kap
         if (m->kappa[t] < 0) return fail(OCN_EINVAL, "diffusivity must be non-negative");
         if (m->kappa[t] != 0.0) m->has_closure = true;
     }
+    return OCN_OK;
+}
+
+// closure = AnisotropicMinimumDissipation(Cν = Cnu, Cκ = Ckappa[tracer]; Cb = nothing); replaces a ScalarDiffusivity
+extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa) {
+    NEED_INIT();
+    if (!m || (m->ntr > 0 && !Ckappa)) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = m->grid->d;
+    if (g.tx == OCN_FLAT || g.ty == OCN_FLAT || g.tz == OCN_FLAT)
+        return fail(OCN_ENOTSUP, "AnisotropicMinimumDissipation needs a grid without Flat directions");
+    int P[3];
+    parent_size(g, LOC_C, P);
+    const size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
+    auto alloc0 = [&](double **p) -> int {
+        if (*p) return OCN_OK;
+        HIP_TRY(dev_alloc((void **)p, bytes));
+        HIP_TRY(hipMemsetAsync(*p, 0, bytes, g_stream));
+        return OCN_OK;
+    };
+    int rc = alloc0(&m->nu_e);
+    for (int t = 0; t < m->ntr && !rc; ++t) rc = alloc0(&m->kappa_e[t]);
+    if (rc) return rc;
+    m->has_amd = true; m->has_closure = false; m->nu = 0.0;
+    m->Cnu = Cnu;
+    for (int t = 0; t < m->ntr; ++t) { m->kappa[t] = 0.0; m->Ckappa[t] = Ckappa[t]; }
     return OCN_OK;
 }
 

@@ -112,6 +112,16 @@ struct ClosureCtx {
     const FView &u, &v, &w;
     double nu;
     bool fx, fy, fz;
+    // the coefficient at a flux location: the number `nu`, or -- K != nullptr -- a ccc array interpolated there
+    // (abstract_scalar_diffusivity_closure.jl:310-330: ν[i,j,k], ℑxyᶠᶠᵃ, ℑxzᶠᵃᶠ, ℑyzᵃᶠᶠ, ℑxᶠᵃᵃ, ℑyᵃᶠᵃ, ℑzᵃᵃᶠ)
+    const FView *K;
+    __device__ __forceinline__ double K_ccc(int i, int j, int k) const { return K ? K->at(i, j, k) : nu; }
+    __device__ __forceinline__ double K_fcc(int i, int j, int k) const { return K ? 0.5 * (K->at(i - 1, j, k) + K->at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_cfc(int i, int j, int k) const { return K ? 0.5 * (K->at(i, j - 1, k) + K->at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_ccf(int i, int j, int k) const { return K ? 0.5 * (K->at(i, j, k - 1) + K->at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_ffc(int i, int j, int k) const { return K ? 0.5 * (K_fcc(i, j - 1, k) + K_fcc(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_fcf(int i, int j, int k) const { return K ? 0.5 * (K_fcc(i, j, k - 1) + K_fcc(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_cff(int i, int j, int k) const { return K ? 0.5 * (K_cfc(i, j, k - 1) + K_cfc(i, j, k)) : nu; }
     __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
     __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
     // ∂ at Center-in-d (f[+1] - f[0]) and at Face-in-d (f[0] - f[-1])
@@ -127,48 +137,188 @@ struct ClosureCtx {
     __device__ __forceinline__ double S12(int i, int j, int k) const { return 0.5 * (ddy_f(u, i, j, k) + ddx_f(v, i, j, k)); }
     __device__ __forceinline__ double S13(int i, int j, int k) const { return 0.5 * (ddz_f(u, i, j, k) + ddx_f(w, i, j, k)); }
     __device__ __forceinline__ double S23(int i, int j, int k) const { return 0.5 * (ddz_f(v, i, j, k) + ddy_f(w, i, j, k)); }
-    __device__ __forceinline__ double vf(double S) const { return -(2 * (nu * S)); }
+    // viscous_flux = -2 ν Σ at the location of Σ
+    __device__ __forceinline__ double vf11(int i, int j, int k) const { return -(2 * (K_ccc(i, j, k) * S11(i, j, k))); }
+    __device__ __forceinline__ double vf22(int i, int j, int k) const { return -(2 * (K_ccc(i, j, k) * S22(i, j, k))); }
+    __device__ __forceinline__ double vf33(int i, int j, int k) const { return -(2 * (K_ccc(i, j, k) * S33(i, j, k))); }
+    __device__ __forceinline__ double vf12(int i, int j, int k) const { return -(2 * (K_ffc(i, j, k) * S12(i, j, k))); }
+    __device__ __forceinline__ double vf13(int i, int j, int k) const { return -(2 * (K_fcf(i, j, k) * S13(i, j, k))); }
+    __device__ __forceinline__ double vf23(int i, int j, int k) const { return -(2 * (K_cff(i, j, k) * S23(i, j, k))); }
 };
 
 // V⁻¹ (δx(Ax flux) + δy(Ay flux) + δz(Az flux)) of the closure for field F at (i, j, k); coef = ν (momentum) or κ (tracer c)
 template <int F>
 __device__ __forceinline__ double closure_divergence(const DGrid &g, const FView &u, const FView &v, const FView &w, const FView &c,
-                                                     double coef, int i, int j, int k) {
-    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT};
+                                                     double coef, int i, int j, int k, const FView *K = nullptr) {
+    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT, K};
     const double dx_ = g.dx, dy_ = g.dy;
     double dx, dy, dz, vinv;
     if (F == F_U) {            // ∂ⱼ_τ₁ⱼ at fcc: Ax_qᶜᶜᶜ, Ay_qᶠᶠᶜ, Az_qᶠᶜᶠ
         vinv = g.vinv_c[k - 1 + g.Hz];
-        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf(X.S11(i, j, k)) - (dy_ * X.dzc(k)) * X.vf(X.S11(i - 1, j, k));
-        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf(X.S12(i, j + 1, k)) - (dx_ * X.dzc(k)) * X.vf(X.S12(i, j, k));
-        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S13(i, j, k + 1)) - (dx_ * dy_) * X.vf(X.S13(i, j, k));
+        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf11(i, j, k) - (dy_ * X.dzc(k)) * X.vf11(i - 1, j, k);
+        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf12(i, j + 1, k) - (dx_ * X.dzc(k)) * X.vf12(i, j, k);
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf13(i, j, k + 1) - (dx_ * dy_) * X.vf13(i, j, k);
     } else if (F == F_V) {     // ∂ⱼ_τ₂ⱼ at cfc: Ax_qᶠᶠᶜ, Ay_qᶜᶜᶜ, Az_qᶜᶠᶠ
         vinv = g.vinv_c[k - 1 + g.Hz];
-        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf(X.S12(i + 1, j, k)) - (dy_ * X.dzc(k)) * X.vf(X.S12(i, j, k));
-        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf(X.S22(i, j, k)) - (dx_ * X.dzc(k)) * X.vf(X.S22(i, j - 1, k));
-        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S23(i, j, k + 1)) - (dx_ * dy_) * X.vf(X.S23(i, j, k));
+        dx = X.fx ? 0.0 : (dy_ * X.dzc(k)) * X.vf12(i + 1, j, k) - (dy_ * X.dzc(k)) * X.vf12(i, j, k);
+        dy = X.fy ? 0.0 : (dx_ * X.dzc(k)) * X.vf22(i, j, k) - (dx_ * X.dzc(k)) * X.vf22(i, j - 1, k);
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf23(i, j, k + 1) - (dx_ * dy_) * X.vf23(i, j, k);
     } else if (F == F_W) {     // ∂ⱼ_τ₃ⱼ at ccf: Ax_qᶠᶜᶠ, Ay_qᶜᶠᶠ, Az_qᶜᶜᶜ
         vinv = g.vinv_f[k - 1 + g.Hz];
-        dx = X.fx ? 0.0 : (dy_ * X.dzf(k)) * X.vf(X.S13(i + 1, j, k)) - (dy_ * X.dzf(k)) * X.vf(X.S13(i, j, k));
-        dy = X.fy ? 0.0 : (dx_ * X.dzf(k)) * X.vf(X.S23(i, j + 1, k)) - (dx_ * X.dzf(k)) * X.vf(X.S23(i, j, k));
-        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf(X.S33(i, j, k)) - (dx_ * dy_) * X.vf(X.S33(i, j, k - 1));
+        dx = X.fx ? 0.0 : (dy_ * X.dzf(k)) * X.vf13(i + 1, j, k) - (dy_ * X.dzf(k)) * X.vf13(i, j, k);
+        dy = X.fy ? 0.0 : (dx_ * X.dzf(k)) * X.vf23(i, j + 1, k) - (dx_ * X.dzf(k)) * X.vf23(i, j, k);
+        dz = X.fz ? 0.0 : (dx_ * dy_) * X.vf33(i, j, k) - (dx_ * dy_) * X.vf33(i, j, k - 1);
     } else {                   // ∇_dot_qᶜ at ccc: Ax_qᶠᶜᶜ, Ay_qᶜᶠᶜ, Az_qᶜᶜᶠ of -(κ ∂c)
         vinv = g.vinv_c[k - 1 + g.Hz];
         const double ax = dy_ * X.dzc(k), ay = dx_ * X.dzc(k), az = dx_ * dy_;
-        dx = X.fx ? 0.0 : ax * -(coef * X.ddx_f(c, i + 1, j, k)) - ax * -(coef * X.ddx_f(c, i, j, k));
-        dy = X.fy ? 0.0 : ay * -(coef * X.ddy_f(c, i, j + 1, k)) - ay * -(coef * X.ddy_f(c, i, j, k));
-        dz = X.fz ? 0.0 : az * -(coef * X.ddz_f(c, i, j, k + 1)) - az * -(coef * X.ddz_f(c, i, j, k));
+        dx = X.fx ? 0.0 : ax * -(X.K_fcc(i + 1, j, k) * X.ddx_f(c, i + 1, j, k)) - ax * -(X.K_fcc(i, j, k) * X.ddx_f(c, i, j, k));
+        dy = X.fy ? 0.0 : ay * -(X.K_cfc(i, j + 1, k) * X.ddy_f(c, i, j + 1, k)) - ay * -(X.K_cfc(i, j, k) * X.ddy_f(c, i, j, k));
+        dz = X.fz ? 0.0 : az * -(X.K_ccf(i, j, k + 1) * X.ddz_f(c, i, j, k + 1)) - az * -(X.K_ccf(i, j, k) * X.ddz_f(c, i, j, k));
     }
     return vinv * ((dx + dy) + dz);
 }
 
 template <int F>
-__global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, double coef, Range6 r) {
+__global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u, FView v, FView w, FView c, FView G, double coef, Range6 r,
+                                                               bool var, FView K) {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = r.k0 + blockIdx.z;
     if (i > r.i1 || j > r.j1 || k > r.k1) return;
-    G.at(i, j, k) = (G.at(i, j, k) - closure_divergence<F>(g, u, v, w, c, coef, i, j, k)) + 0.0;
+    G.at(i, j, k) = (G.at(i, j, k) - closure_divergence<F>(g, u, v, w, c, coef, i, j, k, var ? &K : nullptr)) + 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AnisotropicMinimumDissipation(Cν, Cκ; Cb = nothing): eddy viscosity νₑ and eddy diffusivities κₑ at ccc
+// (turbulence_closure_implementations/anisotropic_minimum_dissipation.jl:152-196 kernels, :226-333 terms; velocity_tracer_gradients.jl:
+// 116-250 normalised gradients -- norm_∂x_u = ∂x_u unscaled, norm_∂x_v = Δᶠx/Δᶠy ∂x_v with Δᶠ = 2Δ at the CALLING index, the
+// ℑxzᶜᵃᶜ of norm_∂y_w at :323 kept as written). Sums and products fold left to right, x^2 = x*x, (-C) δ² r / q.
+// One thread per cell: νₑ, then κₑ of every tracer (the velocity-gradient terms are shared through the L1/L2).
+// ---------------------------------------------------------------------------------------------------------------------
+enum AmdOp { A_DXV, A_DYU, A_DXW, A_DZU, A_DYW, A_DZV, A_S12, A_S13, A_S23, A_DXV2, A_DYU2, A_DXW2, A_DZU2, A_DYW2, A_DZV2,
+             A_DXV_S12, A_DYU_S12, A_DXW_S13, A_DZU_S13, A_DZV_S23, A_DYW_S23, A_DXC, A_DYC, A_DZC, A_DXC2, A_DYC2, A_DZC2 };
+struct AmdCtx {
+    const DGrid &g;
+    const FView &u, &v, &w, &c;
+    __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double FX() const { return 2 * g.dx; }
+    __device__ __forceinline__ double FY() const { return 2 * g.dy; }
+    __device__ __forceinline__ double FZ(int k) const { return 2 * dzc(k); }
+    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return (f.at(i + 1, j, k) - f.at(i, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return (f.at(i, j + 1, k) - f.at(i, j, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return (f.at(i, j, k + 1) - f.at(i, j, k)) * (1.0 / dzc(k)); }
+    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i - 1, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j - 1, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j, k - 1)) * (1.0 / dzf(k)); }
+    template <int OP> __device__ __forceinline__ double op(int i, int j, int k) const {
+        switch (OP) {
+        case A_DXV: return FX() / FY() * ddx_f(v, i, j, k);
+        case A_DYU: return FY() / FX() * ddy_f(u, i, j, k);
+        case A_DXW: return FX() / FZ(k) * ddx_f(w, i, j, k);
+        case A_DZU: return FZ(k) / FX() * ddz_f(u, i, j, k);
+        case A_DYW: return FY() / FZ(k) * ddy_f(w, i, j, k);
+        case A_DZV: return FZ(k) / FY() * ddz_f(v, i, j, k);
+        case A_S12: return 0.5 * (op<A_DYU>(i, j, k) + op<A_DXV>(i, j, k));
+        case A_S13: return 0.5 * (op<A_DZU>(i, j, k) + op<A_DXW>(i, j, k));
+        case A_S23: return 0.5 * (op<A_DZV>(i, j, k) + op<A_DYW>(i, j, k));
+        case A_DXV2: { const double x = op<A_DXV>(i, j, k); return x * x; }
+        case A_DYU2: { const double x = op<A_DYU>(i, j, k); return x * x; }
+        case A_DXW2: { const double x = op<A_DXW>(i, j, k); return x * x; }
+        case A_DZU2: { const double x = op<A_DZU>(i, j, k); return x * x; }
+        case A_DYW2: { const double x = op<A_DYW>(i, j, k); return x * x; }
+        case A_DZV2: { const double x = op<A_DZV>(i, j, k); return x * x; }
+        case A_DXV_S12: return op<A_DXV>(i, j, k) * op<A_S12>(i, j, k);
+        case A_DYU_S12: return op<A_DYU>(i, j, k) * op<A_S12>(i, j, k);
+        case A_DXW_S13: return op<A_DXW>(i, j, k) * op<A_S13>(i, j, k);
+        case A_DZU_S13: return op<A_DZU>(i, j, k) * op<A_S13>(i, j, k);
+        case A_DZV_S23: return op<A_DZV>(i, j, k) * op<A_S23>(i, j, k);
+        case A_DYW_S23: return op<A_DYW>(i, j, k) * op<A_S23>(i, j, k);
+        case A_DXC: return FX() * ddx_f(c, i, j, k);
+        case A_DYC: return FY() * ddy_f(c, i, j, k);
+        case A_DZC: return FZ(k) * ddz_f(c, i, j, k);
+        case A_DXC2: { const double x = op<A_DXC>(i, j, k); return x * x; }
+        case A_DYC2: { const double x = op<A_DYC>(i, j, k); return x * x; }
+        default: { const double x = op<A_DZC>(i, j, k); return x * x; }   // A_DZC2
+        }
+    }
+    template <int OP> __device__ __forceinline__ double Ix(int i, int j, int k) const { return 0.5 * (op<OP>(i, j, k) + op<OP>(i + 1, j, k)); }
+    template <int OP> __device__ __forceinline__ double Iy(int i, int j, int k) const { return 0.5 * (op<OP>(i, j, k) + op<OP>(i, j + 1, k)); }
+    template <int OP> __device__ __forceinline__ double Iz(int i, int j, int k) const { return 0.5 * (op<OP>(i, j, k) + op<OP>(i, j, k + 1)); }
+    template <int OP> __device__ __forceinline__ double Ixy(int i, int j, int k) const { return 0.5 * (Ix<OP>(i, j, k) + Ix<OP>(i, j + 1, k)); }
+    template <int OP> __device__ __forceinline__ double Ixz(int i, int j, int k) const { return 0.5 * (Ix<OP>(i, j, k) + Ix<OP>(i, j, k + 1)); }
+    template <int OP> __device__ __forceinline__ double Iyz(int i, int j, int k) const { return 0.5 * (Iy<OP>(i, j, k) + Iy<OP>(i, j, k + 1)); }
+    __device__ __forceinline__ double delta2(int k) const {
+        const double fx = FX(), fy = FY(), fz = FZ(k);
+        return 3 / ((1 / (fx * fx) + 1 / (fy * fy)) + 1 / (fz * fz));
+    }
+};
+
+__device__ __noinline__ double amd_viscosity(const AmdCtx &A, double Cnu, int i, int j, int k) {
+    const double dxu = A.ddx_c(A.u, i, j, k), dyv = A.ddy_c(A.v, i, j, k), dzw = A.ddz_c(A.w, i, j, k);
+    const double xv2 = A.Ixy<A_DXV2>(i, j, k), yu2 = A.Ixy<A_DYU2>(i, j, k), xw2 = A.Ixz<A_DXW2>(i, j, k), zu2 = A.Ixz<A_DZU2>(i, j, k),
+                 yw2 = A.Iyz<A_DYW2>(i, j, k), zv2 = A.Iyz<A_DZV2>(i, j, k);
+    double q = dxu * dxu + dyv * dyv;
+    q = q + dzw * dzw;
+    q = q + xv2; q = q + yu2; q = q + xw2; q = q + zu2; q = q + yw2; q = q + zv2;
+    if (q == 0) return fmax(0.0, 0.0);
+    double b1 = dxu * (dxu * dxu) + dyv * xv2;
+    b1 = b1 + dzw * xw2;
+    b1 = b1 + 2 * dxu * A.Ixy<A_DXV_S12>(i, j, k);
+    b1 = b1 + 2 * dxu * A.Ixz<A_DXW_S13>(i, j, k);
+    b1 = b1 + 2 * A.Ixy<A_DXV>(i, j, k) * A.Ixz<A_DXW>(i, j, k) * A.Iyz<A_S23>(i, j, k);
+    double b2 = dxu * yu2 + dyv * (dyv * dyv);
+    b2 = b2 + dzw * yw2;
+    b2 = b2 + 2 * dyv * A.Ixy<A_DYU_S12>(i, j, k);
+    b2 = b2 + 2 * A.Ixy<A_DYU>(i, j, k) * A.Iyz<A_DYW>(i, j, k) * A.Ixz<A_S13>(i, j, k);
+    b2 = b2 + 2 * dyv * A.Iyz<A_DYW_S23>(i, j, k);
+    double b3 = dxu * zu2 + dyv * zv2;
+    b3 = b3 + dzw * (dzw * dzw);
+    b3 = b3 + 2 * A.Ixz<A_DZU>(i, j, k) * A.Iyz<A_DZV>(i, j, k) * A.Ixy<A_S12>(i, j, k);
+    b3 = b3 + 2 * dzw * A.Ixz<A_DZU_S13>(i, j, k);
+    b3 = b3 + 2 * dzw * A.Iyz<A_DZV_S23>(i, j, k);
+    const double r = (b1 + b2) + b3;
+    const double Cb_zeta = 0.0 / A.FZ(k);
+    const double nu = -Cnu * A.delta2(k) * (r - Cb_zeta) / q;
+    return fmax(0.0, nu);
+}
+
+__device__ __noinline__ double amd_diffusivity(const AmdCtx &A, double Ck, int i, int j, int k) {
+    const double xc2 = A.Ix<A_DXC2>(i, j, k), yc2 = A.Iy<A_DYC2>(i, j, k), zc2 = A.Iz<A_DZC2>(i, j, k);
+    const double sigma = (xc2 + yc2) + zc2;
+    if (sigma == 0) return fmax(0.0, 0.0);
+    const double dxu = A.ddx_c(A.u, i, j, k), dyv = A.ddy_c(A.v, i, j, k), dzw = A.ddz_c(A.w, i, j, k);
+    const double cx = A.Ix<A_DXC>(i, j, k), cy = A.Iy<A_DYC>(i, j, k), cz = A.Iz<A_DZC>(i, j, k);
+    double t1 = dxu * xc2 + A.Ixy<A_DXV>(i, j, k) * cx * cy;
+    t1 = t1 + A.Ixz<A_DXW>(i, j, k) * cx * cz;
+    double t2 = A.Ixy<A_DYU>(i, j, k) * cy * cx + dyv * yc2;
+    t2 = t2 + A.Ixz<A_DYW>(i, j, k) * cy * cz;
+    double t3 = A.Ixz<A_DZU>(i, j, k) * cz * cx + A.Iyz<A_DZV>(i, j, k) * cz * cy;
+    t3 = t3 + dzw * zc2;
+    const double theta = (t1 + t2) + t3;
+    const double kap = -Ck * A.delta2(k) * theta / sigma;
+    return fmax(0.0, kap);
+}
+
+struct AmdArgs {
+    int ntr;
+    FView u, v, w, c[OCN_MAX_FIELDS], nu_e, kappa_e[OCN_MAX_FIELDS];
+    double Cnu, Ck[OCN_MAX_FIELDS];
+};
+
+__global__ void __launch_bounds__(256) amd_diffusivities_kernel(DGrid g, AmdArgs a) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    {
+        const AmdCtx A{g, a.u, a.v, a.w, a.u};
+        a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);
+    }
+    for (int t = 0; t < a.ntr; ++t) {
+        const AmdCtx A{g, a.u, a.v, a.w, a.c[t]};
+        a.kappa_e[t].at(i, j, k) = amd_diffusivity(A, a.Ck[t], i, j, k);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -298,6 +448,8 @@ struct EpilogueArgs {
     Range6 r[OCN_MAX_FIELDS];
     bool has_coriolis, has_buoyancy, substep, has_zeta;
     double fcor, nu, kappa[OCN_MAX_FIELDS], dt, gamma, zeta;
+    bool amd;                                   // eddy coefficients from arrays (AnisotropicMinimumDissipation)
+    FView nu_e, kappa_e[OCN_MAX_FIELDS];
     // valued Flux boundary conditions (compute_flux_bcs.jl:57-163), applied after the interior terms: [field][side]
     bool any_flux;
     bool has_flux[OCN_MAX_FIELDS][6];
@@ -318,16 +470,17 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
     if (f == 0) {
         if (a.has_coriolis) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
         if (a.has_buoyancy) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
-        if (a.nu != 0.0) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
     } else if (f == 1) {
         if (a.has_coriolis) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
         if (a.has_buoyancy) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
-        if (a.nu != 0.0) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
     } else if (f == 2) {
-        if (a.nu != 0.0) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
     } else {
         const double kap = a.kappa[f - 3];
-        if (kap != 0.0) G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k)) + 0.0;
+        if (kap != 0.0 || a.amd)
+            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, a.amd ? &a.kappa_e[f - 3] : nullptr)) + 0.0;
     }
     if (a.any_flux) {
         // compute_x/y/z_bcs!: G[1] += flux A / V, G[N] -= flux A / V (x, then y, then z as the reference launches them)

@@ -50,6 +50,24 @@ def compute_closure_tendencies(grid, fields, Gn, closure, tracer_names, kernel_p
         Gn[0].data, Gn[1].data, Gn[2].data, _ptr_array(gc) if gc else None, _range(kernel_parameters)))
 
 
+def compute_amd_diffusivities(grid, closure, tracer_names, fields, νₑ, κₑ):
+    """compute_diffusivities!(…, closure::AnisotropicMinimumDissipation, …) over the interior; fields = u, v, w, tracers... with filled
+    halos; fill the halos of νₑ, κₑ afterwards (fill_halo_regions)"""
+    karr, kp = closure.Ckappa_array(tracer_names)
+    tr = fields[3:]
+    _lib.check(_lib.lib().ocn_compute_amd_diffusivities(
+        grid.handle, closure.Cν, kp, fields[0].data, fields[1].data, fields[2].data, _ptr_array(tr) if tr else None, len(tr),
+        νₑ.data, _ptr_array(κₑ) if κₑ else None))
+
+
+def compute_closure_tendencies_field(grid, fields, Gn, νₑ, κₑ, kernel_parameters=None):
+    """adds -∂ⱼτᵢⱼ, -∇·q with the coefficients read from the ccc arrays νₑ, κₑ[tracer] (halos filled)"""
+    tr, gc = fields[3:], Gn[3:]
+    _lib.check(_lib.lib().ocn_compute_closure_tendencies_field(
+        grid.handle, fields[0].data, fields[1].data, fields[2].data, _ptr_array(tr) if tr else None, len(tr), νₑ.data,
+        _ptr_array(κₑ) if κₑ else None, Gn[0].data, Gn[1].data, Gn[2].data, _ptr_array(gc) if gc else None, _range(kernel_parameters)))
+
+
 def update_hydrostatic_pressure(grid, buoyancy, tracers_by_name, pHY):
     """update_hydrostatic_pressure! (update_hydrostatic_pressure.jl:12-49) for BuoyancyTracer | linear SeawaterBuoyancy"""
     from .buoyancy import BuoyancyTracer

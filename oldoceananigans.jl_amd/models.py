@@ -57,9 +57,10 @@ class NonhydrostaticModel:
         if buoyancy is not None and not isinstance(buoyancy, (BuoyancyTracer, SeawaterBuoyancy)):
             raise NotImplementedError("buoyancy must be nothing, BuoyancyTracer() or SeawaterBuoyancy(LinearEquationOfState)")
         self.buoyancy = buoyancy
-        from .closures import ScalarDiffusivity
-        if closure is not None and not isinstance(closure, ScalarDiffusivity):
-            raise NotImplementedError("only closure = nothing | ScalarDiffusivity(ν, κ) is on the accelerated path (SURVEY.md 8f)")
+        from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
+        if closure is not None and not isinstance(closure, (ScalarDiffusivity, AnisotropicMinimumDissipation)):
+            raise NotImplementedError("only closure = nothing | ScalarDiffusivity(ν, κ) | AnisotropicMinimumDissipation(C, Cν, Cκ) is on "
+                                      "the accelerated path (SURVEY.md 8f)")
         self.closure = closure
         self.grid, self.advection = grid, advection
         self.tracer_names = tuple(str(t) for t in (tracers if isinstance(tracers, (tuple, list)) else (tracers,)))
@@ -90,7 +91,17 @@ class NonhydrostaticModel:
             self.pressures = P(self._field("p"))
         if coriolis is not None:
             _lib.check(_lib.lib().ocn_model_set_coriolis(self.handle, 1, coriolis.f))
-        if closure is not None:
+        self.diffusivity_fields = None
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            self._kappa, kp = closure.Ckappa_array(self.tracer_names)
+            _lib.check(_lib.lib().ocn_model_set_amd(self.handle, closure.Cν, kp))
+            # build_diffusivity_fields (anisotropic_minimum_dissipation.jl:339-352). Python normalises identifiers (NFKC): the
+            # attribute written `.νₑ` in source is looked up as "νe", so the tuple's field names are the normalised spellings
+            import unicodedata
+            D = namedtuple("DiffusivityFields", [unicodedata.normalize("NFKC", n) for n in ("νₑ", "κₑ")])
+            K = namedtuple("EddyDiffusivities", self.tracer_names) if self.tracer_names else tuple
+            self.diffusivity_fields = D(self._field("nu_e"), K(*[self._field("kappa_e%d" % n) for n in range(len(self.tracer_names))]))
+        elif closure is not None:
             self._kappa, kp = closure.kappa_array(self.tracer_names)
             _lib.check(_lib.lib().ocn_model_set_closure(self.handle, closure.ν, kp))
         # boundary_conditions = (u = FieldBoundaryConditions(top = FluxBoundaryCondition(Q)), ...) (nonhydrostatic_model.jl:

@@ -562,3 +562,48 @@ def test_nan_checker(ocn, arch):
     checker.erroring = True
     with pytest.raises(RuntimeError, match="NaN found in field u"):
         checker(sim)
+
+
+@pytest.mark.parametrize("topology,size,stretched", [(("Periodic", "Periodic", "Periodic"), (16, 12, 8), False),
+                                                      (("Periodic", "Periodic", "Bounded"), (16, 16, 12), True),
+                                                      (("Bounded", "Bounded", "Bounded"), (12, 10, 8), False)])
+def test_anisotropic_minimum_dissipation_matches_oracle(ocn, oracle, arch, topology, size, stretched):
+    """closure = AnisotropicMinimumDissipation (BASELINE.json configs[4]'s closure): eddy viscosity / diffusivities
+    (interior and filled halos), the tendencies with array coefficients, fused vs separate epilogue, 10 RK3 steps. Parity is
+    against the oracle's restatement, which analytic known answers pin (tests/test_oracle_kats.py::test_amd_known_answers) -- the
+    reference holds no numbers for this closure."""
+    z = tanh_faces(size[2]) if stretched else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+    topo_cls = tuple(getattr(ocn, t) for t in topology)
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo_cls)
+    g_cpu = oracle.Grid(size, topology=tuple({"Periodic": 0, "Bounded": 1}[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    closure = ocn.AnisotropicMinimumDissipation(C=1 / 3, Cκ={"T": 1 / 3, "S": 1 / 12})
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, advection=ocn.WENO(), tracers=("T", "S"), closure=closure)
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_amd(C=1 / 3, Ckappa=[1 / 3, 1 / 12])
+    set_both(ocn, m_gpu, m_cpu, seed=8, enforce_incompressibility=False)
+    for fused in (1, 0):
+        m_gpu.set_option("fused_epilogue", fused)
+        ocn.update_state(m_gpu, True)
+        m_cpu.update_state(True)
+        D = m_gpu.diffusivity_fields
+        assert np.array_equal(D.νₑ.parent(), m_cpu.field("nu_e")) and m_cpu.field("nu_e").max() > 0
+        for t, name in enumerate(("T", "S")):
+            assert np.array_equal(getattr(D.κₑ, name).parent(), m_cpu.field("kappa_e%d" % t)), name
+        for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (n, fused)
+    m_gpu.set_option("fused_epilogue", 1)
+    # the stand-alone operators give the same arrays
+    flds = list(m_gpu.fields().values())
+    nu = ocn.CenterField(g_gpu)
+    ka = [ocn.CenterField(g_gpu), ocn.CenterField(g_gpu)]
+    ocn.kernels.compute_amd_diffusivities(g_gpu, closure, ("T", "S"), flds, nu, ka)
+    ocn.fill_halo_regions([nu] + ka)
+    assert np.array_equal(nu.parent(), m_cpu.field("nu_e")) and np.array_equal(ka[1].parent(), m_cpu.field("kappa_e1"))
+    # 10 RK3 steps
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.1 * min(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))) / 0.6
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (name, rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]))
