@@ -127,11 +127,14 @@ def main():
                          "--gpus 8). Default 0: weak scaling, --size^3 cells per GPU, global (size*N) x size x size")
     ap.add_argument("--tendency-impl", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched", "ppb_physics"],
+    ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched", "ppb_physics", "ppb_amd"],
                     help="ppp: BASELINE.json configs[1] (the metric's configuration, default); ppb_stretched: configs[2], "
                          "256x256x128 (Periodic, Periodic, Bounded) with tanh-stretched z (Fourier-tridiagonal solver), single GPU; "
                          "ppb_physics: the same grid with the SURVEY 8f.1 physics switched on -- ScalarDiffusivity, linear "
-                         "SeawaterBuoyancy (hydrostatic pressure anomaly), surface Flux / bottom Gradient boundary conditions")
+                         "SeawaterBuoyancy (hydrostatic pressure anomaly), surface Flux / bottom Gradient boundary conditions; "
+                         "ppb_amd: the physics of BASELINE.json configs[4] (ocean_wind_mixing_and_convection) on that grid -- "
+                         "AnisotropicMinimumDissipation, linear SeawaterBuoyancy, wind-stress / heat-flux / bottom-gradient conditions "
+                         "(constant values; the example's S-dependent evaporation flux is replaced by a constant)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +169,7 @@ def main():
     else:
         arch = ocn.GPU(local_rank)
         physics = {}
-        if args.workload in ("ppb_stretched", "ppb_physics"):
+        if args.workload in ("ppb_stretched", "ppb_physics", "ppb_amd"):
             from helpers import tanh_faces
             grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
                                        topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
@@ -175,6 +178,13 @@ def main():
                 physics = dict(closure=ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4), buoyancy=ocn.SeawaterBuoyancy(),
                                boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
                                                     "T": F(top=ocn.FluxBoundaryCondition(1e-4), bottom=ocn.GradientBoundaryCondition(0.01))})
+            if args.workload == "ppb_amd":
+                F = ocn.FieldBoundaryConditions
+                physics = dict(closure=ocn.AnisotropicMinimumDissipation(),
+                               buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
+                               boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                                    "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+                                                    "S": F(top=ocn.FluxBoundaryCondition(-2e-8))})
         else:
             grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
         model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"), **physics)
@@ -253,7 +263,9 @@ def main():
                    (f"{N}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
                     "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +
                     ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
-                     if args.workload == "ppb_physics" else "")),
+                     if args.workload == "ppb_physics" else
+                     "; + AnisotropicMinimumDissipation, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (the physics of "
+                     "BASELINE.json configs[4]; constant surface fluxes)" if args.workload == "ppb_amd" else "")),
                    "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}): RCCL send/recv halos, substructured x solve "
                                                                      "(one all-gather of 2 complex per mode per solve)",
                    "dt": dt, "max_abs_divergence_after_run": div,

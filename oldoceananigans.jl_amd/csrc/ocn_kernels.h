@@ -112,16 +112,18 @@ struct ClosureCtx {
     const FView &u, &v, &w;
     double nu;
     bool fx, fy, fz;
-    // the coefficient at a flux location: the number `nu`, or -- K != nullptr -- a ccc array interpolated there
+    // the coefficient at a flux location: the number `nu`, or -- var -- the ccc array K interpolated there
     // (abstract_scalar_diffusivity_closure.jl:310-330: ν[i,j,k], ℑxyᶠᶠᵃ, ℑxzᶠᵃᶠ, ℑyzᵃᶠᶠ, ℑxᶠᵃᵃ, ℑyᵃᶠᵃ, ℑzᵃᵃᶠ)
-    const FView *K;
-    __device__ __forceinline__ double K_ccc(int i, int j, int k) const { return K ? K->at(i, j, k) : nu; }
-    __device__ __forceinline__ double K_fcc(int i, int j, int k) const { return K ? 0.5 * (K->at(i - 1, j, k) + K->at(i, j, k)) : nu; }
-    __device__ __forceinline__ double K_cfc(int i, int j, int k) const { return K ? 0.5 * (K->at(i, j - 1, k) + K->at(i, j, k)) : nu; }
-    __device__ __forceinline__ double K_ccf(int i, int j, int k) const { return K ? 0.5 * (K->at(i, j, k - 1) + K->at(i, j, k)) : nu; }
-    __device__ __forceinline__ double K_ffc(int i, int j, int k) const { return K ? 0.5 * (K_fcc(i, j - 1, k) + K_fcc(i, j, k)) : nu; }
-    __device__ __forceinline__ double K_fcf(int i, int j, int k) const { return K ? 0.5 * (K_fcc(i, j, k - 1) + K_fcc(i, j, k)) : nu; }
-    __device__ __forceinline__ double K_cff(int i, int j, int k) const { return K ? 0.5 * (K_cfc(i, j, k - 1) + K_cfc(i, j, k)) : nu; }
+    // (held by value: a pointer into the kernel-argument struct would push that struct to scratch memory)
+    bool var;
+    const FView &K;
+    __device__ __forceinline__ double K_ccc(int i, int j, int k) const { return var ? K.at(i, j, k) : nu; }
+    __device__ __forceinline__ double K_fcc(int i, int j, int k) const { return var ? 0.5 * (K.at(i - 1, j, k) + K.at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_cfc(int i, int j, int k) const { return var ? 0.5 * (K.at(i, j - 1, k) + K.at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_ccf(int i, int j, int k) const { return var ? 0.5 * (K.at(i, j, k - 1) + K.at(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_ffc(int i, int j, int k) const { return var ? 0.5 * (K_fcc(i, j - 1, k) + K_fcc(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_fcf(int i, int j, int k) const { return var ? 0.5 * (K_fcc(i, j, k - 1) + K_fcc(i, j, k)) : nu; }
+    __device__ __forceinline__ double K_cff(int i, int j, int k) const { return var ? 0.5 * (K_cfc(i, j, k - 1) + K_cfc(i, j, k)) : nu; }
     __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
     __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
     // ∂ at Center-in-d (f[+1] - f[0]) and at Face-in-d (f[0] - f[-1])
@@ -149,8 +151,8 @@ struct ClosureCtx {
 // V⁻¹ (δx(Ax flux) + δy(Ay flux) + δz(Az flux)) of the closure for field F at (i, j, k); coef = ν (momentum) or κ (tracer c)
 template <int F>
 __device__ __forceinline__ double closure_divergence(const DGrid &g, const FView &u, const FView &v, const FView &w, const FView &c,
-                                                     double coef, int i, int j, int k, const FView *K = nullptr) {
-    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT, K};
+                                                     double coef, int i, int j, int k, bool var, const FView &K) {
+    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT, var, K};
     const double dx_ = g.dx, dy_ = g.dy;
     double dx, dy, dz, vinv;
     if (F == F_U) {            // ∂ⱼ_τ₁ⱼ at fcc: Ax_qᶜᶜᶜ, Ay_qᶠᶠᶜ, Az_qᶠᶜᶠ
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u,
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = r.k0 + blockIdx.z;
     if (i > r.i1 || j > r.j1 || k > r.k1) return;
-    G.at(i, j, k) = (G.at(i, j, k) - closure_divergence<F>(g, u, v, w, c, coef, i, j, k, var ? &K : nullptr)) + 0.0;
+    G.at(i, j, k) = (G.at(i, j, k) - closure_divergence<F>(g, u, v, w, c, coef, i, j, k, var, K)) + 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -254,7 +256,7 @@ struct AmdCtx {
     }
 };
 
-__device__ __noinline__ double amd_viscosity(const AmdCtx &A, double Cnu, int i, int j, int k) {
+__device__ __forceinline__ double amd_viscosity(const AmdCtx &A, double Cnu, int i, int j, int k) {
     const double dxu = A.ddx_c(A.u, i, j, k), dyv = A.ddy_c(A.v, i, j, k), dzw = A.ddz_c(A.w, i, j, k);
     const double xv2 = A.Ixy<A_DXV2>(i, j, k), yu2 = A.Ixy<A_DYU2>(i, j, k), xw2 = A.Ixz<A_DXW2>(i, j, k), zu2 = A.Ixz<A_DZU2>(i, j, k),
                  yw2 = A.Iyz<A_DYW2>(i, j, k), zv2 = A.Iyz<A_DZV2>(i, j, k);
@@ -283,7 +285,7 @@ __device__ __noinline__ double amd_viscosity(const AmdCtx &A, double Cnu, int i,
     return fmax(0.0, nu);
 }
 
-__device__ __noinline__ double amd_diffusivity(const AmdCtx &A, double Ck, int i, int j, int k) {
+__device__ __forceinline__ double amd_diffusivity(const AmdCtx &A, double Ck, int i, int j, int k) {
     const double xc2 = A.Ix<A_DXC2>(i, j, k), yc2 = A.Iy<A_DYC2>(i, j, k), zc2 = A.Iz<A_DZC2>(i, j, k);
     const double sigma = (xc2 + yc2) + zc2;
     if (sigma == 0) return fmax(0.0, 0.0);
@@ -315,9 +317,11 @@ __global__ void __launch_bounds__(256) amd_diffusivities_kernel(DGrid g, AmdArgs
         const AmdCtx A{g, a.u, a.v, a.w, a.u};
         a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);
     }
+#pragma unroll 1
     for (int t = 0; t < a.ntr; ++t) {
-        const AmdCtx A{g, a.u, a.v, a.w, a.c[t]};
-        a.kappa_e[t].at(i, j, k) = amd_diffusivity(A, a.Ck[t], i, j, k);
+        const FView c = a.c[t], out = a.kappa_e[t];       // local copies (scalar loads): no address of a kernel argument is taken
+        const AmdCtx A{g, a.u, a.v, a.w, c};
+        out.at(i, j, k) = amd_diffusivity(A, a.Ck[t], i, j, k);
     }
 }
 
@@ -470,17 +474,17 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
     if (f == 0) {
         if (a.has_coriolis) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
         if (a.has_buoyancy) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
     } else if (f == 1) {
         if (a.has_coriolis) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
         if (a.has_buoyancy) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
     } else if (f == 2) {
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd ? &a.nu_e : nullptr)) + 0.0;
+        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
     } else {
         const double kap = a.kappa[f - 3];
         if (kap != 0.0 || a.amd)
-            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, a.amd ? &a.kappa_e[f - 3] : nullptr)) + 0.0;
+            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, a.amd, a.kappa_e[f - 3])) + 0.0;
     }
     if (a.any_flux) {
         // compute_x/y/z_bcs!: G[1] += flux A / V, G[N] -= flux A / V (x, then y, then z as the reference launches them)
