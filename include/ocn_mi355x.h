@@ -149,10 +149,12 @@ int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const double *u, const
                                          const int *range);
 /* compute_diffusivities!(diffusivity_fields, closure::AnisotropicMinimumDissipation, model; parameters = :xyz)
  * (turbulence_closure_implementations/anisotropic_minimum_dissipation.jl:152-216; Cb = nothing): νₑ and κₑ[t] over the interior from
- * fields with filled halos; the caller fills the halos of the results (ocn_fill_halo_regions, default conditions). */
+ * fields with filled halos; the caller fills the halos of the results (ocn_fill_halo_regions, default conditions).
+ * range: NULL = the interior (:xyz), or {i0, i1, j0, j1, k0, k1} reaching at most H - 1 cells into the halos -- an x-slab rank
+ * computes i = 0 and Nx + 1 from its exchanged velocity / tracer halos instead of exchanging νₑ, κₑ. */
 int ocn_compute_amd_diffusivities(ocn_grid_t grid, double Cnu, const double *Ckappa, const double *u, const double *v,
                                   const double *w, const double *const *tracers, int ntracers, double *nu_e,
-                                  double *const *kappa_e);
+                                  double *const *kappa_e, const int *range);
 
 /* ---------------------------------------------------------------- RK3 (TimeSteppers/runge_kutta_3.jl) ----------- */
 /* rk3_substep_field! (:212-226), launched with exclude_periphery (:187). has_zeta == 0 selects the first-stage

@@ -60,7 +60,7 @@ SYMBOLS = {
     "ocn_model_set_closure": (C.c_int, [_vp, C.c_double, _dp]),
     "ocn_model_set_amd": (C.c_int, [_vp, C.c_double, _dp]),
     "ocn_compute_closure_tendencies_field": (C.c_int, [_vp, _vp, _vp, _vp, _pp, C.c_int, _vp, _pp, _vp, _vp, _vp, _pp, _ip]),
-    "ocn_compute_amd_diffusivities": (C.c_int, [_vp, C.c_double, _dp, _vp, _vp, _vp, _pp, C.c_int, _vp, _pp]),
+    "ocn_compute_amd_diffusivities": (C.c_int, [_vp, C.c_double, _dp, _vp, _vp, _vp, _pp, C.c_int, _vp, _pp, _ip]),
     "ocn_ab2_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_double]),
     "ocn_model_time_step_ab2": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int]),
     "ocn_update_hydrostatic_pressure": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp]),

@@ -601,11 +601,22 @@ extern "C" int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const doubl
 }
 
 static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, const double *u, const double *v, const double *w,
-                             const double *const *tr, int ntr, double *nu_e, double *const *kappa_e) {
+                             const double *const *tr, int ntr, double *nu_e, double *const *kappa_e, const int *range = nullptr) {
     if (g.tx == OCN_FLAT || g.ty == OCN_FLAT || g.tz == OCN_FLAT)
         return fail(OCN_ENOTSUP, "AnisotropicMinimumDissipation needs a grid without Flat directions");
     AmdArgs a;
     a.ntr = ntr; a.Cnu = Cnu;
+    a.r = Range6{1, g.Nx, 1, g.Ny, 1, g.Nz};
+    if (range) {
+        // the stencils reach one cell further: the range may extend into the halos by at most H - 1
+        const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz};
+        for (int d = 0; d < 3; ++d)
+            if (range[2 * d] < 2 - H[d] || range[2 * d + 1] > N[d] + H[d] - 1)
+                return fail(OCN_EINVAL, "range [%d, %d] along dimension %d leaves no halo for the stencil", range[2 * d], range[2 * d + 1], d);
+        a.r = Range6{range[0], range[1], range[2], range[3], range[4], range[5]};
+    }
+    const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
     a.u = make_view(g, u, LOC_U); a.v = make_view(g, v, LOC_V); a.w = make_view(g, w, LOC_W);
     a.nu_e = make_view(g, nu_e, LOC_C);
     for (int t = 0; t < ntr; ++t) {
@@ -613,18 +624,18 @@ static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, c
         a.kappa_e[t] = make_view(g, kappa_e[t], LOC_C);
         a.Ck[t] = Ckappa[t];
     }
-    hipLaunchKernelGGL(amd_diffusivities_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, a);
+    hipLaunchKernelGGL(amd_diffusivities_kernel, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, a);
     KERNEL_CHECK();
     return OCN_OK;
 }
 
 extern "C" int ocn_compute_amd_diffusivities(ocn_grid_t grid, double Cnu, const double *Ckappa, const double *u, const double *v,
                                              const double *w, const double *const *tracers, int ntracers, double *nu_e,
-                                             double *const *kappa_e) {
+                                             double *const *kappa_e, const int *range) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !nu_e || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 || (ntracers > 0 && (!tracers || !kappa_e || !Ckappa)))
         return fail(OCN_EINVAL, "invalid argument");
-    return amd_diffusivities(grid->d, Cnu, Ckappa, u, v, w, tracers, ntracers, nu_e, kappa_e);
+    return amd_diffusivities(grid->d, Cnu, Ckappa, u, v, w, tracers, ntracers, nu_e, kappa_e, range);
 }
 
 extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double *const *fields, int ntracers, double *const *Gn,

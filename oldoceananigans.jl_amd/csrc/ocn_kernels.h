@@ -304,15 +304,16 @@ __device__ __forceinline__ double amd_diffusivity(const AmdCtx &A, double Ck, in
 
 struct AmdArgs {
     int ntr;
+    Range6 r;
     FView u, v, w, c[OCN_MAX_FIELDS], nu_e, kappa_e[OCN_MAX_FIELDS];
     double Cnu, Ck[OCN_MAX_FIELDS];
 };
 
 __global__ void __launch_bounds__(256) amd_diffusivities_kernel(DGrid g, AmdArgs a) {
-    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = 1 + blockIdx.z;
-    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const int i = a.r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = a.r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = a.r.k0 + blockIdx.z;
+    if (i > a.r.i1 || j > a.r.j1 || k > a.r.k1) return;
     {
         const AmdCtx A{g, a.u, a.v, a.w, a.u};
         a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);

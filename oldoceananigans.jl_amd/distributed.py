@@ -22,6 +22,7 @@ import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so i
 
 from . import _lib
 from .advection import WENO
+from .closures import AnisotropicMinimumDissipation
 from .fields import Field, _loc_array, _ptr_array
 from .grids import Bounded, Center, Face, FullyConnected, Periodic, RectilinearGrid, _regular_coordinate
 
@@ -364,8 +365,32 @@ class DeviceBackend:
             kernels.add_fplane_coriolis(self.grid.local, self.coriolis.f, self.U[0], self.U[1], self.Gn[0], self.Gn[1], kernel_parameters=rng)
         if getattr(self, "buoyancy", None) is not None:
             kernels.add_hydrostatic_pressure_gradient(self.grid.local, self.pHY, self.Gn[0], self.Gn[1], kernel_parameters=rng)
-        if getattr(self, "closure", None) is not None:
-            kernels.compute_closure_tendencies(self.grid.local, self.U, self.Gn, self.closure, self.tracer_names, kernel_parameters=rng)
+        closure = getattr(self, "closure", None)
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            kernels.compute_closure_tendencies_field(self.grid.local, self.U, self.Gn, self.nu_e, self.kappa_e, kernel_parameters=rng)
+        elif closure is not None:
+            kernels.compute_closure_tendencies(self.grid.local, self.U, self.Gn, closure, self.tracer_names, kernel_parameters=rng)
+
+    def set_closure(self, closure, tracer_names):
+        self.closure, self.tracer_names = closure, tuple(tracer_names)
+        if isinstance(closure, AnisotropicMinimumDissipation):
+            g = self.grid.local
+            self.nu_e = Field((Center,) * 3, g)
+            self.kappa_e = [Field((Center,) * 3, g) for _ in self.tracer_names]
+
+    def compute_diffusivities(self):
+        """compute_diffusivities! + fill_halo_regions!(diffusivity_fields; only_local_halos = true). The reference fills the x halos of
+        νₑ, κₑ of a serial Periodic grid from the opposite side, i.e. with the closure evaluated there; an x-slab evaluates it at
+        i = 0 and Nx + 1 itself from the exchanged velocity / tracer halos -- the same numbers, no extra exchange."""
+        if not isinstance(getattr(self, "closure", None), AnisotropicMinimumDissipation):
+            return
+        from . import kernels
+        from .fields import fill_halo_regions as fill
+        g = self.grid.local
+        ext = 1 if self.ctx.world > 1 else 0
+        kernels.compute_amd_diffusivities(g, self.closure, self.tracer_names, self.U, self.nu_e, self.kappa_e,
+                                          kernel_parameters=(1 - ext, g.Nx + ext, 1, g.Ny, 1, g.Nz))
+        fill([self.nu_e] + self.kappa_e, True)
 
     def profile_read(self):
         """(total ms of the event-timed tendency launches, number of tendency EVALUATIONS) since the last read"""
@@ -441,7 +466,10 @@ class DistributedNonhydrostaticModel:
         # extra tile columns of the fused kernel, more than the exposed exchange; True / False force it
         self.async_halos = None
         if closure is not None:
-            self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
+            if hasattr(self.backend, "set_closure"):
+                self.backend.set_closure(closure, self.tracer_names)
+            else:
+                self.backend.closure, self.backend.tracer_names = closure, self.tracer_names
         if coriolis is not None:
             self.backend.coriolis = coriolis
         if buoyancy is not None:
@@ -540,9 +568,12 @@ def update_state(model, compute_tendencies=True):
         b.n_evals += 1
     # with buoyancy, pHY′ in the x-halo columns needs the exchanged tracers: fill, integrate, then evaluate (no overlap)
     overlap = model.async_halos if model.async_halos is not None else g.Nx >= 3 * 64
+    # eddy diffusivities and pHY′ in the x-halo columns need the exchanged fields: fill, evaluate them, then the tendencies (no overlap)
     if (not compute_tendencies or ctx.world == 1 or not overlap or g.Nx <= 2 * g.Hx or
-            getattr(b, "buoyancy", None) is not None):
+            getattr(b, "buoyancy", None) is not None or isinstance(getattr(b, "closure", None), AnisotropicMinimumDissipation)):
         fill_halo_regions(model, b.U, fill_open_bcs=False)
+        if hasattr(b, "compute_diffusivities"):
+            b.compute_diffusivities()                     # compute_auxiliaries! (update_nonhydrostatic_model_state.jl:58-69)
         if hasattr(b, "update_hydrostatic_pressure"):
             b.update_hydrostatic_pressure()           # compute_auxiliaries! (update_nonhydrostatic_model_state.jl:58-69)
         if compute_tendencies:

@@ -50,14 +50,14 @@ def compute_closure_tendencies(grid, fields, Gn, closure, tracer_names, kernel_p
         Gn[0].data, Gn[1].data, Gn[2].data, _ptr_array(gc) if gc else None, _range(kernel_parameters)))
 
 
-def compute_amd_diffusivities(grid, closure, tracer_names, fields, νₑ, κₑ):
+def compute_amd_diffusivities(grid, closure, tracer_names, fields, νₑ, κₑ, kernel_parameters=None):
     """compute_diffusivities!(…, closure::AnisotropicMinimumDissipation, …) over the interior; fields = u, v, w, tracers... with filled
     halos; fill the halos of νₑ, κₑ afterwards (fill_halo_regions)"""
     karr, kp = closure.Ckappa_array(tracer_names)
     tr = fields[3:]
     _lib.check(_lib.lib().ocn_compute_amd_diffusivities(
         grid.handle, closure.Cν, kp, fields[0].data, fields[1].data, fields[2].data, _ptr_array(tr) if tr else None, len(tr),
-        νₑ.data, _ptr_array(κₑ) if κₑ else None))
+        νₑ.data, _ptr_array(κₑ) if κₑ else None, _range(kernel_parameters)))
 
 
 def compute_closure_tendencies_field(grid, fields, Gn, νₑ, κₑ, kernel_parameters=None):

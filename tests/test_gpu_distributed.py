@@ -37,6 +37,8 @@ def _tracers_and_buoyancy(ocn, zkind):
 
 
 def _closure(ocn, zkind):
+    if zkind == "amd":
+        return ocn.AnisotropicMinimumDissipation(C=1 / 3, Cκ={"T": 1 / 3, "S": 1 / 12})
     return ocn.ScalarDiffusivity(ν=2e-3, κ={"T": 1e-3, "S": 5e-4}) if zkind == "bounded" else None
 
 
@@ -85,6 +87,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
     (4, True, (36, 12, 10), "periodic"),       # odd local Nx (9): padded column pair; Ny/2+1 = 7 modes over 4 ranks
     (2, True, (384, 8, 8), "periodic"),        # local Nx = 192: buffer strips one 64-lane tile wide (buffer_strip_width)
     (2, True, (32, 16, 8), "bounded"),         # z Bounded: distributed Fourier-tridiagonal solver
+    (4, True, (32, 12, 10), "amd"),            # stretched z + AnisotropicMinimumDissipation: νₑ, κₑ evaluated in the x-halo columns
     (4, True, (28, 8, 12), "stretched"),       # stretched z, odd local Nx (7)
 ])
 def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_halos, size, zkind):
