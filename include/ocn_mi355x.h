@@ -63,6 +63,9 @@ void *ocn_stream(void);                                       /* the hipStream_t
  * through torch.distributed are stream-ordered with the kernels; the reference instead calls sync_device! before every
  * MPI call, halo_communication.jl:181) */
 int ocn_set_stream(void *hip_stream);
+/* back to a library-owned stream (the state after ocn_init). Time-step graphs (ocn_model_time_step) need it: a borrowed stream
+ * may be the legacy default stream, which cannot be captured. */
+int ocn_own_stream(void);
 
 /* ---------------------------------------------------------------- grid (src/Grids/rectilinear_grid.jl:3-25) ------ */
 /* N, H, topo, L: per dimension. dx, dy: regular spacings. dzc / dzf: HOST arrays of Δzᵃᵃᶜ / Δzᵃᵃᶠ for index

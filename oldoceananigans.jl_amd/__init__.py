@@ -5,7 +5,7 @@ libocn_mi355x.so (include/ocn_mi355x.h). Import as `import oldoceananigans_jl_am
 from . import _lib
 from ._lib import OcnError, build
 from .advection import WENO
-from .architectures import GPU, architecture, set_option, synchronize
+from .architectures import GPU, architecture, own_stream, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy

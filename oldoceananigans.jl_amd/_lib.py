@@ -46,6 +46,7 @@ SYMBOLS = {
     "ocn_memset_zero": (C.c_int, [_vp, C.c_size_t]),
     "ocn_stream": (_vp, []),
     "ocn_set_stream": (C.c_int, [_vp]),
+    "ocn_own_stream": (C.c_int, []),
     "ocn_pack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos": (C.c_int, [_vp, _pp, _vp, C.c_int, _vp, _vp]),
     "ocn_hasnan": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int)]),

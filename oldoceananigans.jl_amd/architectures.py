@@ -29,3 +29,8 @@ def synchronize(arch=None):
 def set_option(key, value):
     """library-wide tuning knobs (see include/ocn_mi355x.h: ocn_set_option)"""
     _lib.check(_lib.lib().ocn_set_option(key.encode(), int(value)))
+
+
+def own_stream():
+    """run on a stream created and owned by the library again (after distributed.init_process_group pointed it at torch's)"""
+    _lib.check(_lib.lib().ocn_own_stream())

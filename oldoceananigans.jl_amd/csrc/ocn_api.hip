@@ -18,6 +18,7 @@
 // runtime state / error handling
 // ---------------------------------------------------------------------------------------------------------------------
 static thread_local char g_err[512] = "";
+static uint64_t g_epoch = 1;             // bumped by every library-wide option / stream change (invalidates captured time-step graphs)
 static hipStream_t g_stream = nullptr;   // may legitimately be the null (legacy default) stream after ocn_set_stream
 static int g_device = -1;
 static bool g_initialized = false;
@@ -87,6 +88,18 @@ extern "C" int ocn_set_stream(void *stream) {
     if (g_stream && g_stream_owned) { HIP_TRY(hipStreamSynchronize(g_stream)); HIP_TRY(hipStreamDestroy(g_stream)); }
     g_stream = (hipStream_t)stream;
     g_stream_owned = false;
+    g_epoch += 1;
+    return OCN_OK;
+}
+
+// back to a stream created and owned by the library (the state after ocn_init): waits for the borrowed stream first
+extern "C" int ocn_own_stream(void) {
+    if (!g_initialized) return fail(OCN_ESTATE, "ocn_init() has not been called");
+    if (g_stream_owned) return OCN_OK;
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_stream_owned = true;
+    g_epoch += 1;
     return OCN_OK;
 }
 
@@ -1634,6 +1647,16 @@ struct ocn_model_s {
     double *U2[OCN_MAX_FIELDS];
     int fuse_substep = 1;
     int fused_epilogue = 1;                 // Coriolis + hydrostatic gradient + closure (+ substep) as one launch
+    // One RK3 time-step is ~50 dependent launches. Option use_graph = 1 captures the step once per (Δt, configuration) into a
+    // hipGraph and replays it: all pointer swaps of a step cancel out, kernel arguments depend on Δt only; `epoch` is bumped by
+    // everything that changes what a step launches. OFF by default: measured on MI355X (tools/time_small.py) replay and plain
+    // launches take the same time at every size (16^3: 0.436 vs 0.441 ms/step, 256^3: 7.58 vs 7.51) -- small grids are bound by
+    // the ~9 us GPU-side latency between DEPENDENT dispatches, which a graph does not remove; only fewer kernels would.
+    int use_graph = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    double graph_dt = 0.0;
+    uint64_t graph_epoch = 0, epoch = 1;
+    int graph_replays = 0, graph_captures = 0, graph_failures = 0;
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
     bool any_bc = false, any_flux_bc = false;
@@ -1666,6 +1689,7 @@ struct ocn_model_s {
 extern "C" int ocn_model_destroy(ocn_model_t m) {
     if (!m) return OCN_OK;
     for (auto &e : m->events) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (m->graph_exec) hipGraphExecDestroy(m->graph_exec);
     for (int f = 0; f < m->nf; ++f) { hipFree(m->U[f]); hipFree(m->U2[f]); hipFree(m->Gn[f]); hipFree(m->Gm[f]); }
     hipFree(m->pHY);
     hipFree(m->nu_e);
@@ -1758,6 +1782,7 @@ extern "C" int ocn_model_field(ocn_model_t m, const char *name, double **ptr, in
 // library-wide tuning knobs (no reference equivalent; defaults are the tuned values)
 extern "C" int ocn_set_option(const char *key, int value) {
     if (!key) return fail(OCN_EINVAL, "NULL argument");
+    g_epoch += 1;
     if (!strcmp(key, "real_fft")) { g_real_fft = value; return OCN_OK; }
     if (!strcmp(key, "c2r_strided")) { g_c2r_strided = value; return OCN_OK; }
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
@@ -1773,6 +1798,8 @@ extern "C" int ocn_set_option(const char *key, int value) {
 
 extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
+    m->epoch += 1;
+    if (!strcmp(key, "use_graph")) { m->use_graph = value; return OCN_OK; }
     if (!strcmp(key, "tendency_impl")) { m->tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "swap_tendencies")) { m->swap_tendencies = value; return OCN_OK; }
     if (!strcmp(key, "fuse_substep")) { m->fuse_substep = value; return OCN_OK; }
@@ -1835,6 +1862,10 @@ extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) 
     if (!m || !key || !value) return fail(OCN_EINVAL, "NULL argument");
     if (!strcmp(key, "tendency_impl")) { *value = m->tendency_impl; return OCN_OK; }
     if (!strcmp(key, "swap_tendencies")) { *value = m->swap_tendencies; return OCN_OK; }
+    if (!strcmp(key, "use_graph")) { *value = m->use_graph; return OCN_OK; }
+    if (!strcmp(key, "graph_replays")) { *value = m->graph_replays; return OCN_OK; }
+    if (!strcmp(key, "graph_captures")) { *value = m->graph_captures; return OCN_OK; }
+    if (!strcmp(key, "graph_failures")) { *value = m->graph_failures; return OCN_OK; }
     if (!strcmp(key, "fuse_substep")) { *value = m->fuse_substep; return OCN_OK; }
     if (!strcmp(key, "fuse_substep_active")) { *value = can_fuse_substep(m) ? 1 : 0; return OCN_OK; }
     if (!strcmp(key, "fused_tendency_active")) { *value = fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl) ? 1 : 0; return OCN_OK; }
@@ -1920,6 +1951,7 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
 }
 
 extern "C" int ocn_model_set_buoyancy(ocn_model_t m, int kind, int b_or_T_index, int S_index, double grav, double alpha, double beta) {
+    if (m) m->epoch += 1;
     NEED_INIT();
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     if (kind < 0 || kind > 2) return fail(OCN_EINVAL, "buoyancy kind must be 0 (nothing), 1 (BuoyancyTracer) or 2 (linear SeawaterBuoyancy)");
@@ -1938,6 +1970,7 @@ extern "C" int ocn_model_set_buoyancy(ocn_model_t m, int kind, int b_or_T_index,
 }
 
 extern "C" int ocn_model_set_coriolis(ocn_model_t m, int enabled, double f) {
+    if (m) m->epoch += 1;
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     m->has_coriolis = enabled != 0;
     m->fcor = f;
@@ -1945,6 +1978,7 @@ extern "C" int ocn_model_set_coriolis(ocn_model_t m, int enabled, double f) {
 }
 
 extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kappa) {
+    if (m) m->epoch += 1;
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     if (nu < 0) return fail(OCN_EINVAL, "viscosity must be non-negative");
     m->nu = nu;
@@ -1959,6 +1993,7 @@ extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kap
 
 // closure = AnisotropicMinimumDissipation(Cν = Cnu, Cκ = Ckappa[tracer]; Cb = nothing); replaces a ScalarDiffusivity
 extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa) {
+    if (m) m->epoch += 1;
     NEED_INIT();
     if (!m || (m->ntr > 0 && !Ckappa)) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = m->grid->d;
@@ -1983,6 +2018,7 @@ extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa
 }
 
 extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name, int side, int kind, double value) {
+    if (m) m->epoch += 1;
     if (!m || !name) return fail(OCN_EINVAL, "NULL argument");
     int f = -1;
     if (!strcmp(name, "u")) f = 0;
@@ -2049,9 +2085,7 @@ static int cache_previous_tendencies(ocn_model_s *m) {
 }
 
 // time_step!(model::AbstractModel{<:RungeKutta3TimeStepper}, Δt) (TimeSteppers/runge_kutta_3.jl:93-170)
-extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
-    NEED_INIT();
-    if (!m) return fail(OCN_EINVAL, "NULL argument");
+static int rk3_time_step(ocn_model_s *m, double dt) {
     const DGrid &g = m->grid->d;
     int rc;
     if (m->iteration == 0 && (rc = update_state(m, true))) return rc;
@@ -2084,6 +2118,65 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
             substep_done = true;
         } else if ((rc = update_state(m, true))) return rc;
     }
+    return OCN_OK;
+}
+
+struct ClockState { double time, last_dt, last_stage_dt; int64_t iteration; int stage; };
+static ClockState save_clock(const ocn_model_s *m) { return {m->time, m->last_dt, m->last_stage_dt, m->iteration, m->stage}; }
+static void restore_clock(ocn_model_s *m, const ClockState &c) {
+    m->time = c.time; m->last_dt = c.last_dt; m->last_stage_dt = c.last_stage_dt; m->iteration = c.iteration; m->stage = c.stage;
+}
+
+extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    // graphs: not on the first step (it also evaluates the initial tendencies), not while tendency launches are being timed, and only
+    // on a stream the library owns (a borrowed stream may be the legacy default stream, which cannot be captured)
+    if (!m->use_graph || m->profile || m->iteration == 0 || !g_stream_owned) return rk3_time_step(m, dt);
+    if (m->graph_exec && m->graph_dt == dt && m->graph_epoch == m->epoch * 1000003ull + g_epoch) {
+        hipError_t e = hipGraphLaunch(m->graph_exec, g_stream);
+        if (e != hipSuccess) return fail((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
+        // the host side of the step: the clock (tick! x 3, runge_kutta_3.jl:120-168)
+        const double dt1 = dt * OCN_RK3_G1, dt2 = dt * (OCN_RK3_G2 + OCN_RK3_Z2), dt3 = dt * (OCN_RK3_G3 + OCN_RK3_Z3);
+        const double tn1 = m->time + dt;
+        tick(m, dt1, true);
+        tick(m, dt2, true);
+        const double corrected = tn1 - m->time;
+        tick(m, dt3, false);
+        m->last_stage_dt = corrected;
+        m->last_dt = dt;
+        m->graph_replays += 1;
+        return OCN_OK;
+    }
+    if (m->graph_failures >= 2) return rk3_time_step(m, dt);          // capture does not work here: stop trying
+    if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+    const ClockState before = save_clock(m);
+    double *U0[OCN_MAX_FIELDS], *G0[OCN_MAX_FIELDS];
+    for (int f = 0; f < m->nf; ++f) { U0[f] = m->U[f]; G0[f] = m->Gn[f]; }
+    hipGraph_t graph = nullptr;
+    hipError_t e = hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) { (void)hipGetLastError(); m->graph_failures += 1; return rk3_time_step(m, dt); }
+    int rc = rk3_time_step(m, dt);
+    e = hipStreamEndCapture(g_stream, &graph);
+    bool same = true;                           // a step must leave every pointer where it found it, or a replay would be wrong
+    for (int f = 0; f < m->nf; ++f) same = same && U0[f] == m->U[f] && G0[f] == m->Gn[f];
+    if (rc == OCN_OK && e == hipSuccess && graph && same) e = hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0);
+    if (graph) hipGraphDestroy(graph);
+    if (rc != OCN_OK || e != hipSuccess || !m->graph_exec || !same) {
+        // nothing ran on the GPU during the capture: undo the host side and take the step the ordinary way
+        (void)hipGetLastError();
+        if (m->graph_exec) { hipGraphExecDestroy(m->graph_exec); m->graph_exec = nullptr; }
+        restore_clock(m, before);
+        for (int f = 0; f < m->nf; ++f) {
+            if (m->U[f] != U0[f]) std::swap(m->U[f], m->U2[f]);
+            if (m->Gn[f] != G0[f]) std::swap(m->Gn[f], m->Gm[f]);
+        }
+        m->graph_failures += 1;
+        return rk3_time_step(m, dt);
+    }
+    m->graph_dt = dt; m->graph_epoch = m->epoch * 1000003ull + g_epoch; m->graph_captures += 1;
+    e = hipGraphLaunch(m->graph_exec, g_stream);            // the captured step itself (its host side already happened above)
+    if (e != hipSuccess) return fail((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
     return OCN_OK;
 }
 

@@ -607,3 +607,42 @@ def test_anisotropic_minimum_dissipation_matches_oracle(ocn, oracle, arch, topol
         m_cpu.time_step(dt)
     for name, a, b in field_pairs(m_gpu, m_cpu):
         assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (name, rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]))
+
+
+@pytest.mark.parametrize("case", ["ppp", "ppb_physics", "bbb"])
+def test_time_step_graph_replay_is_bit_identical(ocn, arch, case):
+    """after the first step an RK3 time-step is captured into a hipGraph per (Δt, configuration) and replayed: same bits, same clock as
+    issuing the launches one by one; a new Δt or a changed option re-captures"""
+    ocn.own_stream()        # the distributed tests of this process may have pointed the library at torch's (default) stream
+    physics = {}
+    if case == "ppp":
+        grid = ocn.RectilinearGrid(arch, size=(16, 12, 8), extent=(1, 1, 1))
+    elif case == "bbb":
+        grid = ocn.RectilinearGrid(arch, size=(12, 10, 8), extent=(1, 1, 1), topology=(ocn.Bounded,) * 3)
+    else:
+        grid = ocn.RectilinearGrid(arch, size=(16, 16, 12), x=(0, 1), y=(0, 1), z=tanh_faces(12), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        F = ocn.FieldBoundaryConditions
+        physics = dict(closure=ocn.AnisotropicMinimumDissipation(), buoyancy=ocn.SeawaterBuoyancy(), coriolis=ocn.FPlane(f=0.3),
+                       boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-3)), "T": F(bottom=ocn.GradientBoundaryCondition(0.1))})
+    models = []
+    for use_graph in (0, 1):
+        m = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), **physics)
+        m.set_option("use_graph", use_graph)
+        flds = m.fields()
+        ocn.set_model(m, **smooth_state({n: grid.nodes(f.loc) for n, f in flds.items()}, 77))
+        models.append(m)
+    plain, graphed = models
+    dts = [1e-3] * 5 + [7e-4] * 3
+    for n, dt in enumerate(dts):
+        for m in models:
+            ocn.time_step(m, dt)
+        if n == 5:
+            graphed.set_option("fused_epilogue", 1)          # any option change invalidates the captured graph
+    assert graphed.get_option("graph_failures") == 0 and plain.get_option("graph_captures") == 0
+    assert graphed.get_option("graph_captures") == 3 and graphed.get_option("graph_replays") == len(dts) - 1 - 3
+    assert (plain.clock.time, plain.clock.iteration, plain.clock.stage, plain.clock.last_Δt, plain.clock.last_stage_Δt) == \
+           (graphed.clock.time, graphed.clock.iteration, graphed.clock.stage, graphed.clock.last_Δt, graphed.clock.last_stage_Δt)
+    for name in plain.fields():
+        assert np.array_equal(plain.fields()[name].parent(), graphed.fields()[name].parent()), name
+        assert np.array_equal(plain.tendency(name).parent(), graphed.tendency(name).parent()), name
+    assert np.array_equal(plain.pressures.pNHS.parent(), graphed.pressures.pNHS.parent())
