@@ -134,7 +134,7 @@ def main():
                          "SeawaterBuoyancy (hydrostatic pressure anomaly), surface Flux / bottom Gradient boundary conditions; "
                          "ppb_amd: the physics of BASELINE.json configs[4] (ocean_wind_mixing_and_convection) on that grid -- "
                          "AnisotropicMinimumDissipation, linear SeawaterBuoyancy, wind-stress / heat-flux / bottom-gradient conditions "
-                         "(constant values; the example's S-dependent evaporation flux is replaced by a constant)")
+                         "and the example's S-dependent evaporation flux J = -rate S")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -184,7 +184,8 @@ def main():
                                buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
                                boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
                                                     "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
-                                                    "S": F(top=ocn.FluxBoundaryCondition(-2e-8))})
+                                                    "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-1e-3 / 3600.0),
+                                                                                         field_dependencies="S"))})
         else:
             grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
         model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"), **physics)
@@ -265,7 +266,7 @@ def main():
                     ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
                      if args.workload == "ppb_physics" else
                      "; + AnisotropicMinimumDissipation, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (the physics of "
-                     "BASELINE.json configs[4]; constant surface fluxes)" if args.workload == "ppb_amd" else "")),
+                     "BASELINE.json configs[4], evaporation flux -rate S included)" if args.workload == "ppb_amd" else "")),
                    "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}): RCCL send/recv halos, substructured x solve "
                                                                      "(one all-gather of 2 complex per mode per solve)",
                    "dt": dt, "max_abs_divergence_after_run": div,

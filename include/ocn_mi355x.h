@@ -100,6 +100,12 @@ int ocn_fill_halo_regions_bcs(ocn_grid_t grid, double *const *fields, const int 
 /* compute_x_bcs! / compute_y_bcs! / compute_z_bcs! (BoundaryConditions/compute_flux_bcs.jl:12-163), called by
  * compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184): G[1] += flux A / V, G[N] -= flux A / V */
 int ocn_compute_flux_bcs(ocn_grid_t grid, double *G, const int loc[3], const ocn_bc_t bcs[6]);
+/* One side (0 west .. 5 top) of a field-dependent Flux condition of the linear family, flux = a + b dep[i, j, k_boundary]: what
+ * getbc(::ContinuousBoundaryFunction) (BoundaryConditions/continuous_boundary_function.jl:128-161) evaluates for
+ * func(x, y, t, φ, p) = a + b φ with field_dependencies = :φ when φ sits at the location `loc` of the field that carries the condition
+ * (identity interpolation). examples/ocean_wind_mixing_and_convection.jl:125-136: a = 0, b = -evaporation_rate, φ = S. General
+ * callables cannot cross a C ABI; this family covers relaxation / evaporation / linear-drag conditions. */
+int ocn_compute_linear_flux_bc(ocn_grid_t grid, double *G, const int loc[3], int side, double a, double b, const double *dep);
 
 /* ---------------------------------------------------------------- tendencies ------------------------------------ */
 /* compute_Gu!/Gv!/Gw!/Gc! (Models/NonhydrostaticModels/compute_nonhydrostatic_tendencies.jl:138-163) for
@@ -302,6 +308,8 @@ int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
  * computes the model fields "nu_e", "kappa_e0", ... and fills their halos before the tendencies. */
 int ocn_model_set_amd(ocn_model_t model, double Cnu, const double *Ckappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
+/* name.side = FluxBoundaryCondition((ξ, η, t, φ, p) -> a + b φ, field_dependencies = dep); dep at the location of `name` */
+int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, double a, double b, const char *dep);
 /* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
  * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */
 int ocn_set_option(const char *key, int value);

@@ -7,7 +7,7 @@ from ._lib import OcnError, build
 from .advection import WENO
 from .architectures import GPU, architecture, own_stream, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
-                                  GradientBoundaryCondition, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
+                                  GradientBoundaryCondition, LinearFieldFlux, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
 from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)

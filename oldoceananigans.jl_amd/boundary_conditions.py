@@ -9,22 +9,41 @@ SIDES = ("west", "east", "south", "north", "bottom", "top")
 KINDS = {"Default": 0, "Flux": 1, "Value": 2, "Gradient": 3, "Open": 4}
 
 
-class BoundaryCondition:
-    """BoundaryCondition(classification, condition::Number)"""
+class LinearFieldFlux:
+    """the boundary function (ξ, η, t, φ, p) -> a + b φ of one field dependency φ: the family of field-dependent Flux conditions that
+    crosses the C ABI (ocn_model_set_linear_flux_bc). Jˢ(x, y, t, S, rate) = -rate S of examples/ocean_wind_mixing_and_convection.jl:
+    125 is LinearFieldFlux(b=-rate)."""
 
-    def __init__(self, classification, condition=0.0):
+    def __init__(self, a=0.0, b=0.0):
+        self.a, self.b = float(a), float(b)
+
+
+class BoundaryCondition:
+    """BoundaryCondition(classification, condition::Number); Flux conditions also take a LinearFieldFlux with field_dependencies"""
+
+    def __init__(self, classification, condition=0.0, field_dependencies=None):
         if classification not in KINDS:
             raise ValueError(f"unknown boundary condition classification {classification}")
+        self.linear = None
+        if isinstance(condition, LinearFieldFlux):
+            deps = (field_dependencies,) if isinstance(field_dependencies, str) else tuple(field_dependencies or ())
+            if classification != "Flux" or len(deps) != 1:
+                raise NotImplementedError("a LinearFieldFlux is a Flux condition with exactly one field dependency")
+            self.linear = (condition.a, condition.b, str(deps[0]).lstrip(":"))
+            condition = 0.0
         if callable(condition) or not isinstance(condition, (int, float)):
-            raise NotImplementedError("only constant (Number) boundary conditions are on the accelerated path")
+            raise NotImplementedError("only constant (Number) boundary conditions and LinearFieldFlux are on the accelerated path")
         self.classification, self.condition = classification, float(condition)
 
     def __repr__(self):
+        if self.linear:
+            return f"FluxBoundaryCondition: {self.linear[0]} + {self.linear[1]} * {self.linear[2]}"
         return f"{self.classification}BoundaryCondition: {self.condition}"
 
 
-def FluxBoundaryCondition(value):
-    return BoundaryCondition("Flux", value)
+def FluxBoundaryCondition(value, field_dependencies=None, parameters=None):
+    """FluxBoundaryCondition(Number) | FluxBoundaryCondition(LinearFieldFlux(a, b), field_dependencies = :φ)"""
+    return BoundaryCondition("Flux", value, field_dependencies)
 
 
 def ValueBoundaryCondition(value):

@@ -419,6 +419,27 @@ static int compute_flux_bcs(const DGrid &g, double *G, const int loc[3], const o
     return OCN_OK;
 }
 
+static int compute_linear_flux_bc(const DGrid &g, double *G, const int loc[3], int side6, double a, double b, const double *dep) {
+    const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
+    const int d = side6 / 2, side = side6 % 2;
+    if (T[d] != OCN_BOUNDED) return fail(OCN_EINVAL, "a Flux condition needs a Bounded direction");
+    if (loc[d] != OCN_CENTER) return fail(OCN_EINVAL, "a Flux condition needs a field at Center along the boundary direction");
+    const FView vG = make_view(g, G, loc), vP = make_view(g, dep, loc);
+    const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
+    const int nb = (int)(((long)Na * Nb + 255) / 256);
+    if (d == 0) hipLaunchKernelGGL(linear_flux_bc_kernel<0>, dim3(nb), dim3(256), 0, g_stream, g, vG, vP, Na, Nb, N[0], loc[2], side, a, b);
+    if (d == 1) hipLaunchKernelGGL(linear_flux_bc_kernel<1>, dim3(nb), dim3(256), 0, g_stream, g, vG, vP, Na, Nb, N[1], loc[2], side, a, b);
+    if (d == 2) hipLaunchKernelGGL(linear_flux_bc_kernel<2>, dim3(nb), dim3(256), 0, g_stream, g, vG, vP, Na, Nb, N[2], loc[2], side, a, b);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+extern "C" int ocn_compute_linear_flux_bc(ocn_grid_t grid, double *G, const int loc[3], int side, double a, double b, const double *dep) {
+    NEED_INIT();
+    if (!grid || !G || !loc || !dep || side < 0 || side > 5) return fail(OCN_EINVAL, "invalid argument");
+    return compute_linear_flux_bc(grid->d, G, loc, side, a, b, dep);
+}
+
 extern "C" int ocn_compute_flux_bcs(ocn_grid_t grid, double *G, const int loc[3], const ocn_bc_t bcs[6]) {
     NEED_INIT();
     if (!grid || !G || !loc || !bcs) return fail(OCN_EINVAL, "NULL argument");
@@ -1660,6 +1681,8 @@ struct ocn_model_s {
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
     bool any_bc = false, any_flux_bc = false;
+    struct LinBC { bool on = false; int dep = 0; double a = 0.0, b = 0.0; } lin[OCN_MAX_FIELDS][6];   // linear field-dependent Flux
+    bool any_linear_flux = false;
     bool has_closure = false;               // closure = ScalarDiffusivity(ν, κ)
     double nu = 0.0, kappa[OCN_MAX_FIELDS] = {};
     bool has_amd = false;                   // closure = AnisotropicMinimumDissipation(Cν, Cκ)
@@ -1853,7 +1876,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
 static bool can_fuse_substep(const ocn_model_s *m) {
     // without extra physics the substep rides in the fused advection kernel; with Coriolis / buoyancy / closure terms it rides in
     // the epilogue pass that completes the tendencies (any advection path); a valued Flux condition is added after both
-    if (!m->fuse_substep || !m->swap_tendencies) return false;
+    if (!m->fuse_substep || !m->swap_tendencies || m->any_linear_flux) return false;   // linear Flux terms are added after the pass
     if ((has_physics(m) || m->any_flux_bc) && m->fused_epilogue) return true;       // the epilogue pass also applies the Flux conditions
     return !has_physics(m) && !m->any_flux_bc && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
@@ -1925,6 +1948,11 @@ static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *s
         // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) -- inside the epilogue pass when that runs
         if (m->any_flux_bc && !(physics && m->fused_epilogue))
             for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
+        if (m->any_linear_flux)
+            for (int f = 0; f < m->nf && !rc; ++f)
+                for (int sd = 0; sd < 6 && !rc; ++sd)
+                    if (m->lin[f][sd].on)
+                        rc = compute_linear_flux_bc(g, m->Gn[f], m->loc[f], sd, m->lin[f][sd].a, m->lin[f][sd].b, m->U[m->lin[f][sd].dep]);
     }
     return rc;
 }
@@ -1991,6 +2019,34 @@ extern "C" int ocn_model_set_closure(ocn_model_t m, double nu, const double *kap
     return OCN_OK;
 }
 
+static int model_field_index(const ocn_model_s *m, const char *name) {
+    if (!strcmp(name, "u")) return 0;
+    if (!strcmp(name, "v")) return 1;
+    if (!strcmp(name, "w")) return 2;
+    if (name[0] == 'c' && name[1] >= '0' && name[1] <= '9' && !name[2] && name[1] - '0' < m->ntr) return 3 + (name[1] - '0');
+    return -1;
+}
+
+// name.side = FluxBoundaryCondition((ξ, η, t, φ, p) -> a + b φ, field_dependencies = dep) (continuous_boundary_function.jl:128-161)
+extern "C" int ocn_model_set_linear_flux_bc(ocn_model_t m, const char *name, int side, double a, double b, const char *dep) {
+    if (!m || !name || !dep) return fail(OCN_EINVAL, "NULL argument");
+    m->epoch += 1;
+    const int f = model_field_index(m, name), fd = model_field_index(m, dep);
+    if (f < 0 || fd < 0) return fail(OCN_EINVAL, "name %s not found in model.velocities or model.tracers.", f < 0 ? name : dep);
+    int rc = validate_bc(m->grid->d, m->loc[f], side, OCN_BC_FLUX);
+    if (rc) return rc;
+    const int d = side / 2;
+    for (int q = 0; q < 3; ++q)
+        if (m->loc[fd][q] != m->loc[f][q])
+            return fail(OCN_ENOTSUP, "the field dependency %s must sit at the location of %s (identity interpolation to the boundary)", dep, name);
+    (void)d;
+    m->bcs[f][side].kind = OCN_BC_FLUX; m->bcs[f][side].value = 0.0;      // halos of a Flux side: zero gradient
+    m->any_bc = true;
+    m->lin[f][side].on = true; m->lin[f][side].dep = fd; m->lin[f][side].a = a; m->lin[f][side].b = b;
+    m->any_linear_flux = true;
+    return OCN_OK;
+}
+
 // closure = AnisotropicMinimumDissipation(Cν = Cnu, Cκ = Ckappa[tracer]; Cb = nothing); replaces a ScalarDiffusivity
 extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa) {
     if (m) m->epoch += 1;
@@ -2030,6 +2086,10 @@ extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name,
     if (rc) return rc;
     m->bcs[f][side].kind = kind;
     m->bcs[f][side].value = value;
+    m->lin[f][side].on = false;                 // a plain condition replaces a field-dependent one on this side
+    m->any_linear_flux = false;
+    for (int q = 0; q < m->nf; ++q)
+        for (int sd = 0; sd < 6; ++sd) m->any_linear_flux = m->any_linear_flux || m->lin[q][sd].on;
     m->any_bc = m->any_flux_bc = false;
     for (int q = 0; q < m->nf; ++q)
         for (int sd = 0; sd < 6; ++sd) {

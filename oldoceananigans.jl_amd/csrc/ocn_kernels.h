@@ -634,6 +634,28 @@ __global__ void __launch_bounds__(256) flux_bc_kernel(DGrid g, FView G, int Na, 
     (void)lx; (void)ly;
 }
 
+// One side of a field-dependent Flux condition of the linear family: flux = a + b φ[i, j, k_boundary] (getbc of a
+// ContinuousBoundaryFunction with field_dependencies = :φ, continuous_boundary_function.jl:128-161; φ at the location of the field that
+// carries the condition => identity interpolation), applied like the valued Flux above.
+template <int D>
+__global__ void __launch_bounds__(256) linear_flux_bc_kernel(DGrid g, FView G, FView P, int Na, int Nb, int N, int lz, int side, double a_,
+                                                             double b_) {
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)Na * Nb) return;
+    const int a = 1 + t % Na, b = 1 + t / Na;
+    const int n = side ? N : 1;
+    const int i = D == 0 ? n : a, j = D == 1 ? n : (D == 0 ? a : b), k = D == 2 ? n : b;
+    const double dx = g.dx, dy = g.dy;
+    const double dz = lz == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
+    const double vol = (dx * dy) * dz;
+    const double area = D == 0 ? dy * dz : (D == 1 ? dx * dz : dx * dy);
+    const double phi = P.at(i, j, k);
+    const double flux = a_ == 0.0 ? b_ * phi : a_ + b_ * phi;
+    double &Gq = G.at(i, j, k);
+    if (side) Gq -= flux * area / vol;
+    else      Gq += flux * area / vol;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // RK3 substep / tendency caching (src/TimeSteppers/runge_kutta_3.jl:212-226, store_tendencies.jl:6-9)
 // ---------------------------------------------------------------------------------------------------------------------

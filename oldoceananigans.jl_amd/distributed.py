@@ -276,6 +276,8 @@ class DeviceBackend:
         """{index into U: FieldBoundaryConditions}: constant Flux / Value / Gradient / Open conditions on y / z sides"""
         self.bcs = dict(bcs_by_index)
         for fb in self.bcs.values():
+            if any(getattr(bc, "linear", None) is not None for bc in fb.sides.values()):
+                raise NotImplementedError("field-dependent Flux conditions are not wired into the x-slab path yet")
             if any(s in fb.sides for s in ("west", "east")):
                 raise NotImplementedError("the partitioned x direction is Periodic: no west / east conditions")
 

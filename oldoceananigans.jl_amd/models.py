@@ -112,6 +112,11 @@ class NonhydrostaticModel:
             if name not in ("u", "v", "w") + self.tracer_names:
                 raise ValueError(f"boundary conditions given for {name}, which is not a velocity or tracer of the model")
             for side, bc in fbcs.sides.items():
+                if bc.linear is not None:
+                    a, b, dep = bc.linear
+                    _lib.check(_lib.lib().ocn_model_set_linear_flux_bc(self.handle, self._cname(name).encode(), SIDES.index(side), a, b,
+                                                                       self._cname(dep).encode()))
+                    continue
                 _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, self._cname(name).encode(), SIDES.index(side),
                                                                        KINDS[bc.classification], bc.condition))
 

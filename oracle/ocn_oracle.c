@@ -178,6 +178,32 @@ void oro_compute_flux_bcs(const oro_grid *g, double *Gc, const int loc[3], const
     }
 }
 
+/* One side of a field-dependent Flux condition of the linear family: flux = a + b φ[i, j, k_boundary], φ a model field at the same
+ * location as the field that carries the condition in the two tangential directions -- what getbc(::ContinuousBoundaryFunction)
+ * (continuous_boundary_function.jl:128-161) evaluates for func(x, y, t, φ, p) = a + b φ with field_dependencies = :φ (identity
+ * interpolation, boundary-normal index 1 | N). The evaporation condition of examples/ocean_wind_mixing_and_convection.jl:125-136
+ * is a = 0, b = -evaporation_rate, φ = S. Applied like a valued Flux (compute_flux_bcs.jl:57-163). */
+void oro_compute_linear_flux_bc(const oro_grid *g, double *Gc, const int loc[3], int side6, double a, double b, const double *dep) {
+    const int d = side6 / 2, side = side6 % 2;
+    if (g->topo[d] != ORO_BOUNDED) return;
+    fld G = mkfld(g, Gc, loc), P = mkfld(g, dep, loc);
+    const int N = g->N[d], d1 = (d + 1) % 3, d2 = (d + 2) % 3;
+    for (int bb = 1; bb <= g->N[d2]; ++bb)
+        for (int aa = 1; aa <= g->N[d1]; ++aa) {
+            int q[3];
+            q[d1] = aa; q[d2] = bb; q[d] = side ? N : 1;
+            const double vol = (spacing(g, 0, loc[0], q[0]) * spacing(g, 1, loc[1], q[1])) * spacing(g, 2, loc[2], q[2]);
+            double area;
+            if (d == 0)      area = spacing(g, 1, loc[1], q[1]) * spacing(g, 2, loc[2], q[2]);
+            else if (d == 1) area = spacing(g, 0, loc[0], q[0]) * spacing(g, 2, loc[2], q[2]);
+            else             area = spacing(g, 0, loc[0], q[0]) * spacing(g, 1, loc[1], q[1]);
+            const double phi = AT(P, q[0], q[1], q[2]);
+            const double flux = a == 0.0 ? b * phi : a + b * phi;
+            if (side) AT(G, q[0], q[1], q[2]) -= flux * area / vol;
+            else      AT(G, q[0], q[1], q[2]) += flux * area / vol;
+        }
+}
+
 /* ------------------------------------------------------------------------------------------------------------------
  * WENO reconstruction
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -1157,6 +1183,7 @@ struct oro_model {
     int loc[3 + ORO_MAXTR][3];
     oro_bc bcs[3 + ORO_MAXTR][6];
     int any_flux_bc;
+    struct { int on, dep; double a, b; } lin[3 + ORO_MAXTR][6];   /* linear field-dependent Flux conditions */
     int has_closure;
     double nu, kappa[ORO_MAXTR];
     int has_amd;                                    /* closure = AnisotropicMinimumDissipation(Cν, Cκ) */
@@ -1343,8 +1370,29 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
 /* compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184): the time steppers call it right before every
  * substep (runge_kutta_3.jl:118,135,152; quasi_adams_bashforth_2.jl:99), not compute_tendencies! */
 static void compute_flux_bc_tendencies(oro_model *m) {
-    if (!m->any_flux_bc) return;
-    for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(m->g, m->Gn[f], m->loc[f], m->bcs[f]);
+    if (m->any_flux_bc)
+        for (int f = 0; f < 3 + m->ntr; ++f) oro_compute_flux_bcs(m->g, m->Gn[f], m->loc[f], m->bcs[f]);
+    /* side by side as the reference visits them: x (west, east), y, z */
+    for (int f = 0; f < 3 + m->ntr; ++f)
+        for (int sd = 0; sd < 6; ++sd)
+            if (m->lin[f][sd].on)
+                oro_compute_linear_flux_bc(m->g, m->Gn[f], m->loc[f], sd, m->lin[f][sd].a, m->lin[f][sd].b, m->U[m->lin[f][sd].dep]);
+}
+
+/* name.side = FluxBoundaryCondition((ξ, η, t, φ, p) -> a + b φ, field_dependencies = dep); -1 if the side is not Bounded, the field
+ * is not at Center along it, or dep sits elsewhere in the tangential directions */
+int oro_model_set_linear_flux_bc(oro_model *m, const char *name, int side, double a, double b, const char *dep) {
+    char k, kd;
+    const int f = field_index(m, name, &k), fd = field_index(m, dep, &kd);
+    if (f < 0 || fd < 0 || k != 'U' || kd != 'U' || side < 0 || side > 5) return -1;
+    const int d = side / 2;
+    if (m->g->topo[d] != ORO_BOUNDED || m->loc[f][d] != ORO_CENTER) return -1;
+    for (int q = 0; q < 3; ++q)
+        if (q != d && m->loc[f][q] != m->loc[fd][q]) return -1;
+    if (m->loc[fd][d] != ORO_CENTER) return -1;
+    m->bcs[f][side].kind = ORO_BC_FLUX; m->bcs[f][side].value = 0.0;     /* halos of a Flux side: zero gradient */
+    m->lin[f][side].on = 1; m->lin[f][side].dep = fd; m->lin[f][side].a = a; m->lin[f][side].b = b;
+    return 0;
 }
 
 /* pressure_correction.jl:8-20 + solve_for_pressure.jl:91-95 */

@@ -127,6 +127,9 @@ void oro_add_fplane_coriolis(const oro_grid *g, double f, const double *u, const
 void oro_model_set_closure(oro_model *m, double nu, const double *kappa);
 /* closure = AnisotropicMinimumDissipation(Cν, Cκ per tracer; Cb = nothing); fields "nu_e", "kappa_e<t>". -1 on Flat grids */
 int oro_model_set_amd(oro_model *m, double Cnu, const double *Ckappa);
+/* linear field-dependent Flux condition: flux = a + b dep[i, j, k_boundary] (continuous_boundary_function.jl:128-161) */
+void oro_compute_linear_flux_bc(const oro_grid *g, double *G, const int loc[3], int side, double a, double b, const double *dep);
+int oro_model_set_linear_flux_bc(oro_model *m, const char *name, int side, double a, double b, const char *dep);
 void oro_model_update_state(oro_model *m, int compute_tendencies);
 void oro_model_set_finalize(oro_model *m, int enforce_incompressibility); /* set_nonhydrostatic_model.jl:33-60 */
 void oro_model_time_step(oro_model *m, double dt);

@@ -78,6 +78,7 @@ def lib():
         L.oro_add_closure_tendency_field.argtypes = [vp, C.c_int, dp, dp, dp, dp, dp, dp, ip]
         L.oro_compute_amd_diffusivities.argtypes = [vp, C.c_double, dp, dp, dp, dp, C.POINTER(dp), C.c_int, dp, C.POINTER(dp)]
         L.oro_model_set_amd.argtypes = [vp, C.c_double, dp]
+        L.oro_model_set_linear_flux_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_char_p]
         for n in ("oro_compute_Gu", "oro_compute_Gv", "oro_compute_Gw"):
             getattr(L, n).argtypes = [vp, dp, dp, dp, dp, ip]
         L.oro_compute_Gc.argtypes = [vp, dp, dp, dp, dp, dp, ip]
@@ -355,6 +356,11 @@ class Model:
         import ctypes                      # the keyword `C` (the reference's name) shadows the module alias here
         if lib().oro_model_set_amd(self.handle, float(Cnu), k.ctypes.data_as(ctypes.POINTER(ctypes.c_double))) != 0:
             raise ValueError("AnisotropicMinimumDissipation needs a grid without Flat directions")
+
+    def set_linear_flux_bc(self, name, side, a, b, dep):
+        """name.side = FluxBoundaryCondition((x, y, t, φ, p) -> a + b φ, field_dependencies = dep)"""
+        if lib().oro_model_set_linear_flux_bc(self.handle, name.encode(), SIDES[side], float(a), float(b), dep.encode()) != 0:
+            raise ValueError(f"invalid field-dependent flux condition on the {side} side of {name} (dependency {dep})")
 
     def set_bc(self, name, side, kind, value=0.0):
         """field boundary condition with a constant value: kind in flux | value | gradient | open | default"""

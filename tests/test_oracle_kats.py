@@ -765,3 +765,27 @@ def test_amd_model_time_steps_and_dissipates(oracle):
             assert nu.min() >= 0 and ka.min() >= 0 and nu.max() > 0 and ka.max() > 0
             assert np.array_equal(nu[:3], nu[-6:-3]) and np.array_equal(nu[:, :, 2], nu[:, :, 3])     # periodic x; zero-gradient bottom
     assert ke[1] < ke[0]
+
+
+def test_linear_field_dependent_flux_condition(oracle):
+    """FluxBoundaryCondition(Jˢ, field_dependencies = :S, parameters = rate) with Jˢ(x, y, t, S, rate) = -rate S, the evaporation
+    condition of examples/ocean_wind_mixing_and_convection.jl:125-136, as the linear family a + b φ: for a fluid at rest the top cell
+    obeys dS/dt = (rate / Δz) S, which RK3 integrates as the third-order Taylor polynomial; nothing else changes"""
+    g = oracle.Grid((4, 4, 8), topology=(oracle.PERIODIC, oracle.PERIODIC, oracle.BOUNDED), z=(-2.0, 0.0))
+    m = oracle.Model(g, 2)
+    rate = 0.3
+    m.set_linear_flux_bc("c1", "top", 0.0, -rate, "c1")
+    z = np.zeros((4, 4, 8))
+    S0 = 35.0 + z
+    m.set(u=z, v=z, w=np.zeros((4, 4, 9)), c0=20.0 + z, c1=S0)
+    dt = 0.05
+    m.time_step(dt)
+    S = g.interior_cells(m.field("c1"))
+    x = rate * dt / 0.25
+    assert np.allclose(S[:, :, -1], 35.0 * (1 + x + x * x / 2 + x ** 3 / 6), rtol=1e-14, atol=0)
+    assert np.array_equal(S[:, :, :-1], S0[:, :, :-1]) and np.array_equal(g.interior_cells(m.field("c0")), 20.0 + z)
+    # validation: Bounded side, Center along it, dependency at the same tangential location
+    with pytest.raises(ValueError):
+        m.set_linear_flux_bc("c1", "east", 0.0, 1.0, "c1")
+    with pytest.raises(ValueError):
+        m.set_linear_flux_bc("c1", "top", 0.0, 1.0, "u")
