@@ -119,8 +119,8 @@ def cpu_baseline(size, dt, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=256, help="cells per side per GPU")
     ap.add_argument("--global-size", type=int, default=0,
                     help="fixed GLOBAL grid G^3 split into x-slabs over the ranks (strong scaling; 512 = BASELINE.json configs[3] at "
