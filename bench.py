@@ -143,17 +143,20 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1":
+    if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1" or os.environ.get("OCN_SELF_LOOP") == "1":
         import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so (see distributed.init_process_group)
     import oldoceananigans_jl_amd as ocn
     N = args.global_size if (args.global_size and world == 1) else args.size
-    distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1"
+    distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1" or os.environ.get("OCN_SELF_LOOP") == "1"
     if distributed:
         from oldoceananigans_jl_amd import distributed as dist
         # OCN_REHEARSE_ON_ONE_GPU=1: all ranks share card 0, collectives staged through the host over gloo -- exercises this
         # script's N > 1 path on a one-GPU box; the numbers it prints are not measurements
         rehearsal = os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1"
-        ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=rehearsal)
+        # OCN_SELF_LOOP=1 (one rank): the rank is its own west / east neighbour -- the complete N > 1 code path with device copies
+        # in place of the RCCL transfers: the LOCAL cost of the partitioned path, measurable on a one-GPU box
+        self_loop = os.environ.get("OCN_SELF_LOOP") == "1" and world == 1
+        ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=rehearsal, self_loop=self_loop)
         arch = ctx.arch
         if args.global_size:
             G = args.global_size
@@ -251,8 +254,9 @@ def main():
     out = {
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_size else "weak",
-        "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" else None,
-        "dtype": "f64", "data": "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
+        "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" and not distributed else None,
+        "dtype": "f64", "data": "synthetic; SELF-LOOP: one rank running the N > 1 code path with device copies instead of RCCL transfers" if (distributed and os.environ.get("OCN_SELF_LOOP") == "1" and world == 1)
+        else "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
         else "synthetic; REHEARSAL on one card over gloo + host staging: not a measurement",
         "config": {"workload": (f"{gshape} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
                                 "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing " +

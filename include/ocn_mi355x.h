@@ -184,6 +184,9 @@ int ocn_compute_source_term(ocn_grid_t grid, const double *u, const double *v, c
                             int weight_by_dz);
 /* _make_pressure_correction! (pressure_correction.jl:31-37) */
 int ocn_make_pressure_correction(ocn_grid_t grid, double *u, double *v, double *w, const double *p);
+/* the same over {i0, i1, j0, j1, k0, k1} (NULL = everything): an x-slab rank corrects its two boundary strips first, starts the
+ * halo exchange of the next update_state! and corrects the interior while the halos are in flight */
+int ocn_make_pressure_correction_range(ocn_grid_t grid, double *u, double *v, double *w, const double *p, const int *range);
 /* `pNHS ./= Δt⁺` (pressure_correction.jl:48-50): interior of a (Center, Center, Center) field */
 int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor);
 

@@ -775,11 +775,27 @@ extern "C" int ocn_compute_source_term(ocn_grid_t grid, const double *u, const d
     return source_term(grid->d, u, v, w, rhs_complex, weight_by_dz != 0);
 }
 
-static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p) {
-    hipLaunchKernelGGL(pressure_correction_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C));
+static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p, const int *range = nullptr) {
+    Range6 r{1, g.Nx, 1, g.Ny, 1, g.Nz};
+    if (range) {
+        const int N[3] = {g.Nx, g.Ny, g.Nz};
+        for (int d = 0; d < 3; ++d)
+            if (range[2 * d] < 1 || range[2 * d + 1] > N[d])
+                return fail(OCN_EINVAL, "range [%d, %d] along dimension %d leaves the interior", range[2 * d], range[2 * d + 1], d);
+        r = Range6{range[0], range[1], range[2], range[3], range[4], range[5]};
+    }
+    const int nx = r.i1 - r.i0 + 1, ny = r.j1 - r.j0 + 1, nz = r.k1 - r.k0 + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
+    hipLaunchKernelGGL(pressure_correction_kernel, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C), r);
     KERNEL_CHECK();
     return OCN_OK;
+}
+
+extern "C" int ocn_make_pressure_correction_range(ocn_grid_t grid, double *u, double *v, double *w, const double *p, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !p) return fail(OCN_EINVAL, "NULL argument");
+    return pressure_correction(grid->d, u, v, w, p, range);
 }
 
 extern "C" int ocn_make_pressure_correction(ocn_grid_t grid, double *u, double *v, double *w, const double *p) {
@@ -1389,7 +1405,8 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
     if (!solver || !local_grid) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
     if (R < 1 || rank < 0 || rank >= R) return fail(OCN_EINVAL, "invalid rank %d of %d", rank, R);
-    if (g.ty != OCN_PERIODIC || (R > 1 && g.tx != OCN_CONNECTED) || (R == 1 && g.tx != OCN_PERIODIC))
+    // (one rank with a FullyConnected x is its own neighbour on both sides: the N > 1 code path measured on one GPU)
+    if (g.ty != OCN_PERIODIC || (R > 1 && g.tx != OCN_CONNECTED) || (R == 1 && g.tx != OCN_PERIODIC && g.tx != OCN_CONNECTED))
         return fail(OCN_ENOTSUP, "the distributed Poisson solvers are accelerated for (Periodic, Periodic, Periodic | Bounded) x-slab partitions");
     // validate_poisson_solver_distributed_grid (:194-229): Ny must be divisible by Rx
     if (g.Ny % R != 0) return fail(OCN_EINVAL, "Ny = %d must be divisible by the number of ranks %d (transpose y -> x)", g.Ny, R);

@@ -735,11 +735,11 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     } else ((double2 *)rhs)[q] = make_double2(val, 0.0);    // the reference's complex storage
 }
 
-__global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p) {
-    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = 1 + blockIdx.z;
-    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+__global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p, Range6 r) {
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
     const double pc = p.at(i, j, k);
     u.at(i, j, k) -= (g.tx == OCN_FLAT ? 0.0 : pc - p.at(i - 1, j, k)) * g.rdx;            // ∂xᶠᶜᶜ = δx * Δx⁻¹
     v.at(i, j, k) -= (g.ty == OCN_FLAT ? 0.0 : pc - p.at(i, j - 1, k)) * g.rdy;

@@ -56,6 +56,11 @@ class DistributedContext:
         self.partition = Partition(world)
         self.west, self.east = self.partition.neighbours(rank)
 
+    @property
+    def partitioned(self):
+        """does x carry rank boundaries (FullyConnected topology, halo exchange, strips)? True for world > 1"""
+        return self.world > 1
+
     # -- collectives ---------------------------------------------------------------------------------------------
     def exchange_start(self, west_send, east_send, west_recv, east_recv):
         """MPI.Isend/Irecv! to both neighbours (halo_communication.jl:300,326). Order of the ops makes the pairing
@@ -90,6 +95,33 @@ class DistributedContext:
 
     def barrier(self):
         self.dist.barrier()
+
+
+class SelfLoopContext(DistributedContext):
+    """MEASUREMENT ONLY: one rank that is its own west and east neighbour. The model runs the complete N > 1 code path --
+    FullyConnected x, halo pack / exchange / unpack, interior + buffer strips, thin exchanges, substructured solve with an
+    all-gather -- with device-to-device copies in place of the RCCL transfers, so the LOCAL cost of the partitioned path can
+    be timed on a one-GPU box (bench.py: OCN_SELF_LOOP=1). The result equals the one-rank Periodic run."""
+
+    partitioned = True
+
+    def exchange_start(self, west_send, east_send, west_recv, east_recv):
+        west_recv.copy_(east_send)        # what goes out of the east side comes in from the west (periodic ring of one)
+        east_recv.copy_(west_send)
+        return []
+
+    def all_to_all(self, recv, send):
+        if recv.data_ptr() != send.data_ptr():
+            recv.copy_(send)
+
+    def all_gather(self, gathered, payload):
+        gathered.copy_(payload)
+
+    def allreduce_max(self, value):
+        return float(value)
+
+    def barrier(self):
+        pass
 
 
 class HostStagedContext(DistributedContext):
@@ -148,7 +180,7 @@ class HostStagedContext(DistributedContext):
         return float(t.item())
 
 
-def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False):
+def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False, self_loop=False):
     """one process per GPU; MASTER_ADDR/PORT, RANK, WORLD_SIZE come from torch.distributed.run.
     rehearse_on_one_gpu: all ranks on card 0, collectives staged through the host over gloo (HostStagedContext)"""
     if _lib._lib is not None and _lib.LOADED_BEFORE_TORCH:
@@ -179,6 +211,12 @@ def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False):
         else:
             dist.init_process_group(backend)
     rank, world = dist.get_rank(), dist.get_world_size()
+    if self_loop:
+        if world != 1 or not use_gpu:
+            raise _lib.OcnError("self_loop measures the partitioned path with ONE rank on a GPU")
+        arch = GPU(local_rank)
+        _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return SelfLoopContext(0, 1, torch.device("cuda", local_rank), torch, dist, arch)
     if use_gpu:
         arch = GPU(local_rank)
         # all library work goes to torch's current stream so RCCL ops are stream-ordered with the kernels
@@ -221,7 +259,7 @@ class DistributedRectilinearGrid:
         self.x_global = (float(x[0]), float(x[1]))
         self.Lx_global = _regular_coordinate(x, self.global_size[0], "x")[1]
         xl = x if R == 1 else partition_coordinate(x, nxl, R, r)
-        topo = (topology[0] if R == 1 else FullyConnected, topology[1], topology[2])
+        topo = (FullyConnected if ctx.partitioned else topology[0], topology[1], topology[2])
         self.local_size = (nxl, self.global_size[1], self.global_size[2])
         self.i_offset = r * nxl                      # global index of local i = 1 minus one
         if make_local_grid is None:
@@ -389,7 +427,7 @@ class DeviceBackend:
         from . import kernels
         from .fields import fill_halo_regions as fill
         g = self.grid.local
-        ext = 1 if self.ctx.world > 1 else 0
+        ext = 1 if self.ctx.partitioned else 0
         kernels.compute_amd_diffusivities(g, self.closure, self.tracer_names, self.U, self.nu_e, self.kappa_e,
                                           kernel_parameters=(1 - ext, g.Nx + ext, 1, g.Ny, 1, g.Nz))
         fill([self.nu_e] + self.kappa_e, True)
@@ -421,9 +459,11 @@ class DeviceBackend:
     def poisson_backward_yz(self):
         _lib.check(_lib.lib().ocn_dist_poisson_backward_yz(self.solver, self.p.data))
 
-    def pressure_correction(self):
+    def pressure_correction(self, rng=None):
+        from .kernels import _range
         U = self.U
-        _lib.check(_lib.lib().ocn_make_pressure_correction(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.p.data))
+        _lib.check(_lib.lib().ocn_make_pressure_correction_range(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.p.data,
+                                                                 _range(rng)))
 
     def divide_pressure(self, divisor):
         _lib.check(_lib.lib().ocn_divide_interior(self.grid.local.handle, self.p.data, float(divisor)))
@@ -519,7 +559,7 @@ def fill_halo_regions(model, fields, fill_open_bcs=True, x_fields=None, x_depth=
     x_fields / x_depth: exchange only these fields' x halos, only this many columns deep (see compute_pressure_correction)"""
     b, ctx = model.backend, model.ctx
     b.fill_local_halos(fields, fill_open_bcs)
-    if ctx.world > 1:
+    if ctx.partitioned:
         xf = fields if x_fields is None else x_fields
         ws, es, wr, er = b.pack_x(xf, x_depth)
         ctx.exchange(ws, es, wr, er)
@@ -533,7 +573,7 @@ def solve_for_pressure(model):
     if getattr(b, "payload", None) is not None:
         # z Periodic: substructured solve along the partitioned direction -- local transforms and sweeps, one small all-gather
         b.poisson_forward_local()
-        if ctx.world > 1:
+        if ctx.partitioned:
             ctx.all_gather(b.gathered, b.payload)
         else:
             b.gathered.copy_(b.payload)
@@ -568,10 +608,27 @@ def update_state(model, compute_tendencies=True):
     g = model.grid.local
     if compute_tendencies and hasattr(b, "n_evals"):
         b.n_evals += 1
+    reqs = getattr(model, "_halos_in_flight", None)
+    if reqs is not None:
+        # the x exchange was started by make_pressure_correction: finish the local fills (all columns are final now), take the
+        # halos, then everything in one piece
+        model._halos_in_flight = None
+        b.fill_local_halos(b.U, False)
+        ctx.exchange_wait(reqs)
+        b.unpack_x(b.U)
+        if hasattr(b, "compute_diffusivities"):
+            b.compute_diffusivities()
+        if hasattr(b, "update_hydrostatic_pressure"):
+            b.update_hydrostatic_pressure()
+        if compute_tendencies:
+            b.compute_tendencies(None)
+            if hasattr(b, "flux_bc_tendencies"):
+                b.flux_bc_tendencies()
+        return
     # with buoyancy, pHY′ in the x-halo columns needs the exchanged tracers: fill, integrate, then evaluate (no overlap)
     overlap = model.async_halos if model.async_halos is not None else g.Nx >= 3 * 64
     # eddy diffusivities and pHY′ in the x-halo columns need the exchanged fields: fill, evaluate them, then the tendencies (no overlap)
-    if (not compute_tendencies or ctx.world == 1 or not overlap or g.Nx <= 2 * g.Hx or
+    if (not compute_tendencies or not ctx.partitioned or not overlap or g.Nx <= 2 * g.Hx or
             getattr(b, "buoyancy", None) is not None or isinstance(getattr(b, "closure", None), AnisotropicMinimumDissipation)):
         fill_halo_regions(model, b.U, fill_open_bcs=False)
         if hasattr(b, "compute_diffusivities"):
@@ -611,10 +668,29 @@ def compute_pressure_correction(model):
     fill_halo_regions(model, [b.p], fill_open_bcs=True, x_depth=1 if thin else None)
 
 
-def make_pressure_correction(model, Δt):
-    b = model.backend
-    b.pressure_correction()
-    b.divide_pressure(max(np.finfo(np.float64).eps, Δt))
+def make_pressure_correction(model, Δt, start_halo_exchange=False):
+    """make_pressure_correction! (pressure_correction.jl:40-53).
+    start_halo_exchange (the caller evaluates tendencies next): correct the two Hx-wide boundary strips first, fill their y / z halos,
+    pack them and START the x exchange of the coming update_state!; the interior correction, p / Δt and the final local fills
+    then run while the halos are in flight, and the tendencies need no interior / buffer split -- one full launch of the fused
+    kernel (measured on one rank looped onto itself, 256^3: 1.92 ms for interior + two strips -> 1.73 ms). Same values everywhere:
+    every cell is corrected once, the packed columns are final when they are packed."""
+    b, ctx = model.backend, model.ctx
+    g = model.grid.local
+    dtp = max(np.finfo(np.float64).eps, Δt)
+    if not (start_halo_exchange and ctx.partitioned and getattr(model, "early_exchange", True) and model.async_halos is not False and
+            g.Nx > 2 * g.Hx and hasattr(b, "pack_x")):
+        b.pressure_correction()
+        b.divide_pressure(dtp)
+        return
+    Nx, Ny, Nz, Hx = g.Nx, g.Ny, g.Nz, g.Hx
+    b.pressure_correction((1, Hx, 1, Ny, 1, Nz))
+    b.pressure_correction((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))
+    b.fill_local_halos(b.U, False)                       # the strips' y / z halos (corners ride along in the buffers)
+    ws, es, wr, er = b.pack_x(b.U)
+    model._halos_in_flight = ctx.exchange_start(ws, es, wr, er)
+    b.pressure_correction((Hx + 1, Nx - Hx, 1, Ny, 1, Nz))
+    b.divide_pressure(dtp)
 
 
 def set_model(model, enforce_incompressibility=True, **kwargs):
@@ -667,7 +743,7 @@ def time_step(model, Δt):
             _tick(model, stage_dt[2], False)
             model.last_stage_Δt, model.last_Δt = corrected, Δt
         compute_pressure_correction(model)
-        make_pressure_correction(model, stage_dt[s])
+        make_pressure_correction(model, stage_dt[s], start_halo_exchange=True)      # update_state!(…; compute_tendencies) follows
         if s < 2:
             b.swap_tendencies()           # cache_previous_tendencies! as a pointer swap (see ocn_api.hip)
         if s < 2 and fuse:

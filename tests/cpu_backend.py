@@ -182,9 +182,18 @@ class CpuBackend:
         H = g.halo_size
         self.p.a[H[0]:H[0] + g.Nx, H[1]:H[1] + g.Ny, H[2]:H[2] + g.Nz] = z.real
 
-    def pressure_correction(self):
+    def pressure_correction(self, rng=None):
         u, v, w = (f.a for f in self.U[:3])
-        self.grid.local.o.pressure_correct(u, v, w, self.p.a)
+        if rng is None:
+            self.grid.local.o.pressure_correct(u, v, w, self.p.a)
+            return
+        # the oracle corrects whole fields: correct copies and keep the requested x range (test infrastructure, not the product)
+        cu, cv, cw = u.copy(order="F"), v.copy(order="F"), w.copy(order="F")
+        self.grid.local.o.pressure_correct(cu, cv, cw, self.p.a)
+        H = self.grid.local.Hx
+        sl = slice(H + rng[0] - 1, H + rng[1])
+        for a, c in ((u, cu), (v, cv), (w, cw)):
+            a[sl] = c[sl]
 
     def divide_pressure(self, divisor):
         g = self.grid.local

@@ -23,6 +23,7 @@ class LoopbackContext:
         self.torch, self.arch = world.torch, world.arch
         self.device = world.torch.device("cuda", 0)
         self.west, self.east = (rank - 1) % world.R, (rank + 1) % world.R
+        self.partitioned = world.R > 1
 
     def exchange_start(self, ws, es, wr, er):
         w = self.w

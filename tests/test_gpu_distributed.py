@@ -286,3 +286,43 @@ def test_separate_processes_match_single_gpu(ocn, arch, tmp_path, R, size, zkind
             a = out[name]
             err = np.abs(a[3:-3, 3:-3, 3:-3] - ref[3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]).max() / np.abs(ref).max()
             assert err <= 1e-12, (r, name, err)
+
+
+@pytest.mark.parametrize("size,zkind,substructured", [((32, 16, 8), "periodic", 1), ((32, 16, 8), "periodic", 0), ((32, 12, 10), "stretched", 1),
+                                                      ((384, 8, 8), "periodic", 1)])
+def test_self_loop_rank_equals_single_gpu(ocn, arch, size, zkind, substructured):
+    """SelfLoopContext: ONE rank that is its own neighbour runs the whole partitioned code path (FullyConnected x, pack / exchange /
+    unpack, strips, thin exchanges, gathered interface solve) with device copies; the fields equal the single-GPU model's"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    ocn.set_option("dist_substructured", substructured)
+    try:
+        ctx = dist.SelfLoopContext(0, 1, torch.device("cuda", 0), torch, None, arch)
+        z, topo = _z_and_topology(ocn, zkind, size[2])
+        grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+        assert grid.local.topology[0] is ocn.FullyConnected
+        model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind),
+                                                    coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
+        flds = model.fields()
+        dist.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()})
+        dt = 0.1 * grid.local.Δxᶜᵃᵃ / 0.6
+        for _ in range(3):
+            dist.time_step(model, dt)
+        out = {n: f.parent() for n, f in flds.items()}
+        out["p"] = model.pressure.parent()
+        model.backend.close()
+    finally:
+        ocn.set_option("dist_substructured", 1)
+    sgrid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    smodel = ocn.NonhydrostaticModel(grid=sgrid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind),
+                                     coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
+    ocn.set_model(smodel, **{n: analytic(n, *sgrid.nodes(f.loc)) for n, f in smodel.fields().items()})
+    for _ in range(3):
+        ocn.time_step(smodel, dt)
+    ref = {n: f.parent() for n, f in smodel.fields().items()}
+    ref["p"] = smodel.pressures.pNHS.parent()
+    for name, a in out.items():
+        err = np.abs(a[3:-3, 3:-3, 3:-3] - ref[name][3:-3, 3:-3, 3:-3]).max() / np.abs(ref[name]).max()
+        assert err <= 1e-12, (name, err)
