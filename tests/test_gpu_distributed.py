@@ -265,7 +265,7 @@ def test_separate_processes_match_single_gpu(ocn, arch, tmp_path, R, size, zkind
     here = os.path.dirname(os.path.abspath(__file__))
     nsteps = 3
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={R}", "--master-addr", "127.0.0.1",
-           "--master-port", str(29530 + R + 10 * substructured), os.path.join(here, "gpu_dist_worker.py"), str(tmp_path),
+           "--master-port", str(29560 + R + 10 * substructured + (20 if zkind == "stretched" else 0)), os.path.join(here, "gpu_dist_worker.py"), str(tmp_path),
            str(size[0]), str(size[1]), str(size[2]), str(nsteps), zkind, str(substructured)]
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout[-2000:] + run.stderr[-4000:]
