@@ -314,8 +314,6 @@ class DeviceBackend:
         """{index into U: FieldBoundaryConditions}: constant Flux / Value / Gradient / Open conditions on y / z sides"""
         self.bcs = dict(bcs_by_index)
         for fb in self.bcs.values():
-            if any(getattr(bc, "linear", None) is not None for bc in fb.sides.values()):
-                raise NotImplementedError("field-dependent Flux conditions are not wired into the x-slab path yet")
             if any(s in fb.sides for s in ("west", "east")):
                 raise NotImplementedError("the partitioned x direction is Periodic: no west / east conditions")
 
@@ -330,10 +328,19 @@ class DeviceBackend:
 
     def flux_bc_tendencies(self):
         """compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184)"""
-        from .boundary_conditions import compute_flux_bcs
+        from .boundary_conditions import SIDES, compute_flux_bcs
+        names = ["u", "v", "w"] + list(getattr(self, "tracer_names", ()))
         for n, fb in getattr(self, "bcs", {}).items():
             if any(bc.classification == "Flux" and bc.condition != 0.0 for bc in fb.sides.values()):
                 compute_flux_bcs(self.Gn[n], fb)
+        for n, fb in getattr(self, "bcs", {}).items():
+            for side, bc in fb.sides.items():
+                if getattr(bc, "linear", None) is not None:          # flux = a + b φ[i, j, k_boundary]
+                    a, b_, dep = bc.linear
+                    G = self.Gn[n]
+                    loc = (C.c_int * 3)(*[1 if l is Face else 0 for l in G.loc])
+                    _lib.check(_lib.lib().ocn_compute_linear_flux_bc(self.grid.local.handle, G.data, loc, SIDES.index(side), a, b_,
+                                                                     self.U[names.index(dep)].data))
 
     def _slab(self, f):
         """doubles one field contributes per side: Hx x Py x Pz of ITS parent (Face fields on Bounded dims have one more plane)"""
@@ -373,7 +380,7 @@ class DeviceBackend:
 
     def can_fuse_substep(self):
         g = self.grid.local
-        no_flux = not any(bc.classification == "Flux" and bc.condition != 0.0
+        no_flux = not any(bc.classification == "Flux" and (bc.condition != 0.0 or getattr(bc, "linear", None) is not None)
                           for fb in getattr(self, "bcs", {}).values() for bc in fb.sides.values())
         return (no_flux and getattr(self, "closure", None) is None and getattr(self, "buoyancy", None) is None and
                 getattr(self, "coriolis", None) is None and
@@ -501,6 +508,8 @@ class DistributedNonhydrostaticModel:
         self.grid, self.ctx = grid, grid.ctx
         self.tracer_names = tuple(tracers)
         self.backend = backend if backend is not None else DeviceBackend(grid.ctx, grid, len(self.tracer_names))
+        if not hasattr(self.backend, "tracer_names"):
+            self.backend.tracer_names = self.tracer_names
         self.time, self.iteration, self.stage = 0.0, 0, 1
         self.last_Δt = self.last_stage_Δt = float("inf")
         # overlap the halo exchange with the interior tendencies (AsynchronousDistributed)? None = automatic: only when the slab

@@ -25,14 +25,20 @@ def _z_and_topology(ocn, zkind, Nz):
 
 def _bcs(ocn, zkind):
     """config-5 style conditions on the Bounded z sides (constant Flux / Gradient / Value)"""
+    F = ocn.FieldBoundaryConditions
+    if zkind == "amd":      # the conditions of examples/ocean_wind_mixing_and_convection.jl, evaporation flux -rate S included
+        return {"u": F(top=ocn.FluxBoundaryCondition(-1e-3)),
+                "T": F(top=ocn.FluxBoundaryCondition(4e-3), bottom=ocn.GradientBoundaryCondition(0.01)),
+                "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-2.5e-3), field_dependencies="S"))}
     if zkind != "stretched":
         return None
-    F = ocn.FieldBoundaryConditions
     return {"u": F(top=ocn.FluxBoundaryCondition(-2e-3), bottom=ocn.ValueBoundaryCondition(0.0)),
             "T": F(top=ocn.FluxBoundaryCondition(5e-3), bottom=ocn.GradientBoundaryCondition(0.4))}
 
 
 def _tracers_and_buoyancy(ocn, zkind):
+    if zkind == "amd":
+        return ("T", "S"), ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4))
     return (("T", "S"), ocn.SeawaterBuoyancy()) if zkind == "bounded" else (("T", "S"), None)
 
 
@@ -90,7 +96,8 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
     (8, True, (64, 8, 8), "stretched"),        # 8 ranks, transposing Fourier-tridiagonal solver
     (2, True, (384, 8, 8), "periodic"),        # local Nx = 192: buffer strips one 64-lane tile wide (buffer_strip_width)
     (2, True, (32, 16, 8), "bounded"),         # z Bounded: distributed Fourier-tridiagonal solver
-    (4, True, (32, 12, 10), "amd"),            # stretched z + AnisotropicMinimumDissipation: νₑ, κₑ evaluated in the x-halo columns
+    (4, True, (32, 12, 10), "amd"),            # the whole configs[4] physics: stretched z, AMD (νₑ, κₑ evaluated in the x-halo columns),
+                                               # linear seawater, wind stress / heat flux / bottom gradient / evaporation conditions
     (4, True, (28, 8, 12), "stretched"),       # stretched z, odd local Nx (7)
 ])
 def test_virtual_ranks_match_single_gpu_and_oracle(ocn, oracle, arch, R, async_halos, size, zkind):
