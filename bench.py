@@ -116,6 +116,22 @@ def cpu_baseline(size, dt, budget_s=25.0):
             "ms_per_step": 1e3 * el / nsteps}
 
 
+def workload_physics(ocn, workload):
+    """keyword arguments of the model for the non-default workloads (see --workload)"""
+    F = ocn.FieldBoundaryConditions
+    if workload == "ppb_physics":
+        return dict(closure=ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4), buoyancy=ocn.SeawaterBuoyancy(),
+                    boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                         "T": F(top=ocn.FluxBoundaryCondition(1e-4), bottom=ocn.GradientBoundaryCondition(0.01))})
+    if workload == "ppb_amd":
+        return dict(closure=ocn.AnisotropicMinimumDissipation(),
+                    buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
+                    boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                         "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+                                         "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-1e-3 / 3600.0), field_dependencies="S"))})
+    return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,9 +177,14 @@ def main():
         if args.global_size:
             G = args.global_size
             grid = dist.DistributedRectilinearGrid(ctx, size=(G, G, G), extent=(1.0, 1.0, 1.0))
+        elif args.workload != "ppp":
+            from helpers import tanh_faces
+            grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N // 2), x=(0.0, float(world)), y=(0.0, 1.0), z=tanh_faces(N // 2),
+                                                   topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
         else:
             grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
-        model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+        model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"),
+                                                    **workload_physics(ocn, args.workload))
         model.fuse_substep = os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"
         step = lambda dt: dist.time_step(model, dt)          # noqa: E731
         barrier = ctx.barrier
@@ -176,19 +197,7 @@ def main():
             from helpers import tanh_faces
             grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
                                        topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
-            if args.workload == "ppb_physics":
-                F = ocn.FieldBoundaryConditions
-                physics = dict(closure=ocn.ScalarDiffusivity(ν=1e-4, κ=1e-4), buoyancy=ocn.SeawaterBuoyancy(),
-                               boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
-                                                    "T": F(top=ocn.FluxBoundaryCondition(1e-4), bottom=ocn.GradientBoundaryCondition(0.01))})
-            if args.workload == "ppb_amd":
-                F = ocn.FieldBoundaryConditions
-                physics = dict(closure=ocn.AnisotropicMinimumDissipation(),
-                               buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
-                               boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
-                                                    "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
-                                                    "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-1e-3 / 3600.0),
-                                                                                         field_dependencies="S"))})
+            physics = workload_physics(ocn, args.workload)
         else:
             grid = ocn.RectilinearGrid(arch, size=(N, N, N), extent=(1, 1, 1))
         model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"), **physics)
@@ -265,14 +274,16 @@ def main():
                                  "(BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU: {N}^3 cells on each of {world} x-slabs; "
                                                                 "at 8 GPUs the cell count of configs[3]'s 512^3") + ")"))
                    if args.workload == "ppp" else
-                   (f"{N}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
+                   (f"{N * world}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
                     "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +
                     ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
                      if args.workload == "ppb_physics" else
                      "; + AnisotropicMinimumDissipation, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (the physics of "
                      "BASELINE.json configs[4], evaporation flux -rate S included)" if args.workload == "ppb_amd" else "")),
-                   "parallelism": "single GPU" if world == 1 else f"x-slab Partition({world}): RCCL send/recv halos, substructured x solve "
-                                                                     "(one all-gather of 2 complex per mode per solve)",
+                   "parallelism": "single GPU" if world == 1 else
+                   (f"x-slab Partition({world}): RCCL send/recv halos, " +
+                    ("substructured x solve (one all-gather of 2 complex per mode per solve)" if args.workload == "ppp" else
+                     "distributed Fourier-tridiagonal solve (two all-to-all transposes)")),
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
                                        "benchmarks.md:128); older version without RK3/2 tracers -- context only"},
