@@ -786,7 +786,8 @@ static int pressure_correction(const DGrid &g, double *u, double *v, double *w, 
     }
     const int nx = r.i1 - r.i0 + 1, ny = r.j1 - r.j0 + 1, nz = r.k1 - r.k0 + 1;
     if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
-    hipLaunchKernelGGL(pressure_correction_kernel, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
+    const dim3 blk = nx < 16 ? dim3(4, 64, 1) : BLK;        // an Hx-wide boundary strip: threads along y instead of 61 idle lanes in x
+    hipLaunchKernelGGL(pressure_correction_kernel, grid3(nx, ny, nz, blk), blk, 0, g_stream, g, make_view(g, u, LOC_U),
                        make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C), r);
     KERNEL_CHECK();
     return OCN_OK;
