@@ -1830,6 +1830,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
     if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
+    if (!strcmp(key, "fused_xcd")) { g_fused_xcd = value; return OCN_OK; }
     if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
     if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
     if (!strcmp(key, "dist_substructured")) { g_dist_substructured = value; return OCN_OK; }
