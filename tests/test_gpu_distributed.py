@@ -94,6 +94,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
     (8, True, (64, 8, 8), "periodic"),         # the rank count of one MI355X node: 8-point interface system of the x solve
     (3, True, (24, 9, 6), "periodic"),         # a rank count that is not a power of two (Ny must divide by it: the reference's validation)
     (8, True, (64, 8, 8), "stretched"),        # 8 ranks, transposing Fourier-tridiagonal solver
+    (2, None, (512, 24, 16), "periodic"),      # local Nx = 256, automatic overlap choice: several tiles in every direction
     (2, True, (384, 8, 8), "periodic"),        # local Nx = 192: buffer strips one 64-lane tile wide (buffer_strip_width)
     (2, True, (32, 16, 8), "bounded"),         # z Bounded: distributed Fourier-tridiagonal solver
     (4, True, (32, 12, 10), "amd"),            # the whole configs[4] physics: stretched z, AMD (νₑ, κₑ evaluated in the x-halo columns),
