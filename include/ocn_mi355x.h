@@ -274,6 +274,9 @@ int ocn_model_time_step(ocn_model_t model, double dt);
  * SURVEY.md 8f.1): χ = 0.1 is the reference's default; a forward-Euler step is taken when Δt differs from clock.last_Δt (first
  * step) or euler != 0 */
 int ocn_model_time_step_ab2(ocn_model_t model, double dt, double chi, int euler);
+/* reset!(model.clock); reset!(model.timestepper) (Simulations/simulation.jl:203-213): time = 0, iteration = 0, stage = 1,
+ * last_Δt = Inf, Gⁿ = G⁻ = 0. The next time-step starts with update_state! again. */
+int ocn_model_reset(ocn_model_t model);
 int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *stage, double *last_dt,
                     double *last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */

@@ -2276,6 +2276,23 @@ extern "C" int ocn_model_time_step_ab2(ocn_model_t m, double dt, double chi, int
     return update_state(m, true);
 }
 
+// reset!(model.clock) + reset!(model.timestepper) (TimeSteppers/clock.jl reset!, runge_kutta_3.jl / quasi_adams_bashforth_2.jl reset!):
+// time 0, iteration 0, stage 1, last Δt = Inf, both tendency sets zero
+extern "C" int ocn_model_reset(ocn_model_t m) {
+    NEED_INIT();
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    m->time = 0; m->iteration = 0; m->stage = 1; m->last_dt = INFINITY; m->last_stage_dt = INFINITY;
+    const DGrid &g = m->grid->d;
+    for (int f = 0; f < m->nf; ++f) {
+        int P[3];
+        parent_size(g, m->loc[f], P);
+        const size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
+        HIP_TRY(hipMemsetAsync(m->Gn[f], 0, bytes, g_stream));
+        HIP_TRY(hipMemsetAsync(m->Gm[f], 0, bytes, g_stream));
+    }
+    return OCN_OK;
+}
+
 extern "C" int ocn_model_clock(ocn_model_t m, double *time, int64_t *iteration, int *stage, double *last_dt, double *last_stage_dt) {
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     if (time) *time = m->time;

@@ -1,8 +1,12 @@
 """Simulation-level pieces that touch the hot path: cell_advection_timescale (Advection/cell_advection_timescale.jl:
 13-34), cell_diffusion_timescale (TurbulenceClosures/turbulence_closure_diagnostics.jl:7-47) and TimeStepWizard / new_time_step
-(Simulations/time_step_wizard.jl:5-115); hasnan / NaNChecker (Diagnostics/nan_checker.jl)."""
+(Simulations/time_step_wizard.jl:5-115); hasnan / NaNChecker (Diagnostics/nan_checker.jl);
+Simulation / run! / Callback / IterationInterval / TimeInterval (Simulations/simulation.jl, run.jl, callback.jl, Utils/schedules.jl) -- host
+logic only, every device operation goes through the model's C-ABI calls."""
 import ctypes as C
 import math
+import time as _time
+from collections import OrderedDict
 
 import numpy as np
 
@@ -45,6 +49,10 @@ class TimeStepWizard:
             raise ValueError(f"max_change must be > 1. You provided max_change = {max_change}.")
         self.cfl, self.diffusive_cfl = float(cfl), float(diffusive_cfl)
         self.max_change, self.min_change, self.max_Δt, self.min_Δt = float(max_change), float(min_change), float(max_Δt), float(min_Δt)
+
+    def __call__(self, simulation):
+        """(wizard::TimeStepWizard)(simulation) = simulation.Δt = new_time_step(simulation.Δt, wizard, simulation.model)"""
+        simulation.Δt = new_time_step(simulation.Δt, self, simulation.model)
 
 
 def new_time_step(old_Δt, wizard, model):
@@ -93,3 +101,149 @@ class NaNChecker:
 def default_nan_checker(model):
     """NaNChecker on the first prognostic field, u (Models/Models.jl:173-184)"""
     return NaNChecker({"u": model.velocities.u if hasattr(model, "velocities") else model.backend.U[0]})
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# schedules, callbacks, Simulation (host logic)
+# ----------------------------------------------------------------------------------------------------------------------
+class IterationInterval:
+    """IterationInterval(interval; offset = 0): actuates when (iteration - offset) % interval == 0 (Utils/schedules.jl:120-123)"""
+
+    def __init__(self, interval, offset=0):
+        self.interval, self.offset = int(interval), int(offset)
+
+    def initialize(self, model):
+        self(model)
+        return True
+
+    def __call__(self, model):
+        return (model.clock.iteration - self.offset) % self.interval == 0
+
+    def aligned_time_step(self, clock, Δt):
+        return Δt
+
+
+class TimeInterval:
+    """TimeInterval(interval): actuates every `interval` of model time; time steps are shortened to land on it (schedules.jl:30-93)"""
+
+    def __init__(self, interval):
+        self.interval, self.first_actuation_time, self.actuations = float(interval), 0.0, 0
+
+    def initialize(self, model):
+        self.first_actuation_time, self.actuations = model.clock.time, 0
+        return True
+
+    def next_actuation_time(self):
+        return self.first_actuation_time + (self.actuations + 1) * self.interval
+
+    def __call__(self, model):
+        if model.clock.time >= self.next_actuation_time():
+            self.actuations += 1
+            return True
+        return False
+
+    def aligned_time_step(self, clock, Δt):
+        return min(Δt, self.next_actuation_time() - clock.time)
+
+
+class Callback:
+    """Callback(func, schedule = IterationInterval(1); parameters = nothing): func(sim) or func(sim, parameters) (callback.jl)"""
+
+    def __init__(self, func, schedule=None, parameters=None):
+        self.func, self.schedule, self.parameters = func, schedule or IterationInterval(1), parameters
+
+    def __call__(self, sim):
+        return self.func(sim) if self.parameters is None else self.func(sim, self.parameters)
+
+
+def stop_iteration_exceeded(sim):
+    if sim.model.clock.iteration >= sim.stop_iteration:
+        sim.running = False
+
+
+def stop_time_exceeded(sim):
+    if sim.model.clock.time >= sim.stop_time:
+        sim.running = False
+
+
+def wall_time_limit_exceeded(sim):
+    if sim.run_wall_time >= sim.wall_time_limit:
+        sim.running = False
+
+
+class Simulation:
+    """Simulation(model; Δt, stop_iteration = Inf, stop_time = Inf, wall_time_limit = Inf, align_time_step = true,
+    minimum_relative_step = 0) (Simulations/simulation.jl:67-121). `callbacks` is an ordered dict of Callback; the three stop
+    criteria and the default NaN checker (every 100 iterations) are installed like the reference does."""
+
+    def __init__(self, model, Δt, stop_iteration=math.inf, stop_time=math.inf, wall_time_limit=math.inf, align_time_step=True,
+                 minimum_relative_step=0.0, verbose=False):
+        self.model, self.Δt = model, float(Δt)
+        self.stop_iteration, self.stop_time, self.wall_time_limit = float(stop_iteration), float(stop_time), float(wall_time_limit)
+        self.align_time_step, self.minimum_relative_step, self.verbose = bool(align_time_step), float(minimum_relative_step), verbose
+        self.run_wall_time, self.initialized, self.running = 0.0, False, False
+        self.callbacks = OrderedDict()
+        self.callbacks["stop_time_exceeded"] = Callback(stop_time_exceeded)
+        self.callbacks["stop_iteration_exceeded"] = Callback(stop_iteration_exceeded)
+        self.callbacks["wall_time_limit_exceeded"] = Callback(wall_time_limit_exceeded)
+        self.callbacks["nan_checker"] = Callback(default_nan_checker(model), IterationInterval(100))
+
+    # -- one time-step ---------------------------------------------------------------------------------------------
+    def aligned_time_step(self, Δt):
+        """aligned_time_step(sim, Δt) (run.jl:43-59): callbacks on a TimeInterval first, then the stop time (which wins)"""
+        clock = self.model.clock
+        aligned = Δt
+        for cb in self.callbacks.values():
+            aligned = cb.schedule.aligned_time_step(clock, aligned)
+        aligned = min(aligned, self.stop_time - clock.time)
+        return Δt if aligned <= 0 else aligned
+
+    def initialize(self):
+        """initialize!(sim) (run.jl:196-251): update_state!, schedules, callbacks at iteration 0"""
+        from .models import update_state
+        if hasattr(self.model, "handle"):
+            update_state(self.model, True)
+        for cb in self.callbacks.values():
+            cb.schedule.initialize(self.model)
+        if self.model.clock.iteration == 0:
+            for cb in self.callbacks.values():
+                cb(self)
+        self.initialized = True
+
+    def time_step(self, Δt=None):
+        """time_step!(sim) / time_step!(sim, Δt) (run.jl:113-174)"""
+        from .models import time_step as model_time_step
+        start = _time.perf_counter()
+        if Δt is not None:
+            self.Δt, self.align_time_step = float(Δt), False
+        Δt = self.aligned_time_step(self.Δt) if self.align_time_step else self.Δt
+        if not self.initialized:
+            self.initialize()
+        if Δt < self.minimum_relative_step * self.Δt:
+            raise NotImplementedError("skipping a tiny aligned time step needs a writable clock (minimum_relative_step > 0)")
+        if hasattr(self.model, "backend"):
+            from . import distributed
+            distributed.time_step(self.model, Δt)
+        else:
+            model_time_step(self.model, Δt)
+        for cb in self.callbacks.values():
+            if cb.schedule(self.model):
+                cb(self)
+        self.run_wall_time += _time.perf_counter() - start
+
+    def reset(self):
+        """reset!(sim) (simulation.jl:203-213)"""
+        _lib.check(_lib.lib().ocn_model_reset(self.model.handle))
+        self.stop_iteration = self.stop_time = self.wall_time_limit = math.inf
+        self.run_wall_time, self.initialized, self.running = 0.0, False, True
+
+
+def run(sim):
+    """run!(simulation) (run.jl:97-111): step until a stop criterion clears `running`"""
+    sim.initialized, sim.running, sim.run_wall_time = False, True, 0.0
+    while sim.running:
+        sim.time_step()
+
+
+def reset(sim):
+    sim.reset()

@@ -687,3 +687,56 @@ def test_ocean_wind_mixing_and_convection_physics_matches_oracle(ocn, oracle, ar
         ocn.time_step(m_ref, dt)
     dS = m_gpu.tracers.S.interior()[:, :, -1] - m_ref.tracers.S.interior()[:, :, -1]
     assert dS.min() > 0 and np.allclose(dS / m_ref.tracers.S.interior()[:, :, -1], 10 * dt * rate / float(g_gpu.Δzᵃᵃᶜ[-4]), rtol=0.3)   # advection / mixing move some of it
+
+
+def test_simulation_run_loop(ocn, arch):
+    """run_basic_simulation_tests (test/test_simulations.jl:77-150): stop criteria, run!, reset!, stop-time alignment, the wizard as a
+    callback; plus a TimeInterval callback whose actuation times the aligned time steps must hit"""
+    grid = ocn.RectilinearGrid(arch, size=(4, 4, 4), extent=(1, 1, 1))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=())
+    sim = ocn.Simulation(model, Δt=3, stop_iteration=1)
+    sim.running = True
+    ocn.stop_iteration_exceeded(sim)
+    assert sim.running
+    ocn.run(sim)
+    sim.running = True
+    ocn.stop_iteration_exceeded(sim)
+    assert not sim.running
+    assert np.isclose(model.clock.time, sim.Δt) and model.clock.iteration == 1 and sim.run_wall_time > 0
+    sim.running = True
+    ocn.stop_time_exceeded(sim)
+    assert sim.running
+    sim.stop_time = 1e-12
+    ocn.stop_time_exceeded(sim)
+    assert not sim.running
+    sim.running = True
+    ocn.wall_time_limit_exceeded(sim)
+    assert sim.running
+    sim.wall_time_limit = 1e-12
+    ocn.wall_time_limit_exceeded(sim)
+    assert not sim.running
+    # stops at stop_iteration
+    ocn.reset(sim)
+    assert model.clock.time == 0 and model.clock.iteration == 0 and model.clock.last_Δt == np.inf
+    sim.stop_iteration = 3
+    ocn.run(sim)
+    assert model.clock.iteration == 3
+    # stops at stop_time: the last step is shortened
+    ocn.reset(sim)
+    sim.stop_time = 20.20
+    ocn.run(sim)
+    assert np.isclose(model.clock.time, 20.20, rtol=1e-14) and model.clock.iteration == 7
+    # the wizard as a callback
+    ocn.reset(sim)
+    sim.stop_iteration = 2
+    sim.callbacks["wizard"] = ocn.Callback(ocn.TimeStepWizard(cfl=0.1), ocn.IterationInterval(1))
+    ocn.run(sim)
+    assert model.clock.iteration == 2
+    del sim.callbacks["wizard"]
+    # a callback on a TimeInterval: time steps land on its actuation times
+    ocn.reset(sim)
+    sim.Δt, sim.stop_time = 0.25, 2.0
+    times = []
+    sim.callbacks["record"] = ocn.Callback(lambda s: times.append(s.model.clock.time), ocn.TimeInterval(0.7))
+    ocn.run(sim)
+    assert np.allclose(times, [0.0, 0.7, 1.4], rtol=1e-14, atol=0) and np.isclose(model.clock.time, 2.0, rtol=1e-14)
