@@ -322,6 +322,15 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         KERNEL_CHECK();
         return OCN_OK;
     }
+    // an x-slab rank (x FullyConnected: its x halos come from the neighbours) with periodic y and z: the same kernel with no x slab
+    // -- H0 = 0, N0 = P0 makes every i its own source -- fills the y and z halos over the whole x extent in one launch
+    if (g_fused_halo && T[0] == OCN_CONNECTED && T[1] == OCN_PERIODIC && T[2] == OCN_PERIODIC && N[1] >= H[1] && N[2] >= H[2]) {
+        const long total = (long)P[0] * P[1] * (2 * H[2]) + (long)P[0] * (2 * H[1]) * N[2];
+        hipLaunchKernelGGL(fill_periodic_xyz_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, fl, P[0], P[1], P[2], P[0],
+                           N[1], N[2], 0, H[1], H[2]);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     for (int d = 2; d >= 0; --d) {
         if (T[d] != OCN_PERIODIC) continue;
         const int Pa = d == 0 ? P[1] : P[0], Pb = d == 2 ? P[1] : P[2];
