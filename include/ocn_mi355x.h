@@ -249,6 +249,11 @@ int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver);
  *   source_term -> forward_local -> [all_gather(gathered, payload)] -> backward_local -> phi.
  * Same solution as the transposed FFT solve to round-off. payload_size = 0: the solver transposes (stages above). */
 int ocn_dist_poisson_payload_size(ocn_dist_poisson_t solver, size_t *complex_elements);
+/* which local layout the substructured solve runs on (diagnostic): 2 = z-fastest real array, ONE 2-D (y, z) R2C / C2R plan batched over
+ * the local x index, spectrum already in the order of the Thomas sweeps (default); 1 = the same with 1-D plans (rocFFT refuses the
+ * 2-D interleaved-batch layout for some small sizes); 0 = paired real columns + Hermitian separation (option dist_zfirst = 0);
+ * -1 = transposing solver */
+int ocn_dist_poisson_layout(ocn_dist_poisson_t solver, int *layout);
 int ocn_dist_poisson_set_gather_buffers(ocn_dist_poisson_t solver, double *payload_complex, double *gathered_complex);
 int ocn_dist_poisson_forward_local(ocn_dist_poisson_t solver);
 int ocn_dist_poisson_backward_local(ocn_dist_poisson_t solver, double *phi);

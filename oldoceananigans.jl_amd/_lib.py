@@ -53,6 +53,7 @@ SYMBOLS = {
     "ocn_model_set_linear_flux_bc": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_char_p]),
     "ocn_make_pressure_correction_range": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _ip]),
     "ocn_model_reset": (C.c_int, [_vp]),
+    "ocn_dist_poisson_layout": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "ocn_hasnan": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int)]),
     "ocn_pack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "ocn_unpack_x_halos_depth": (C.c_int, [_vp, _pp, _vp, C.c_int, C.c_int, _vp, _vp]),

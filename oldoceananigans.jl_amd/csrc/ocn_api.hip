@@ -832,6 +832,7 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
+static int g_dist_zfirst = 1;          // substructured solve on the z-fastest layout (R2C along z); 0: paired-column layout
 
 struct ocn_poisson_s {
     ocn_grid_t grid;
@@ -1396,6 +1397,16 @@ struct ocn_dist_poisson_s {
     double2 *Y = nullptr, *iface = nullptr;
     double *rden = nullptr, *cpf = nullptr, *svec = nullptr;
     double2 *payload = nullptr, *gathered = nullptr;     // borrowed (host layer: torch tensors): 2M+1 and R*(2M+1) complex
+    // z-fastest variant of the substructured solve (option dist_zfirst): source term written z-fastest, unit-stride R2C along z, strided
+    // y transform whose output is already in the order the Thomas sweeps want -- no Hermitian separation / re-pairing passes
+    bool zfirst = false;
+    int Nzh = 0;
+    double *rreal = nullptr;    // (Nz, Nxl, Ny) real
+    double2 *spec = nullptr;    // (Nzh, Nxl, Ny) complex, modes m = kz + Nzh*ky
+    hipfftHandle plan_zr2c = 0, plan_zc2r = 0;       // 2-D (y, z) D2Z / Z2D, batched over the local x index (zf_2d) ...
+    hipfftHandle plan_y = 0;                         // ... or 1-D along z plus this strided 1-D y transform
+    bool zf_2d = false;
+    bool has_zf = false;
 };
 
 extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
@@ -1406,6 +1417,8 @@ extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     hipFree(s->Y); hipFree(s->iface); hipFree(s->rden); hipFree(s->cpf); hipFree(s->svec);
     hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
+    if (s->has_zf) { hipfftDestroy(s->plan_zr2c); hipfftDestroy(s->plan_zc2r); if (!s->zf_2d) hipfftDestroy(s->plan_y); }
+    hipFree(s->rreal); hipFree(s->spec);
     delete s;
     return OCN_OK;
 }
@@ -1485,7 +1498,97 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         }
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(local y/z) failed (%d)", (int)r); goto bad; }
         s->has_loc = true;
-        if (zmode == 0 && g_dist_substructured) {
+        if (zmode == 0 && g_dist_substructured && g_dist_zfirst) {
+            s->sub = true; s->zfirst = true;
+            s->Nzh = s->Nz / 2 + 1;
+            s->M = (long)s->Nzh * s->Ny;
+            const size_t slab = (size_t)s->M * s->Nxl;
+            TRY_OR_FREE(dev_alloc((void **)&s->rreal, (size_t)s->Nz * s->Nxl * s->Ny * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->spec, slab * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->rden, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->cpf, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->svec, slab * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->iface, (2 * (size_t)s->M + 2) * sizeof(double2)));
+            const double a = 1.0 / (g.dx * g.dx);
+            // mode m = kz + Nzh*ky: the setup kernel indexes its first eigenvalue array with m % n and the second with m / n
+            hipLaunchKernelGGL(sub_setup_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, (int)s->M, s->Nzh, s->Nxl, a,
+                               s->lam[2], s->lam[1], s->rden, s->cpf, s->svec, (double *)(s->iface + 2 * s->M + 1));
+            TRY_OR_FREE(hipGetLastError());
+            // ONE 2-D real plan over (y, z) per direction, the local x index as the batch in the middle of the layout: row pitch
+            // Nz*Nxl (Nzh*Nxl on the complex side), batch distance Nz (Nzh). As a 2-D plan rocFFT runs the strided y pass with its
+            // column kernel; the same pass as a 1-D strided plan gets the 3x slower row kernel (measured: 280 vs 90 us).
+            int nyz[2] = {s->Ny, s->Nz};
+            int remb[2] = {s->Ny, s->Nz * s->Nxl}, cemb[2] = {s->Ny, s->Nzh * s->Nxl};
+            hipfftResult rz = hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzh, HIPFFT_D2Z, s->Nxl);
+            if (rz == HIPFFT_SUCCESS) {
+                rz = hipfftPlanMany(&s->plan_zc2r, 2, nyz, cemb, 1, s->Nzh, remb, 1, s->Nz, HIPFFT_Z2D, s->Nxl);
+                if (rz != HIPFFT_SUCCESS) { hipfftDestroy(s->plan_zr2c); s->plan_zr2c = 0; }
+            }
+            s->zf_2d = rz == HIPFFT_SUCCESS;
+            if (!s->zf_2d) {
+                // rocFFT refuses the interleaved-batch 2-D layout for some (small) sizes: 1-D R2C along z + 1-D strided y transform
+                (void)hipGetLastError();
+                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny};
+                rz = hipfftPlanMany(&s->plan_zr2c, 1, nz1, nullptr, 1, s->Nz, nullptr, 1, s->Nzh, HIPFFT_D2Z, s->Nxl * s->Ny);
+                if (rz == HIPFFT_SUCCESS) rz = hipfftPlanMany(&s->plan_zc2r, 1, nz1, nullptr, 1, s->Nzh, nullptr, 1, s->Nz, HIPFFT_Z2D, s->Nxl * s->Ny);
+                if (rz == HIPFFT_SUCCESS)
+                    rz = hipfftPlanMany(&s->plan_y, 1, ny1, ny1, s->Nzh * s->Nxl, 1, ny1, s->Nzh * s->Nxl, 1, HIPFFT_Z2Z, s->Nzh * s->Nxl);
+                if (rz != HIPFFT_SUCCESS) { rc = fail(1000 + (int)rz, "hipfftPlanMany(z-fastest local transforms) failed (%d)", (int)rz); goto bad; }
+                if ((rc = plan_set_stream(s->plan_y))) goto bad;
+                if ((rc = verify_complex_plan(s->plan_y, s->spec, (long)slab, 1.0 / (double)s->Ny, "distributed y (z-fastest layout)"))) goto bad;
+            }
+            s->has_zf = true;
+            if ((rc = plan_set_stream(s->plan_zr2c)) || (rc = plan_set_stream(s->plan_zc2r))) goto bad;
+            if (s->zf_2d) {
+                // a round trip cannot tell a transform of a mis-read layout from the right one: check the 2-D plan's spectrum against
+                // plain 1-D plans once (pseudo-random data), then drop them
+                hipfftHandle pz = 0, py = 0;
+                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny};
+                double2 *ref = nullptr;
+                double *bm = nullptr;
+                const long nreal = (long)s->Nz * s->Nxl * s->Ny;
+                hipfftResult r1 = hipfftPlanMany(&pz, 1, nz1, nullptr, 1, s->Nz, nullptr, 1, s->Nzh, HIPFFT_D2Z, s->Nxl * s->Ny);
+                hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlanMany(&py, 1, ny1, ny1, s->Nzh * s->Nxl, 1, ny1, s->Nzh * s->Nxl, 1, HIPFFT_Z2Z, s->Nzh * s->Nxl) : r1;
+                bool ok = r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS && dev_alloc((void **)&ref, slab * sizeof(double2)) == hipSuccess &&
+                          dev_alloc((void **)&bm, 256 * sizeof(double)) == hipSuccess;
+                double err = -1.0;
+                if (ok) {
+                    hipfftSetStream(pz, g_stream); hipfftSetStream(py, g_stream);
+                    hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, g_stream, s->rreal, nreal);
+                    ok = hipfftExecD2Z(pz, s->rreal, (hipfftDoubleComplex *)ref) == HIPFFT_SUCCESS &&
+                         hipfftExecZ2Z(py, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, HIPFFT_FORWARD) == HIPFFT_SUCCESS &&
+                         hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec) == HIPFFT_SUCCESS;
+                    if (ok) {
+                        hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->spec,
+                                           2 * (long)slab, bm);
+                        ok = reduce_blockmax(bm, 256, &err) == OCN_OK;
+                    }
+                }
+                if (pz) hipfftDestroy(pz);
+                if (py) hipfftDestroy(py);
+                hipFree(ref); hipFree(bm);
+                if (!ok || !(err >= 0.0 && err < 1e-9 * (double)s->Ny * (double)s->Nz)) {
+                    rc = fail(OCN_EFFT, "the 2-D (y, z) real plan disagrees with 1-D plans (max difference %.3g): refusing it", err);
+                    goto bad;
+                }
+            }
+            {   // real pair: fill, R2C, C2R, compare
+                const long n = (long)s->Nz * s->Nxl * s->Ny;
+                const int nb = 256;
+                double *bm = nullptr;
+                TRY_OR_FREE(dev_alloc((void **)&bm, nb * sizeof(double)));
+                hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, s->rreal, n);
+                hipfftResult r1 = hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec);
+                if (r1 == HIPFFT_SUCCESS) r1 = hipfftExecZ2D(s->plan_zc2r, (hipfftDoubleComplex *)s->spec, s->rreal);
+                hipLaunchKernelGGL(selfcheck_compare_real, dim3(nb), dim3(256), 0, g_stream, s->rreal, s->Nz, s->Nxl, s->Ny, s->Nz, s->Nxl, 0, 0, 0,
+                                   s->zf_2d ? 1.0 / ((double)s->Nz * (double)s->Ny) : 1.0 / (double)s->Nz, bm);
+                double err = 0;
+                rc = r1 == HIPFFT_SUCCESS ? reduce_blockmax(bm, nb, &err) : fail(1000 + (int)r1, "hipFFT exec failed in the plan self-check (%d)", (int)r1);
+                hipFree(bm);
+                if (rc) goto bad;
+                if (!(err < 1e-10)) { rc = fail(OCN_EFFT, "rocFFT self-check failed for the (y, z) real transform pair (round-trip error %.3g)", err); goto bad; }
+            }
+        } else if (zmode == 0 && g_dist_substructured) {
             s->sub = true;
             s->M = (long)s->Nyh * s->Nz;
             const size_t slab = (size_t)s->M * s->Nxl;
@@ -1537,6 +1640,13 @@ extern "C" int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t s, size_t *comple
     return OCN_OK;
 }
 
+// 0: paired-column layout; 1: z-fastest layout with 1-D plans; 2: z-fastest layout with the 2-D (y, z) real plans; -1 transposing solver
+extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int *layout) {
+    if (!s || !layout) return fail(OCN_EINVAL, "NULL argument");
+    *layout = !s->sub ? -1 : (!s->zfirst ? 0 : (s->zf_2d ? 2 : 1));
+    return OCN_OK;
+}
+
 // substructured mode: complex elements of the per-rank payload (first / last value per mode + the null mode's sum); 0 otherwise
 extern "C" int ocn_dist_poisson_payload_size(ocn_dist_poisson_t s, size_t *complex_elements) {
     if (!s || !complex_elements) return fail(OCN_EINVAL, "NULL argument");
@@ -1557,13 +1667,25 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
     NEED_INIT();
     if (!s || !s->sub || !s->payload) return fail(OCN_EINVAL, "substructured solver / gather buffers not set");
     int rc;
+    const double a = 1.0 / (s->grid->d.dx * s->grid->d.dx);
+    if (s->zfirst) {
+        if ((rc = plan_set_stream(s->plan_zr2c))) return rc;
+        FFT_TRY(hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec));
+        if (!s->zf_2d) {
+            if ((rc = plan_set_stream(s->plan_y))) return rc;
+            FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_FORWARD));
+        }
+        hipLaunchKernelGGL(sub_thomas_kernel<true>, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf,
+                           s->spec, s->payload, s->Nzh);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     if ((rc = plan_set_stream(s->plan_loc))) return rc;
     FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
     const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
     hipLaunchKernelGGL(sub_separate_kernel, grd, blk, 0, g_stream, s->zfield, s->Y, s->Nxl, s->Nxh, s->Ny, s->Nyh, s->Nz);
-    const double a = 1.0 / (s->grid->d.dx * s->grid->d.dx);
-    hipLaunchKernelGGL(sub_thomas_kernel, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf, s->Y,
-                       s->payload);
+    hipLaunchKernelGGL(sub_thomas_kernel<false>, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf, s->Y,
+                       s->payload, 1);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -1577,8 +1699,24 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
     const double a = 1.0 / (g.dx * g.dx);
     hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Nyh, s->Nxl, s->R, s->rank,
                        a, s->lam[1], s->lam[2], s->svec, (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
-    const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
     const double scale = 1.0 / ((double)s->Ny * (double)s->Nz);
+    if (s->zfirst) {
+        const long total = s->M * s->Nxl;
+        hipLaunchKernelGGL(sub_correct_zfast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, s->spec, s->svec, s->iface,
+                           s->M, s->Nxl, s->Nzh, s->Ny, a, scale);
+        int rcz;
+        if (!s->zf_2d) {
+            if ((rcz = plan_set_stream(s->plan_y))) return rcz;
+            FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_BACKWARD));
+        }
+        if ((rcz = plan_set_stream(s->plan_zc2r))) return rcz;
+        FFT_TRY(hipfftExecZ2D(s->plan_zc2r, (hipfftDoubleComplex *)s->spec, s->rreal));
+        hipLaunchKernelGGL(copy_real_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
+                           make_view(g, phi, LOC_C), s->rreal);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
+    const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
     hipLaunchKernelGGL(sub_correct_combine_kernel, grd, blk, 0, g_stream, s->Y, s->svec, s->iface, s->zfield, s->Nxl, s->Nxh, s->Ny, s->Nyh,
                        s->Nz, a, scale);
     int rc;
@@ -1601,6 +1739,13 @@ extern "C" int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t s, double *send_c
 extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *u, const double *v, const double *w) {
     NEED_INIT();
     if (!s || !u || !v || !w) return fail(OCN_EINVAL, "NULL argument");
+    if (s->zfirst) {
+        const DGrid &g = s->grid->d;
+        hipLaunchKernelGGL(source_term_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
+                           make_view(g, u, LOC_U), make_view(g, v, LOC_V), make_view(g, w, LOC_W), s->rreal);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     return source_term(s->grid->d, u, v, w, s->zfield, s->zmode == 1, true, (long)s->Nxe * s->Nz, (long)s->Nxe, s->Nxe != s->Nxl);
 }
 
@@ -1843,6 +1988,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
     if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
     if (!strcmp(key, "dist_substructured")) { g_dist_substructured = value; return OCN_OK; }
+    if (!strcmp(key, "dist_zfirst")) { g_dist_zfirst = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

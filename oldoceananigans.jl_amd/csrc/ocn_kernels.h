@@ -1221,10 +1221,17 @@ __global__ void __launch_bounds__(256) sub_separate_kernel(const double2 *Z, dou
 }
 
 // Thomas sweeps along x for every mode (in place), then the payload: first / last value per mode and, for mode 0, the sum
+// ZF: the spectrum is stored z-fastest, Y[kz + Nzh*(i + N*ky)] with m = kz + Nzh*ky (what R2C along z + a strided y transform leave
+// behind); otherwise mode-fastest, Y[m + M*i]. The factor arrays are mode-fastest in both cases.
+template <bool ZF>
 __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a, const double *__restrict__ rden, const double *__restrict__ cp,
-                                                        double2 *__restrict__ Y, double2 *__restrict__ payload) {
+                                                        double2 *__restrict__ Yin, double2 *__restrict__ payload, int Nzh) {
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
+    // element (m, i) of the spectrum: base + stride * i
+    const long ybase = ZF ? (m % Nzh) + (long)Nzh * N * (m / Nzh) : m;
+    const long ystride = ZF ? (long)Nzh : M;
+    double2 *__restrict__ Y = Yin + ybase - m;          // so that Y[m + ystride * i] below is the element
     constexpr int TB = 8;
     double2 prev = make_double2(0.0, 0.0);
     for (int i0 = 0; i0 < N; i0 += TB) {
@@ -1232,12 +1239,12 @@ __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a,
         double d[TB];
 #pragma unroll
         for (int n = 0; n < TB; ++n)
-            if (i0 + n < N) { r[n] = Y[m + M * (i0 + n)]; d[n] = rden[m + M * (i0 + n)]; }
+            if (i0 + n < N) { r[n] = Y[m + ystride * (i0 + n)]; d[n] = rden[m + M * (i0 + n)]; }
 #pragma unroll
         for (int n = 0; n < TB; ++n)
             if (i0 + n < N) {
                 prev = make_double2((r[n].x - a * prev.x) * d[n], (r[n].y - a * prev.y) * d[n]);
-                Y[m + M * (i0 + n)] = prev;
+                Y[m + ystride * (i0 + n)] = prev;
             }
     }
     double2 sum = prev;                           // prev = y[N-1] is final already
@@ -1247,12 +1254,12 @@ __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a,
         double c[TB];
 #pragma unroll
         for (int n = 0; n < TB; ++n)
-            if (i0 - n >= 0) { y[n] = Y[m + M * (i0 - n)]; c[n] = cp[m + M * (i0 - n)]; }
+            if (i0 - n >= 0) { y[n] = Y[m + ystride * (i0 - n)]; c[n] = cp[m + M * (i0 - n)]; }
 #pragma unroll
         for (int n = 0; n < TB; ++n)
             if (i0 - n >= 0) {
                 prev = make_double2(y[n].x - c[n] * prev.x, y[n].y - c[n] * prev.y);
-                Y[m + M * (i0 - n)] = prev;
+                Y[m + ystride * (i0 - n)] = prev;
                 sum.x += prev.x; sum.y += prev.y;
             }
     }
@@ -1368,6 +1375,80 @@ __global__ void __launch_bounds__(256) sub_correct_combine_kernel(const double2 
             if (j != 0 && jm >= Nyh) Z[ih + (long)Nxh * (km + (long)Nz * jm)] = make_double2(A.x + B.y, B.x - A.y);
         }
     }
+}
+
+// z-fastest variant of the local stage (R2C along z, then y): p = (y - a gL s - a gR s[N-1-i] - mean[mode 0]) * scale, in place on
+// Y[kz + Nzh*(i + N*ky)]; one thread per element, mode m = kz + Nzh*ky
+__global__ void __launch_bounds__(256) sub_correct_zfast_kernel(double2 *Y, const double *svec, const double2 *iface, long M, int N, int Nzh,
+                                                                int Ny, double a, double scale) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * N) return;
+    const int kz = t % Nzh;
+    const long r = t / Nzh;
+    const int i = r % N, ky = r / N;
+    const long m = kz + (long)Nzh * ky;
+    const double2 gl = iface[m], gr = iface[M + m];
+    const double2 mu = m == 0 ? iface[2 * M] : make_double2(0.0, 0.0);
+    const double2 y = Y[t];
+    const double s0 = svec[m + M * i], s1 = svec[m + M * (N - 1 - i)];
+    Y[t] = make_double2((y.x - a * gl.x * s0 - a * gr.x * s1 - mu.x) * scale, (y.y - a * gl.y * s0 - a * gr.y * s1 - mu.y) * scale);
+    (void)Ny;
+}
+
+// compute_source_term! into a dense real array stored z-fastest, r[(k-1) + Nz*((i-1) + Nx*(j-1))] (the layout a unit-stride R2C along z
+// wants): the divergence is evaluated with threads along x (coalesced reads), transposed through an LDS tile and written with threads
+// along z. Same expression as source_term_kernel (weight_by_dz = false: z Periodic).
+__global__ void __launch_bounds__(256) source_term_zfast_kernel(DGrid g, FView u, FView v, FView w, double *r) {
+    __shared__ double tile[32][33];
+    const int i0 = 1 + blockIdx.x * 32, k0 = 1 + blockIdx.y * 32, j = 1 + blockIdx.z;
+    const int tx = threadIdx.x, ty = threadIdx.y;          // block (32, 8)
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int i = i0 + tx, k = k0 + kk;
+        if (i <= g.Nx && k <= g.Nz) {
+            const int kq = k - 1 + g.Hz;
+            const double ax = g.ax[kq], ay = g.ay[kq], az = g.az;
+            const double dx = ax * u.at(i + 1, j, k) - ax * u.at(i, j, k);
+            const double dy = ay * v.at(i, j + 1, k) - ay * v.at(i, j, k);
+            const double dz = az * w.at(i, j, k + 1) - az * w.at(i, j, k);
+            const double div = g.vinv_c[kq] * ((dx + dy) + dz);
+            tile[kk][tx] = 1.0 * div;
+        }
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {
+        const int k = k0 + tx, i = i0 + ii;
+        if (i <= g.Nx && k <= g.Nz) r[(long)(k - 1) + (long)g.Nz * ((i - 1) + (long)g.Nx * (j - 1))] = tile[tx][ii];
+    }
+}
+
+// the way back: dense z-fastest real array -> interior of the haloed (Center, Center, Center) field
+__global__ void __launch_bounds__(256) copy_real_zfast_kernel(DGrid g, FView p, const double *r) {
+    __shared__ double tile[32][33];
+    const int i0 = 1 + blockIdx.x * 32, k0 = 1 + blockIdx.y * 32, j = 1 + blockIdx.z;
+    const int tx = threadIdx.x, ty = threadIdx.y;
+    for (int ii = ty; ii < 32; ii += 8) {
+        const int k = k0 + tx, i = i0 + ii;
+        if (i <= g.Nx && k <= g.Nz) tile[ii][tx] = r[(long)(k - 1) + (long)g.Nz * ((i - 1) + (long)g.Nx * (j - 1))];
+    }
+    __syncthreads();
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int i = i0 + tx, k = k0 + kk;
+        if (i <= g.Nx && k <= g.Nz) p.at(i, j, k) = tile[tx][kk];
+    }
+}
+
+// per-block max |a - b| (plan cross-checks)
+__global__ void __launch_bounds__(256) max_abs_diff_kernel(const double *a, const double *b, long n, double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) m = fmax(m, fabs(a[q] - b[q]));
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
 }
 
 // deterministic two-stage sum of a complex array (for mean(ϕ)); stage 1: per-block partials, stage 2: one block.

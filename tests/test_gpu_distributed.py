@@ -334,3 +334,34 @@ def test_self_loop_rank_equals_single_gpu(ocn, arch, size, zkind, substructured)
     for name, a in out.items():
         err = np.abs(a[3:-3, 3:-3, 3:-3] - ref[name][3:-3, 3:-3, 3:-3]).max() / np.abs(ref[name]).max()
         assert err <= 1e-12, (name, err)
+
+
+def test_substructured_solver_layouts(ocn, arch):
+    """the three local layouts of the substructured x solve agree: z-fastest with the 2-D (y, z) real plan, z-fastest with 1-D plans
+    (what rocFFT leaves when it refuses the interleaved-batch 2-D layout), paired real columns (option dist_zfirst = 0)"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    outs, layouts = [], []
+    for size, zfirst in (((256, 24, 16), 1), ((256, 24, 16), 0), ((64, 24, 16), 1), ((64, 24, 16), 0)):
+        ocn.set_option("dist_zfirst", zfirst)
+        try:
+            ctx = dist.SelfLoopContext(0, 1, torch.device("cuda", 0), torch, None, arch)
+            grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0))
+            model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
+            lay = C.c_int()
+            _lib.check(_lib.lib().ocn_dist_poisson_layout(model.backend.solver, C.byref(lay)))
+            layouts.append(lay.value)
+            dist.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in model.fields().items()})
+            for _ in range(2):
+                dist.time_step(model, 0.1 * grid.local.Δxᶜᵃᵃ / 0.6)
+            outs.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressure.parent()})
+            model.backend.close()
+        finally:
+            ocn.set_option("dist_zfirst", 1)
+    assert layouts[1] == 0 and layouts[3] == 0 and layouts[0] in (1, 2) and layouts[2] in (1, 2)
+    for a, b in ((outs[0], outs[1]), (outs[2], outs[3])):
+        for name in a:
+            err = np.abs(a[name][3:-3, 3:-3, 3:-3] - b[name][3:-3, 3:-3, 3:-3]).max() / np.abs(b[name]).max()
+            assert err <= 1e-12, (name, err)
