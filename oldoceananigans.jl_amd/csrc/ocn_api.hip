@@ -832,6 +832,7 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
+static int g_dist_yline = 1;           // z Bounded: local y transform by strided_line_fft_kernel (Ny = 2^m <= 512) instead of rocFFT's 1-D strided plan
 static int g_dist_zfirst = 1;          // substructured solve on the z-fastest layout (R2C along z); 0: paired-column layout
 
 struct ocn_poisson_s {
@@ -1405,6 +1406,10 @@ struct ocn_dist_poisson_s {
     double2 *spec = nullptr;    // (Nzh, Nxl, Ny) complex, modes m = kz + Nzh*ky
     hipfftHandle plan_zr2c = 0, plan_zc2r = 0;       // 2-D (y, z) D2Z / Z2D, batched over the local x index (zf_2d) ...
     hipfftHandle plan_y = 0;                         // ... or 1-D along z plus this strided 1-D y transform
+    // z Bounded, Ny = 2^m <= 512: the local y transform by strided_line_fft_kernel instead of rocFFT's 1-D strided plan
+    bool yline = false;
+    int logn_y = 0;
+    double2 *ytw = nullptr;
     bool zf_2d = false;
     bool has_zf = false;
 };
@@ -1418,7 +1423,7 @@ extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     hipFree(s->D); hipFree(s->lower); hipFree(s->t);
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
     if (s->has_zf) { hipfftDestroy(s->plan_zr2c); hipfftDestroy(s->plan_zc2r); if (!s->zf_2d) hipfftDestroy(s->plan_y); }
-    hipFree(s->rreal); hipFree(s->spec);
+    hipFree(s->rreal); hipFree(s->spec); hipFree(s->ytw);
     delete s;
     return OCN_OK;
 }
@@ -1617,6 +1622,38 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if ((rc = plan_set_stream(s->plan_loc))) goto bad;
         const double sc = zmode == 0 ? 1.0 / ((double)s->Ny * s->Nz) : 1.0 / (double)s->Ny;
         if ((rc = verify_complex_plan(s->plan_loc, s->zfield, (long)s->nz_c, sc, "distributed local (y, z)"))) goto bad;
+        if (zmode == 1 && g_dist_yline && s->Ny >= 8 && s->Ny <= 512 && (s->Ny & (s->Ny - 1)) == 0) {
+            while ((1 << s->logn_y) < s->Ny) ++s->logn_y;
+            std::vector<double2> tw(s->Ny / 2);
+            for (int m = 0; m < s->Ny / 2; ++m) {
+                const double ang = -2.0 * M_PI * (double)m / (double)s->Ny;
+                tw[m] = make_double2(cos(ang), sin(ang));
+            }
+            TRY_OR_FREE(dev_alloc((void **)&s->ytw, tw.size() * sizeof(double2)));
+            TRY_OR_FREE(hipMemcpy(s->ytw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
+            // accept the kernel only if it reproduces the library transform on pseudo-random data (both directions)
+            double2 *ref = nullptr;
+            double *bm = nullptr;
+            TRY_OR_FREE(dev_alloc((void **)&ref, s->nz_c * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&bm, 256 * sizeof(double)));
+            const long C = (long)s->Nxh * s->Nz;
+            const dim3 grd((unsigned)((C + OCN_ZL - 1) / OCN_ZL));
+            const size_t lds = (size_t)s->Ny * OCN_ZL * sizeof(double2);
+            double err[2] = {-1.0, -1.0};
+            bool ok = true;
+            for (int dir = 0; dir < 2 && ok; ++dir) {
+                hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((s->nz_c + 255) / 256)), dim3(256), 0, g_stream, s->zfield, (long)s->nz_c);
+                ok = hipMemcpyAsync(ref, s->zfield, s->nz_c * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
+                     hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD) == HIPFFT_SUCCESS;
+                hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, dir, 1.0);
+                hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->zfield,
+                                   2 * (long)s->nz_c, bm);
+                ok = ok && reduce_blockmax(bm, 256, &err[dir]) == OCN_OK;
+            }
+            hipFree(ref); hipFree(bm);
+            s->yline = ok && err[0] >= 0 && err[1] >= 0 && err[0] < 1e-10 * s->Ny && err[1] < 1e-10 * s->Ny;
+            (void)hipGetLastError();
+        }
         if (!s->xfused && !s->sub) {
             int nx[1] = {s->Nxg};
             r = hipfftPlanMany(&s->plan_x, 1, nx, nullptr, 1, s->Nxg, nullptr, 1, s->Nxg, HIPFFT_Z2Z, s->Nyc * s->Nz);
@@ -1763,8 +1800,14 @@ extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s) {
     NEED_INIT();
     if (!s || !s->send) return fail(OCN_EINVAL, "solver / buffers not set");
     int rc;
-    if ((rc = plan_set_stream(s->plan_loc))) return rc;
-    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
+    if (s->yline) {
+        const long C = (long)s->Nxh * s->Nz;
+        hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256), (size_t)s->Ny * OCN_ZL * sizeof(double2),
+                           g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, 0, 1.0);
+    } else {
+        if ((rc = plan_set_stream(s->plan_loc))) return rc;
+        FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
+    }
     hipLaunchKernelGGL(dist_pack_forward_kernel, grid3(s->Nxh, s->Nyp, s->Nz, BLK), BLK, 0, g_stream, s->zfield, s->send, s->Nxl, s->Nxh,
                        s->Ny, s->Nyh, s->Nyc, s->Nyp, s->Nz, s->zmode == 0);
     KERNEL_CHECK();
@@ -1819,8 +1862,14 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
     int rc;
     hipLaunchKernelGGL(dist_combine_backward_kernel, grid3(s->Nxh, s->Ny, s->Nz, BLK), BLK, 0, g_stream, s->recv, s->zfield, s->Nxl, s->Nxh,
                        s->Ny, s->Nyh, s->Nyc, s->Nz, s->zmode == 0);
-    if ((rc = plan_set_stream(s->plan_loc))) return rc;
-    FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    if (s->yline) {
+        const long C = (long)s->Nxh * s->Nz;
+        hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256), (size_t)s->Ny * OCN_ZL * sizeof(double2),
+                           g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, 1, 1.0);
+    } else {
+        if ((rc = plan_set_stream(s->plan_loc))) return rc;
+        FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    }
     hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
                        (const double *)s->zfield, s->Nxe);
     KERNEL_CHECK();
@@ -1989,6 +2038,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
     if (!strcmp(key, "dist_substructured")) { g_dist_substructured = value; return OCN_OK; }
     if (!strcmp(key, "dist_zfirst")) { g_dist_zfirst = value; return OCN_OK; }
+    if (!strcmp(key, "dist_yline")) { g_dist_yline = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }

@@ -1051,6 +1051,93 @@ __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const dou
         for (int k = kq; k < Nz; k += 256 / OCN_ZL) hc[base + plane * k] = zbuf[k * OCN_ZL + il];
 }
 
+// One-directional FFT of length N = 2^logn along the SLOWEST dimension of a (C, N) complex array (element (c, n) at c + C*n): the
+// column transform rocFFT runs with its row kernel when it is planned as a 1-D strided transform (measured 129 us for 67 MB; this
+// kernel: the same LDS machinery as zline_solve_kernel, OCN_ZL consecutive lines = 128-B rows per workgroup).
+// forward: natural -> radix-4 DIF -> stored through the bit-reversal; inverse: loaded through the bit-reversal -> DIT -> natural,
+// times `scale`. Same arithmetic as rocFFT's to round-off, not bitwise.
+__global__ void __launch_bounds__(256) strided_line_fft_kernel(double2 *data, const double2 *tw, long C, int N, int logn, int inverse,
+                                                               double scale) {
+    extern __shared__ double2 zbuf[];                 // [N][OCN_ZL]
+    const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;
+    const long c = (long)blockIdx.x * OCN_ZL + il;
+    const bool live = c < C;
+    const int half = N >> 1, quarter = N >> 2, KQ = 256 / OCN_ZL;
+#define ZB(n) zbuf[(n) * OCN_ZL + il]
+#define CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)
+#define CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)
+    if (!inverse) {
+        for (int k = kq; k < N; k += KQ) zbuf[k * OCN_ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
+        __syncthreads();
+        int h = half, st = 1;
+        if (logn & 1) {
+            for (int q = kq; q < half; q += KQ) {
+                const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+                const double2 xa = ZB(a), xb = ZB(b), w = tw[jj * st];
+                ZB(a) = make_double2(xa.x + xb.x, xa.y + xb.y);
+                ZB(b) = CMUL(xa.x - xb.x, xa.y - xb.y, w);
+            }
+            __syncthreads();
+            h >>= 1; st <<= 1;
+        }
+        for (; h >= 2; h >>= 2, st <<= 2) {
+            const int h2 = h >> 1;
+            for (int q = kq; q < quarter; q += KQ) {
+                const int jj = q & (h2 - 1), a = ((q - jj) << 2) + jj;
+                const double2 x0 = ZB(a), x1 = ZB(a + h2), x2 = ZB(a + h), x3 = ZB(a + h + h2);
+                const double2 wa = tw[jj * st], wb = tw[(jj + h2) * st], wc = tw[jj * 2 * st];
+                const double2 y0 = make_double2(x0.x + x2.x, x0.y + x2.y), y2 = CMUL(x0.x - x2.x, x0.y - x2.y, wa);
+                const double2 y1 = make_double2(x1.x + x3.x, x1.y + x3.y), y3 = CMUL(x1.x - x3.x, x1.y - x3.y, wb);
+                ZB(a) = make_double2(y0.x + y1.x, y0.y + y1.y);
+                ZB(a + h2) = CMUL(y0.x - y1.x, y0.y - y1.y, wc);
+                ZB(a + h) = make_double2(y2.x + y3.x, y2.y + y3.y);
+                ZB(a + h + h2) = CMUL(y2.x - y3.x, y2.y - y3.y, wc);
+            }
+            __syncthreads();
+        }
+        if (live)
+            for (int p = kq; p < N; p += KQ) data[c + C * (long)(__brev((unsigned)p) >> (32 - logn))] = zbuf[p * OCN_ZL + il];
+    } else {
+        for (int k = kq; k < N; k += KQ)
+            zbuf[(int)(__brev((unsigned)k) >> (32 - logn)) * OCN_ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
+        __syncthreads();
+        int h = 1, st = half;
+        for (; (h << 1) <= half; h <<= 2, st >>= 2) {
+            for (int q = kq; q < quarter; q += KQ) {
+                const int jj = q & (h - 1), a = ((q - jj) << 2) + jj;
+                const double2 x0 = ZB(a), x1 = ZB(a + h), x2 = ZB(a + 2 * h), x3 = ZB(a + 3 * h);
+                const double2 wa = tw[jj * st], wb = tw[jj * (st >> 1)], wc = tw[(jj + h) * (st >> 1)];
+                const double2 t1 = CMULC(x1, wa), t3 = CMULC(x3, wa);
+                const double2 y0 = make_double2(x0.x + t1.x, x0.y + t1.y), y1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+                const double2 y2 = make_double2(x2.x + t3.x, x2.y + t3.y), y3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+                const double2 u2 = CMULC(y2, wb), u3 = CMULC(y3, wc);
+                ZB(a) = make_double2(y0.x + u2.x, y0.y + u2.y);
+                ZB(a + 2 * h) = make_double2(y0.x - u2.x, y0.y - u2.y);
+                ZB(a + h) = make_double2(y1.x + u3.x, y1.y + u3.y);
+                ZB(a + 3 * h) = make_double2(y1.x - u3.x, y1.y - u3.y);
+            }
+            __syncthreads();
+        }
+        if (h <= half) {
+            for (int q = kq; q < half; q += KQ) {
+                const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+                const double2 xa = ZB(a), t = CMULC(ZB(b), tw[jj * st]);
+                ZB(a) = make_double2(xa.x + t.x, xa.y + t.y);
+                ZB(b) = make_double2(xa.x - t.x, xa.y - t.y);
+            }
+            __syncthreads();
+        }
+        if (live)
+            for (int k = kq; k < N; k += KQ) {
+                const double2 v = zbuf[k * OCN_ZL + il];
+                data[c + C * k] = make_double2(v.x * scale, v.y * scale);
+            }
+    }
+#undef ZB
+#undef CMUL
+#undef CMULC
+}
+
 // The x stage of the distributed FFT solve in ONE pass (distributed_fft_based_poisson_solver.jl:152-166 with the transposes'
 // unpack / pack folded in): a workgroup gathers L whole x-lines (length Nxg = R * Nxl, a power of two) from the all-to-all
 // receive buffer -- chunk p holds columns [p*Nxl, (p+1)*Nxl) of every line (il fastest) --, transforms them forward (radix-4
