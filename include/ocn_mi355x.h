@@ -249,8 +249,9 @@ int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t solver);
  *   source_term -> forward_local -> [all_gather(gathered, payload)] -> backward_local -> phi.
  * Same solution as the transposed FFT solve to round-off. payload_size = 0: the solver transposes (stages above). */
 int ocn_dist_poisson_payload_size(ocn_dist_poisson_t solver, size_t *complex_elements);
-/* which local layout the substructured solve runs on (diagnostic): 2 = z-fastest real array, ONE 2-D (y, z) R2C / C2R plan batched over
- * the local x index, spectrum already in the order of the Thomas sweeps (default); 1 = the same with 1-D plans (rocFFT refuses the
+/* which local layout the substructured solve runs on (diagnostic): 3 = z-fastest real array, 1-D R2C / C2R plans along z and the y
+ * pass by the library's own LDS column-FFT kernel (Ny = 2^m <= 512; default); 2 = z-fastest real array, ONE 2-D (y, z) R2C / C2R plan batched over
+ * the local x index, spectrum already in the order of the Thomas sweeps; 1 = the same with 1-D plans (rocFFT refuses the
  * 2-D interleaved-batch layout for some small sizes); 0 = paired real columns + Hermitian separation (option dist_zfirst = 0);
  * -1 = transposing solver */
 int ocn_dist_poisson_layout(ocn_dist_poisson_t solver, int *layout);

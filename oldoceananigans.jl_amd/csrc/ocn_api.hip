@@ -1524,7 +1524,11 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
             // column kernel; the same pass as a 1-D strided plan gets the 3x slower row kernel (measured: 280 vs 90 us).
             int nyz[2] = {s->Ny, s->Nz};
             int remb[2] = {s->Ny, s->Nz * s->Nxl}, cemb[2] = {s->Ny, s->Nzh * s->Nxl};
-            hipfftResult rz = hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzh, HIPFFT_D2Z, s->Nxl);
+            // ... unless Ny = 2^m <= 512: then the y pass is strided_line_fft_kernel (3x faster again than the column kernel of the 2-D
+            // plan) next to plain 1-D plans along z
+            const bool want_yline = g_dist_yline && s->Ny >= 8 && s->Ny <= 512 && (s->Ny & (s->Ny - 1)) == 0;
+            hipfftResult rz = want_yline ? HIPFFT_NOT_SUPPORTED
+                                         : hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzh, HIPFFT_D2Z, s->Nxl);
             if (rz == HIPFFT_SUCCESS) {
                 rz = hipfftPlanMany(&s->plan_zc2r, 2, nyz, cemb, 1, s->Nzh, remb, 1, s->Nz, HIPFFT_Z2D, s->Nxl);
                 if (rz != HIPFFT_SUCCESS) { hipfftDestroy(s->plan_zr2c); s->plan_zr2c = 0; }
@@ -1541,6 +1545,37 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
                 if (rz != HIPFFT_SUCCESS) { rc = fail(1000 + (int)rz, "hipfftPlanMany(z-fastest local transforms) failed (%d)", (int)rz); goto bad; }
                 if ((rc = plan_set_stream(s->plan_y))) goto bad;
                 if ((rc = verify_complex_plan(s->plan_y, s->spec, (long)slab, 1.0 / (double)s->Ny, "distributed y (z-fastest layout)"))) goto bad;
+                if (want_yline) {
+                    while ((1 << s->logn_y) < s->Ny) ++s->logn_y;
+                    std::vector<double2> tw(s->Ny / 2);
+                    for (int m = 0; m < s->Ny / 2; ++m) {
+                        const double ang = -2.0 * M_PI * (double)m / (double)s->Ny;
+                        tw[m] = make_double2(cos(ang), sin(ang));
+                    }
+                    TRY_OR_FREE(dev_alloc((void **)&s->ytw, tw.size() * sizeof(double2)));
+                    TRY_OR_FREE(hipMemcpy(s->ytw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
+                    double2 *ref = nullptr;
+                    double *bm = nullptr;
+                    TRY_OR_FREE(dev_alloc((void **)&ref, slab * sizeof(double2)));
+                    TRY_OR_FREE(dev_alloc((void **)&bm, 256 * sizeof(double)));
+                    const long C = (long)s->Nzh * s->Nxl;
+                    const dim3 grd((unsigned)((C + OCN_ZL - 1) / OCN_ZL));
+                    const size_t lds = (size_t)s->Ny * OCN_ZL * sizeof(double2);
+                    double err[2] = {-1.0, -1.0};
+                    bool ok = true;
+                    for (int dir = 0; dir < 2 && ok; ++dir) {      // accept the kernel only if it reproduces the library transform
+                        hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, g_stream, s->spec, (long)slab);
+                        ok = hipMemcpyAsync(ref, s->spec, slab * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
+                             hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD) == HIPFFT_SUCCESS;
+                        hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, dir, 1.0);
+                        hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->spec,
+                                           2 * (long)slab, bm);
+                        ok = ok && reduce_blockmax(bm, 256, &err[dir]) == OCN_OK;
+                    }
+                    hipFree(ref); hipFree(bm);
+                    s->yline = ok && err[0] >= 0 && err[1] >= 0 && err[0] < 1e-10 * s->Ny && err[1] < 1e-10 * s->Ny;
+                    (void)hipGetLastError();
+                }
             }
             s->has_zf = true;
             if ((rc = plan_set_stream(s->plan_zr2c)) || (rc = plan_set_stream(s->plan_zc2r))) goto bad;
@@ -1680,7 +1715,7 @@ extern "C" int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t s, size_t *comple
 // 0: paired-column layout; 1: z-fastest layout with 1-D plans; 2: z-fastest layout with the 2-D (y, z) real plans; -1 transposing solver
 extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int *layout) {
     if (!s || !layout) return fail(OCN_EINVAL, "NULL argument");
-    *layout = !s->sub ? -1 : (!s->zfirst ? 0 : (s->zf_2d ? 2 : 1));
+    *layout = !s->sub ? -1 : (!s->zfirst ? 0 : (s->yline ? 3 : (s->zf_2d ? 2 : 1)));
     return OCN_OK;
 }
 
@@ -1708,7 +1743,11 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
     if (s->zfirst) {
         if ((rc = plan_set_stream(s->plan_zr2c))) return rc;
         FFT_TRY(hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec));
-        if (!s->zf_2d) {
+        if (s->yline) {
+            const long C = (long)s->Nzh * s->Nxl;
+            hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
+                               (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 0, 1.0);
+        } else if (!s->zf_2d) {
             if ((rc = plan_set_stream(s->plan_y))) return rc;
             FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_FORWARD));
         }
@@ -1742,7 +1781,11 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
         hipLaunchKernelGGL(sub_correct_zfast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, s->spec, s->svec, s->iface,
                            s->M, s->Nxl, s->Nzh, s->Ny, a, scale);
         int rcz;
-        if (!s->zf_2d) {
+        if (s->yline) {
+            const long C = (long)s->Nzh * s->Nxl;
+            hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
+                               (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 1, 1.0);
+        } else if (!s->zf_2d) {
             if ((rcz = plan_set_stream(s->plan_y))) return rcz;
             FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_BACKWARD));
         }
