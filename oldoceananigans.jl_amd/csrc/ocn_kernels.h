@@ -746,6 +746,28 @@ __global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView
     w.at(i, j, k) -= (g.tz == OCN_FLAT ? 0.0 : pc - p.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz];
 }
 
+// _make_pressure_correction! and `pNHS ./= Δt⁺` in one pass, with the pressure read from the DENSE real array the inverse transform
+// leaves (x, y Periodic: the lower neighbours wrap; z Periodic wraps, z Bounded has p[0] = p[1] -- the no-flux halo -- so the
+// bottom face keeps its w). The haloed pressure field receives p / Δt⁺. Same expressions as pressure_correction_kernel +
+// divide_interior_kernel.
+__global__ void __launch_bounds__(256) pressure_correction_dense_kernel(DGrid g, FView u, FView v, FView w, const double *pd, FView p,
+                                                                        double divisor, bool zbounded) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const long sx = g.Nx, sxy = (long)g.Nx * g.Ny;
+    const long q = (long)(i - 1) + sx * (j - 1) + sxy * (k - 1);
+    const double pc = pd[q];
+    const double pim = pd[i == 1 ? q + (g.Nx - 1) : q - 1];
+    const double pjm = pd[j == 1 ? q + sx * (g.Ny - 1) : q - sx];
+    const double pkm = k == 1 ? (zbounded ? pc : pd[q + sxy * (g.Nz - 1)]) : pd[q - sxy];
+    u.at(i, j, k) -= (pc - pim) * g.rdx;
+    v.at(i, j, k) -= (pc - pjm) * g.rdy;
+    w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
+    p.at(i, j, k) = pc / divisor;
+}
+
 __global__ void __launch_bounds__(256) divide_interior_kernel(DGrid g, FView p, double divisor) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -1057,8 +1079,9 @@ __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const dou
 // forward: natural -> radix-4 DIF -> stored through the bit-reversal; inverse: loaded through the bit-reversal -> DIT -> natural,
 // times `scale`. Same arithmetic as rocFFT's to round-off, not bitwise.
 __global__ void __launch_bounds__(256) strided_line_fft_kernel(double2 *data, const double2 *tw, long C, int N, int logn, int inverse,
-                                                               double scale) {
+                                                               double scale, long plane_stride = 0) {
     extern __shared__ double2 zbuf[];                 // [N][OCN_ZL]
+    data += plane_stride * blockIdx.y;                // gridDim.y independent (C, N) arrays `plane_stride` elements apart
     const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;
     const long c = (long)blockIdx.x * OCN_ZL + il;
     const bool live = c < C;
