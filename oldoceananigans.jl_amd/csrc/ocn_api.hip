@@ -861,6 +861,7 @@ struct ocn_poisson_s {
     // pass by strided_line_fft_kernel (61 us against the 82 us of the 2-D plan's column kernel); the inverse lands in the dense
     // real array, which pressure_correction_dense_kernel reads directly
     bool split = false;
+    int Nxp = 0;                 // row pitch (complex elements) of hc / hc2 on the split path: Nxh rounded up to a multiple of 8
     hipfftHandle plan_xr2c = 0, plan_xc2r = 0;
     int logn_y = 0;
     double2 *ytw = nullptr;
@@ -1120,10 +1121,14 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
         // ---- real-transform path (the complex-to-complex resources of the reference API are created on first use) ----
         s->Nxh = g.Nx / 2 + 1;
         s->nh = (size_t)s->Nxh * g.Ny * g.Nz;
+        s->Nxp = (s->Nxh + 7) & ~7;                          // row pitch of the split path: whole 128-B rows
+        const size_t nh_alloc = (size_t)s->Nxp * g.Ny * g.Nz;
         TRY_OR_FREE(dev_alloc((void **)&s->rrhs, s->n * sizeof(double)));
-        TRY_OR_FREE(dev_alloc((void **)&s->hc, s->nh * sizeof(double2)));
+        TRY_OR_FREE(dev_alloc((void **)&s->hc, nh_alloc * sizeof(double2)));
+        TRY_OR_FREE(hipMemset(s->hc, 0, nh_alloc * sizeof(double2)));
         if (kind == 1) {
-            TRY_OR_FREE(dev_alloc((void **)&s->hc2, s->nh * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->hc2, nh_alloc * sizeof(double2)));
+            TRY_OR_FREE(hipMemset(s->hc2, 0, nh_alloc * sizeof(double2)));
             TRY_OR_FREE(hipMemset(s->hc2, 0, s->nh * sizeof(double2)));
         }
         const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
@@ -1169,8 +1174,9 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
         if (g_split_solve && (kind == 1 || s->zfused) && g.Ny >= 8 && g.Ny <= 512 && (g.Ny & (g.Ny - 1)) == 0 && g.tx == OCN_PERIODIC &&
             g.ty == OCN_PERIODIC) {
             int nx1[1] = {g.Nx};
-            hipfftResult r1 = hipfftPlanMany(&s->plan_xr2c, 1, nx1, nullptr, 1, g.Nx, nullptr, 1, s->Nxh, HIPFFT_D2Z, g.Ny * g.Nz);
-            hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlanMany(&s->plan_xc2r, 1, nx1, nullptr, 1, s->Nxh, nullptr, 1, g.Nx, HIPFFT_Z2D, g.Ny * g.Nz) : r1;
+            int rembx[1] = {g.Nx}, cembx[1] = {s->Nxp};
+            hipfftResult r1 = hipfftPlanMany(&s->plan_xr2c, 1, nx1, rembx, 1, g.Nx, cembx, 1, s->Nxp, HIPFFT_D2Z, g.Ny * g.Nz);
+            hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlanMany(&s->plan_xc2r, 1, nx1, cembx, 1, s->Nxp, rembx, 1, g.Nx, HIPFFT_Z2D, g.Ny * g.Nz) : r1;
             if (r1 == HIPFFT_SUCCESS && r2 != HIPFFT_SUCCESS) hipfftDestroy(s->plan_xr2c);
             if (r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS) {
                 hipfftSetStream(s->plan_xr2c, g_stream); hipfftSetStream(s->plan_xc2r, g_stream);
@@ -1189,18 +1195,18 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
                 if (ok) {
                     // forward: the split form against the library's 2-D plan on pseudo-random data; inverse: round trip of the split form
                     const long n = (long)s->n;
-                    const dim3 grd((unsigned)((s->Nxh + OCN_ZL - 1) / OCN_ZL), (unsigned)g.Nz);
+                    const dim3 grd((unsigned)(s->Nxp / OCN_ZL), (unsigned)g.Nz);
                     const size_t lds = (size_t)g.Ny * OCN_ZL * sizeof(double2);
                     hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, s->rrhs, n);
                     ok = hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)ref) == HIPFFT_SUCCESS &&
                          hipfftExecD2Z(s->plan_xr2c, s->rrhs, (hipfftDoubleComplex *)s->hc) == HIPFFT_SUCCESS;
-                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxh, g.Ny, s->logn_y, 0, 1.0,
-                                       (long)s->Nxh * g.Ny);
-                    hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->hc,
-                                       2 * (long)s->nh, bm);
+                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 0, 1.0,
+                                       (long)s->Nxp * g.Ny);
+                    hipLaunchKernelGGL(max_abs_diff_pitched_kernel, dim3(256), dim3(256), 0, g_stream, (const double2 *)ref, s->Nxh,
+                                       (const double2 *)s->hc, s->Nxp, s->Nxh, (long)g.Ny * g.Nz, bm);
                     ok = ok && reduce_blockmax(bm, 256, &e_fwd) == OCN_OK;
-                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxh, g.Ny, s->logn_y, 1, 1.0,
-                                       (long)s->Nxh * g.Ny);
+                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 1, 1.0,
+                                       (long)s->Nxp * g.Ny);
                     ok = ok && hipfftExecZ2D(s->plan_xc2r, (hipfftDoubleComplex *)s->hc, s->rrhs) == HIPFFT_SUCCESS;
                     hipLaunchKernelGGL(selfcheck_compare_real, dim3(256), dim3(256), 0, g_stream, s->rrhs, g.Nx, g.Ny, g.Nz, g.Nx, g.Ny, 0, 0, 0,
                                        1.0 / ((double)g.Nx * g.Ny), bm);
@@ -1329,25 +1335,25 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
 static int poisson_solve_real_split(ocn_poisson_s *s) {
     const DGrid &g = s->grid->d;
     { int rc_; if ((rc_ = plan_set_stream(s->plan_xr2c)) || (rc_ = plan_set_stream(s->plan_xc2r))) return rc_; }
-    const dim3 grd((unsigned)((s->Nxh + OCN_ZL - 1) / OCN_ZL), (unsigned)g.Nz);
+    const dim3 grd((unsigned)(s->Nxp / OCN_ZL), (unsigned)g.Nz);       // rows of pitch Nxp: whole, 128-B aligned 8-line groups
     const size_t lds = (size_t)g.Ny * OCN_ZL * sizeof(double2);
     FFT_TRY(hipfftExecD2Z(s->plan_xr2c, s->rrhs, (hipfftDoubleComplex *)s->hc));
-    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxh, g.Ny, s->logn_y, 0, 1.0,
-                       (long)s->Nxh * g.Ny);
+    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 0, 1.0,
+                       (long)s->Nxp * g.Ny);
     double2 *sol = s->hc;
     if (s->kind == 0) {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
         hipLaunchKernelGGL(zline_solve_kernel, dim3((s->Nxh + OCN_ZL - 1) / OCN_ZL, g.Ny), dim3(256), (size_t)g.Nz * OCN_ZL * sizeof(double2),
-                           g_stream, s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale);
+                           g_stream, s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale, s->Nxp);
     } else {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
         hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((s->Nxh + 63) / 64, g.Ny), dim3(64), 0, g_stream, s->Nxh, g.Nx, g.Ny, g.Nz,
-                           s->lower, s->D, s->lower, s->hc, s->t, s->hc2, scale, true);
-        hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, g_stream, s->hc2, (long)s->Nxh * g.Ny, g.Nz);
+                           s->lower, s->D, s->lower, s->hc, s->t, s->hc2, scale, true, s->Nxp);
+        hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, g_stream, s->hc2, (long)s->Nxp * g.Ny, g.Nz);
         sol = s->hc2;
     }
-    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, sol, s->ytw, (long)s->Nxh, g.Ny, s->logn_y, 1, 1.0,
-                       (long)s->Nxh * g.Ny);
+    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, sol, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 1, 1.0,
+                       (long)s->Nxp * g.Ny);
     FFT_TRY(hipfftExecZ2D(s->plan_xc2r, (hipfftDoubleComplex *)sol, s->rrhs));
     KERNEL_CHECK();
     return OCN_OK;

@@ -821,12 +821,13 @@ __global__ void __launch_bounds__(256) copy_real_kernel(DGrid g, FView phi, cons
 __global__ void __launch_bounds__(64) tridiagonal_z_kernel(int Nxs, int ldb, int Ny, int Nz, const double *__restrict__ a,
                                                            const double *__restrict__ b, const double *__restrict__ c,
                                                            const double2 *__restrict__ f, double *__restrict__ t,
-                                                           double2 *__restrict__ phi, double fscale, bool apply_scale) {
+                                                           double2 *__restrict__ phi, double fscale, bool apply_scale, int ldf = 0) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y;
     if (i >= Nxs || j >= Ny) return;
-    const long st = (long)Nxs * Ny, stb = (long)ldb * Ny;
-    long q = (long)i + (long)Nxs * j, qb = (long)i + (long)ldb * j;
+    const int ldx = ldf > 0 ? ldf : Nxs;              // row pitch of f / phi
+    const long st = (long)ldx * Ny, stb = (long)ldb * Ny;
+    long q = (long)i + (long)ldx * j, qb = (long)i + (long)ldb * j;
     double beta = b[qb];
     double2 f1 = f[q];
     if (apply_scale) { f1.x *= fscale; f1.y *= fscale; }
@@ -984,13 +985,14 @@ __global__ void __launch_bounds__(256) line_scatter_kernel(const double2 *B, dou
 // ---------------------------------------------------------------------------------------------------------------------
 #define OCN_ZL 8
 __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const double2 *tw, const double *lx, const double *ly,
-                                                          const double *lz, int Nxs, int Ny, int Nz, int logn, double scale) {
+                                                          const double *lz, int Nxs, int Ny, int Nz, int logn, double scale, int pitch = 0) {
     extern __shared__ double2 zbuf[];                 // [Nz][OCN_ZL]
     const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;       // 32 k-rows per pass
     const int i0 = blockIdx.x * OCN_ZL, j = blockIdx.y;
     const int i = i0 + il;
     const bool live = i < Nxs;
-    const long plane = (long)Nxs * Ny, base = (long)i + (long)Nxs * j;
+    const int ldx = pitch > 0 ? pitch : Nxs;          // row pitch of the spectrum (>= Nxs: padded to whole 128-B rows on the split path)
+    const long plane = (long)ldx * Ny, base = (long)i + (long)ldx * j;
     for (int k = kq; k < Nz; k += 256 / OCN_ZL) zbuf[k * OCN_ZL + il] = live ? hc[base + plane * k] : make_double2(0.0, 0.0);
     __syncthreads();
     const int half = Nz >> 1, quarter = Nz >> 2, KQ = 256 / OCN_ZL;
@@ -1552,6 +1554,27 @@ __global__ void __launch_bounds__(256) max_abs_diff_kernel(const double *a, cons
     __shared__ double sm[256];
     double m = 0;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long)gridDim.x * blockDim.x) m = fmax(m, fabs(a[q] - b[q]));
+    sm[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = sm[0];
+}
+
+// the same for two row-major complex arrays of `n0` columns and `rows` rows with different row pitches
+__global__ void __launch_bounds__(256) max_abs_diff_pitched_kernel(const double2 *a, int pa, const double2 *b, int pb, int n0, long rows,
+                                                                   double *blockmax) {
+    __shared__ double sm[256];
+    double m = 0;
+    const long total = (long)n0 * rows;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const long r = q / n0;
+        const int c = q - r * n0;
+        const double2 x = a[c + (long)pa * r], y = b[c + (long)pb * r];
+        m = fmax(m, fmax(fabs(x.x - y.x), fabs(x.y - y.y)));
+    }
     sm[threadIdx.x] = m;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
