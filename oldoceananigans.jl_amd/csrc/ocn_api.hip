@@ -1491,9 +1491,9 @@ struct ocn_dist_poisson_s {
     // z-fastest variant of the substructured solve (option dist_zfirst): source term written z-fastest, unit-stride R2C along z, strided
     // y transform whose output is already in the order the Thomas sweeps want -- no Hermitian separation / re-pairing passes
     bool zfirst = false;
-    int Nzh = 0;
+    int Nzh = 0, Nzp = 0;       // modes along z (Nz/2 + 1) and the row pitch they are stored with (multiple of 8: whole 128-B lines)
     double *rreal = nullptr;    // (Nz, Nxl, Ny) real
-    double2 *spec = nullptr;    // (Nzh, Nxl, Ny) complex, modes m = kz + Nzh*ky
+    double2 *spec = nullptr;    // (Nzp, Nxl, Ny) complex, modes m = kz + Nzh*ky at [kz + Nzp*(i + Nxl*ky)]
     hipfftHandle plan_zr2c = 0, plan_zc2r = 0;       // 2-D (y, z) D2Z / Z2D, batched over the local x index (zf_2d) ...
     hipfftHandle plan_y = 0;                         // ... or 1-D along z plus this strided 1-D y transform
     // z Bounded, Ny = 2^m <= 512: the local y transform by strided_line_fft_kernel instead of rocFFT's 1-D strided plan
@@ -1596,10 +1596,13 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if (zmode == 0 && g_dist_substructured && g_dist_zfirst) {
             s->sub = true; s->zfirst = true;
             s->Nzh = s->Nz / 2 + 1;
+            s->Nzp = (s->Nzh + 7) & ~7;
             s->M = (long)s->Nzh * s->Ny;
-            const size_t slab = (size_t)s->M * s->Nxl;
+            const size_t slab = (size_t)s->M * s->Nxl;                       // factor arrays: mode-fastest, unpadded
+            const size_t pslab = (size_t)s->Nzp * s->Nxl * s->Ny;            // the spectrum itself: padded rows
             TRY_OR_FREE(dev_alloc((void **)&s->rreal, (size_t)s->Nz * s->Nxl * s->Ny * sizeof(double)));
-            TRY_OR_FREE(dev_alloc((void **)&s->spec, slab * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->spec, pslab * sizeof(double2)));
+            TRY_OR_FREE(hipMemset(s->spec, 0, pslab * sizeof(double2)));
             TRY_OR_FREE(dev_alloc((void **)&s->rden, slab * sizeof(double)));
             TRY_OR_FREE(dev_alloc((void **)&s->cpf, slab * sizeof(double)));
             TRY_OR_FREE(dev_alloc((void **)&s->svec, slab * sizeof(double)));
@@ -1613,28 +1616,28 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
             // Nz*Nxl (Nzh*Nxl on the complex side), batch distance Nz (Nzh). As a 2-D plan rocFFT runs the strided y pass with its
             // column kernel; the same pass as a 1-D strided plan gets the 3x slower row kernel (measured: 280 vs 90 us).
             int nyz[2] = {s->Ny, s->Nz};
-            int remb[2] = {s->Ny, s->Nz * s->Nxl}, cemb[2] = {s->Ny, s->Nzh * s->Nxl};
+            int remb[2] = {s->Ny, s->Nz * s->Nxl}, cemb[2] = {s->Ny, s->Nzp * s->Nxl};
             // ... unless Ny = 2^m <= 512: then the y pass is strided_line_fft_kernel (3x faster again than the column kernel of the 2-D
             // plan) next to plain 1-D plans along z
             const bool want_yline = g_dist_yline && s->Ny >= 8 && s->Ny <= 512 && (s->Ny & (s->Ny - 1)) == 0;
             hipfftResult rz = want_yline ? HIPFFT_NOT_SUPPORTED
-                                         : hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzh, HIPFFT_D2Z, s->Nxl);
+                                         : hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzp, HIPFFT_D2Z, s->Nxl);
             if (rz == HIPFFT_SUCCESS) {
-                rz = hipfftPlanMany(&s->plan_zc2r, 2, nyz, cemb, 1, s->Nzh, remb, 1, s->Nz, HIPFFT_Z2D, s->Nxl);
+                rz = hipfftPlanMany(&s->plan_zc2r, 2, nyz, cemb, 1, s->Nzp, remb, 1, s->Nz, HIPFFT_Z2D, s->Nxl);
                 if (rz != HIPFFT_SUCCESS) { hipfftDestroy(s->plan_zr2c); s->plan_zr2c = 0; }
             }
             s->zf_2d = rz == HIPFFT_SUCCESS;
             if (!s->zf_2d) {
                 // rocFFT refuses the interleaved-batch 2-D layout for some (small) sizes: 1-D R2C along z + 1-D strided y transform
                 (void)hipGetLastError();
-                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny};
-                rz = hipfftPlanMany(&s->plan_zr2c, 1, nz1, nullptr, 1, s->Nz, nullptr, 1, s->Nzh, HIPFFT_D2Z, s->Nxl * s->Ny);
-                if (rz == HIPFFT_SUCCESS) rz = hipfftPlanMany(&s->plan_zc2r, 1, nz1, nullptr, 1, s->Nzh, nullptr, 1, s->Nz, HIPFFT_Z2D, s->Nxl * s->Ny);
+                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny}, rez[1] = {s->Nz}, cez[1] = {s->Nzp};
+                rz = hipfftPlanMany(&s->plan_zr2c, 1, nz1, rez, 1, s->Nz, cez, 1, s->Nzp, HIPFFT_D2Z, s->Nxl * s->Ny);
+                if (rz == HIPFFT_SUCCESS) rz = hipfftPlanMany(&s->plan_zc2r, 1, nz1, cez, 1, s->Nzp, rez, 1, s->Nz, HIPFFT_Z2D, s->Nxl * s->Ny);
                 if (rz == HIPFFT_SUCCESS)
-                    rz = hipfftPlanMany(&s->plan_y, 1, ny1, ny1, s->Nzh * s->Nxl, 1, ny1, s->Nzh * s->Nxl, 1, HIPFFT_Z2Z, s->Nzh * s->Nxl);
+                    rz = hipfftPlanMany(&s->plan_y, 1, ny1, ny1, s->Nzp * s->Nxl, 1, ny1, s->Nzp * s->Nxl, 1, HIPFFT_Z2Z, s->Nzp * s->Nxl);
                 if (rz != HIPFFT_SUCCESS) { rc = fail(1000 + (int)rz, "hipfftPlanMany(z-fastest local transforms) failed (%d)", (int)rz); goto bad; }
                 if ((rc = plan_set_stream(s->plan_y))) goto bad;
-                if ((rc = verify_complex_plan(s->plan_y, s->spec, (long)slab, 1.0 / (double)s->Ny, "distributed y (z-fastest layout)"))) goto bad;
+                if ((rc = verify_complex_plan(s->plan_y, s->spec, (long)pslab, 1.0 / (double)s->Ny, "distributed y (z-fastest layout)"))) goto bad;
                 if (want_yline) {
                     while ((1 << s->logn_y) < s->Ny) ++s->logn_y;
                     std::vector<double2> tw(s->Ny / 2);
@@ -1646,20 +1649,20 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
                     TRY_OR_FREE(hipMemcpy(s->ytw, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice));
                     double2 *ref = nullptr;
                     double *bm = nullptr;
-                    TRY_OR_FREE(dev_alloc((void **)&ref, slab * sizeof(double2)));
+                    TRY_OR_FREE(dev_alloc((void **)&ref, pslab * sizeof(double2)));
                     TRY_OR_FREE(dev_alloc((void **)&bm, 256 * sizeof(double)));
-                    const long C = (long)s->Nzh * s->Nxl;
+                    const long C = (long)s->Nzp * s->Nxl;
                     const dim3 grd((unsigned)((C + OCN_ZL - 1) / OCN_ZL));
                     const size_t lds = (size_t)s->Ny * OCN_ZL * sizeof(double2);
                     double err[2] = {-1.0, -1.0};
                     bool ok = true;
                     for (int dir = 0; dir < 2 && ok; ++dir) {      // accept the kernel only if it reproduces the library transform
-                        hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, g_stream, s->spec, (long)slab);
-                        ok = hipMemcpyAsync(ref, s->spec, slab * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
+                        hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((pslab + 255) / 256)), dim3(256), 0, g_stream, s->spec, (long)pslab);
+                        ok = hipMemcpyAsync(ref, s->spec, pslab * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
                              hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD) == HIPFFT_SUCCESS;
                         hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, dir, 1.0);
                         hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->spec,
-                                           2 * (long)slab, bm);
+                                           2 * (long)pslab, bm);
                         ok = ok && reduce_blockmax(bm, 256, &err[dir]) == OCN_OK;
                     }
                     hipFree(ref); hipFree(bm);
@@ -1667,30 +1670,31 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
                     (void)hipGetLastError();
                 }
             }
+            TRY_OR_FREE(hipMemsetAsync(s->spec, 0, pslab * sizeof(double2), g_stream));     // the self-checks wrote into the padding
             s->has_zf = true;
             if ((rc = plan_set_stream(s->plan_zr2c)) || (rc = plan_set_stream(s->plan_zc2r))) goto bad;
             if (s->zf_2d) {
                 // a round trip cannot tell a transform of a mis-read layout from the right one: check the 2-D plan's spectrum against
                 // plain 1-D plans once (pseudo-random data), then drop them
                 hipfftHandle pz = 0, py = 0;
-                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny};
+                int nz1[1] = {s->Nz}, ny1[1] = {s->Ny}, rez2[1] = {s->Nz}, cez2[1] = {s->Nzp};
                 double2 *ref = nullptr;
                 double *bm = nullptr;
                 const long nreal = (long)s->Nz * s->Nxl * s->Ny;
-                hipfftResult r1 = hipfftPlanMany(&pz, 1, nz1, nullptr, 1, s->Nz, nullptr, 1, s->Nzh, HIPFFT_D2Z, s->Nxl * s->Ny);
-                hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlanMany(&py, 1, ny1, ny1, s->Nzh * s->Nxl, 1, ny1, s->Nzh * s->Nxl, 1, HIPFFT_Z2Z, s->Nzh * s->Nxl) : r1;
-                bool ok = r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS && dev_alloc((void **)&ref, slab * sizeof(double2)) == hipSuccess &&
+                hipfftResult r1 = hipfftPlanMany(&pz, 1, nz1, rez2, 1, s->Nz, cez2, 1, s->Nzp, HIPFFT_D2Z, s->Nxl * s->Ny);
+                hipfftResult r2 = r1 == HIPFFT_SUCCESS ? hipfftPlanMany(&py, 1, ny1, ny1, s->Nzp * s->Nxl, 1, ny1, s->Nzp * s->Nxl, 1, HIPFFT_Z2Z, s->Nzp * s->Nxl) : r1;
+                bool ok = r1 == HIPFFT_SUCCESS && r2 == HIPFFT_SUCCESS && dev_alloc((void **)&ref, pslab * sizeof(double2)) == hipSuccess &&
                           dev_alloc((void **)&bm, 256 * sizeof(double)) == hipSuccess;
                 double err = -1.0;
                 if (ok) {
                     hipfftSetStream(pz, g_stream); hipfftSetStream(py, g_stream);
                     hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((nreal + 255) / 256)), dim3(256), 0, g_stream, s->rreal, nreal);
-                    ok = hipfftExecD2Z(pz, s->rreal, (hipfftDoubleComplex *)ref) == HIPFFT_SUCCESS &&
+                    ok = hipMemsetAsync(ref, 0, pslab * sizeof(double2), g_stream) == hipSuccess && hipfftExecD2Z(pz, s->rreal, (hipfftDoubleComplex *)ref) == HIPFFT_SUCCESS &&
                          hipfftExecZ2Z(py, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, HIPFFT_FORWARD) == HIPFFT_SUCCESS &&
                          hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec) == HIPFFT_SUCCESS;
                     if (ok) {
                         hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->spec,
-                                           2 * (long)slab, bm);
+                                           2 * (long)pslab, bm);
                         ok = reduce_blockmax(bm, 256, &err) == OCN_OK;
                     }
                 }
@@ -1834,7 +1838,7 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
         if ((rc = plan_set_stream(s->plan_zr2c))) return rc;
         FFT_TRY(hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec));
         if (s->yline) {
-            const long C = (long)s->Nzh * s->Nxl;
+            const long C = (long)s->Nzp * s->Nxl;
             hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
                                (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 0, 1.0);
         } else if (!s->zf_2d) {
@@ -1842,7 +1846,7 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
             FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_FORWARD));
         }
         hipLaunchKernelGGL(sub_thomas_kernel<true>, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf,
-                           s->spec, s->payload, s->Nzh);
+                           s->spec, s->payload, s->Nzh, s->Nzp);
         KERNEL_CHECK();
         return OCN_OK;
     }
@@ -1851,7 +1855,7 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
     const dim3 blk(16, 16), grd((s->Nxh + 15) / 16, (s->Nyh + 15) / 16, s->Nz);
     hipLaunchKernelGGL(sub_separate_kernel, grd, blk, 0, g_stream, s->zfield, s->Y, s->Nxl, s->Nxh, s->Ny, s->Nyh, s->Nz);
     hipLaunchKernelGGL(sub_thomas_kernel<false>, dim3((unsigned)((s->M + 63) / 64)), dim3(64), 0, g_stream, s->M, s->Nxl, a, s->rden, s->cpf, s->Y,
-                       s->payload, 1);
+                       s->payload, 1, 1);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -1867,12 +1871,12 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
                        a, s->lam[1], s->lam[2], s->svec, (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
     const double scale = 1.0 / ((double)s->Ny * (double)s->Nz);
     if (s->zfirst) {
-        const long total = s->M * s->Nxl;
+        const long total = (long)s->Nzp * s->Nxl * s->Ny;
         hipLaunchKernelGGL(sub_correct_zfast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, s->spec, s->svec, s->iface,
-                           s->M, s->Nxl, s->Nzh, s->Ny, a, scale);
+                           s->M, s->Nxl, s->Nzh, s->Ny, a, scale, s->Nzp);
         int rcz;
         if (s->yline) {
-            const long C = (long)s->Nzh * s->Nxl;
+            const long C = (long)s->Nzp * s->Nxl;
             hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
                                (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 1, 1.0);
         } else if (!s->zf_2d) {

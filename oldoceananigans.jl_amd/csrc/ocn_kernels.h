@@ -1333,16 +1333,16 @@ __global__ void __launch_bounds__(256) sub_separate_kernel(const double2 *Z, dou
 }
 
 // Thomas sweeps along x for every mode (in place), then the payload: first / last value per mode and, for mode 0, the sum
-// ZF: the spectrum is stored z-fastest, Y[kz + Nzh*(i + N*ky)] with m = kz + Nzh*ky (what R2C along z + a strided y transform leave
+// ZF: the spectrum is stored z-fastest, Y[kz + Nzp*(i + N*ky)] (row pitch Nzp >= Nzh) with m = kz + Nzh*ky (what R2C along z + a strided y transform leave
 // behind); otherwise mode-fastest, Y[m + M*i]. The factor arrays are mode-fastest in both cases.
 template <bool ZF>
 __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a, const double *__restrict__ rden, const double *__restrict__ cp,
-                                                        double2 *__restrict__ Yin, double2 *__restrict__ payload, int Nzh) {
+                                                        double2 *__restrict__ Yin, double2 *__restrict__ payload, int Nzh, int Nzp) {
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    // element (m, i) of the spectrum: base + stride * i
-    const long ybase = ZF ? (m % Nzh) + (long)Nzh * N * (m / Nzh) : m;
-    const long ystride = ZF ? (long)Nzh : M;
+    // element (m, i) of the spectrum: base + stride * i (ZF: rows of Nzh modes stored with pitch Nzp >= Nzh, whole 128-B lines)
+    const long ybase = ZF ? (m % Nzh) + (long)Nzp * N * (m / Nzh) : m;
+    const long ystride = ZF ? (long)Nzp : M;
     double2 *__restrict__ Y = Yin + ybase - m;          // so that Y[m + ystride * i] below is the element
     constexpr int TB = 8;
     double2 prev = make_double2(0.0, 0.0);
@@ -1492,11 +1492,12 @@ __global__ void __launch_bounds__(256) sub_correct_combine_kernel(const double2 
 // z-fastest variant of the local stage (R2C along z, then y): p = (y - a gL s - a gR s[N-1-i] - mean[mode 0]) * scale, in place on
 // Y[kz + Nzh*(i + N*ky)]; one thread per element, mode m = kz + Nzh*ky
 __global__ void __launch_bounds__(256) sub_correct_zfast_kernel(double2 *Y, const double *svec, const double2 *iface, long M, int N, int Nzh,
-                                                                int Ny, double a, double scale) {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M * N) return;
-    const int kz = t % Nzh;
-    const long r = t / Nzh;
+                                                                int Ny, double a, double scale, int Nzp) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;          // index into the padded array (pitch Nzp)
+    if (t >= (long)Nzp * N * Ny) return;
+    const int kz = t % Nzp;
+    if (kz >= Nzh) return;                                                 // padding
+    const long r = t / Nzp;
     const int i = r % N, ky = r / N;
     const long m = kz + (long)Nzh * ky;
     const double2 gl = iface[m], gr = iface[M + m];
