@@ -187,6 +187,10 @@ int ocn_make_pressure_correction(ocn_grid_t grid, double *u, double *v, double *
 /* the same over {i0, i1, j0, j1, k0, k1} (NULL = everything): an x-slab rank corrects its two boundary strips first, starts the
  * halo exchange of the next update_state! and corrects the interior while the halos are in flight */
 int ocn_make_pressure_correction_range(ocn_grid_t grid, double *u, double *v, double *w, const double *p, const int *range);
+/* _make_pressure_correction! and `pNHS ./= Δt⁺` (pressure_correction.jl:31-50) in one pass over `range` (NULL = everything): p / divisor
+ * goes to a SECOND haloed array `p_divided` (other threads still read p), which the caller makes the pressure field afterwards */
+int ocn_make_pressure_correction_divide(ocn_grid_t grid, double *u, double *v, double *w, const double *p, double *p_divided,
+                                        double divisor, const int *range);
 /* `pNHS ./= Δt⁺` (pressure_correction.jl:48-50): interior of a (Center, Center, Center) field */
 int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor);
 

@@ -52,6 +52,7 @@ SYMBOLS = {
     "ocn_compute_linear_flux_bc": (C.c_int, [_vp, _vp, _ip, C.c_int, C.c_double, C.c_double, _vp]),
     "ocn_model_set_linear_flux_bc": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_char_p]),
     "ocn_make_pressure_correction_range": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _ip]),
+    "ocn_make_pressure_correction_divide": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_double, _ip]),
     "ocn_model_reset": (C.c_int, [_vp]),
     "ocn_dist_poisson_layout": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "ocn_hasnan": (C.c_int, [_vp, C.c_size_t, C.POINTER(C.c_int)]),

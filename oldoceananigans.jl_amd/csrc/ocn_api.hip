@@ -784,7 +784,8 @@ extern "C" int ocn_compute_source_term(ocn_grid_t grid, const double *u, const d
     return source_term(grid->d, u, v, w, rhs_complex, weight_by_dz != 0);
 }
 
-static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p, const int *range = nullptr) {
+static int pressure_correction(const DGrid &g, double *u, double *v, double *w, const double *p, const int *range = nullptr,
+                               double *pdiv = nullptr, double divisor = 1.0) {
     Range6 r{1, g.Nx, 1, g.Ny, 1, g.Nz};
     if (range) {
         const int N[3] = {g.Nx, g.Ny, g.Nz};
@@ -797,9 +798,16 @@ static int pressure_correction(const DGrid &g, double *u, double *v, double *w, 
     if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
     const dim3 blk = nx < 16 ? dim3(4, 64, 1) : BLK;        // an Hx-wide boundary strip: threads along y instead of 61 idle lanes in x
     hipLaunchKernelGGL(pressure_correction_kernel, grid3(nx, ny, nz, blk), blk, 0, g_stream, g, make_view(g, u, LOC_U),
-                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C), r);
+                       make_view(g, v, LOC_V), make_view(g, w, LOC_W), make_view(g, p, LOC_C), r, pdiv, divisor);
     KERNEL_CHECK();
     return OCN_OK;
+}
+
+extern "C" int ocn_make_pressure_correction_divide(ocn_grid_t grid, double *u, double *v, double *w, const double *p, double *p_divided,
+                                                   double divisor, const int *range) {
+    NEED_INIT();
+    if (!grid || !u || !v || !w || !p || !p_divided || p_divided == p) return fail(OCN_EINVAL, "invalid argument (p_divided must be a second array)");
+    return pressure_correction(grid->d, u, v, w, p, range, p_divided, divisor);
 }
 
 extern "C" int ocn_make_pressure_correction_range(ocn_grid_t grid, double *u, double *v, double *w, const double *p, const int *range) {

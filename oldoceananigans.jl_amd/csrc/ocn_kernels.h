@@ -735,12 +735,15 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     } else ((double2 *)rhs)[q] = make_double2(val, 0.0);    // the reference's complex storage
 }
 
-__global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p, Range6 r) {
+// pdiv != nullptr: also `pNHS ./= Δt⁺`, written to a SECOND haloed array (neighbouring threads still read p) that the caller swaps in
+__global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView u, FView v, FView w, FView p, Range6 r,
+                                                                  double *pdiv = nullptr, double divisor = 1.0) {
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = r.k0 + blockIdx.z;
     if (i > r.i1 || j > r.j1 || k > r.k1) return;
     const double pc = p.at(i, j, k);
+    if (pdiv) pdiv[p.lin(i, j, k)] = pc / divisor;
     u.at(i, j, k) -= (g.tx == OCN_FLAT ? 0.0 : pc - p.at(i - 1, j, k)) * g.rdx;            // ∂xᶠᶜᶜ = δx * Δx⁻¹
     v.at(i, j, k) -= (g.ty == OCN_FLAT ? 0.0 : pc - p.at(i, j - 1, k)) * g.rdy;
     w.at(i, j, k) -= (g.tz == OCN_FLAT ? 0.0 : pc - p.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz];

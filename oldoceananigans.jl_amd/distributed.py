@@ -287,6 +287,7 @@ class DeviceBackend:
         self.Gn = [Field(l, g) for l in locs]
         self.Gm = [Field(l, g) for l in locs]
         self.p = Field((Center,) * 3, g)
+        self.p2 = Field((Center,) * 3, g)       # receives p / Δt from the pressure-correction pass; swapped in as the pressure afterwards
         nf = len(locs)
         mk = lambda n: torch.zeros(n, dtype=torch.float64, device=ctx.device)   # noqa: E731
         total = sum(self._slab(f) for f in self.U)
@@ -471,6 +472,16 @@ class DeviceBackend:
         U = self.U
         _lib.check(_lib.lib().ocn_make_pressure_correction_range(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.p.data,
                                                                  _range(rng)))
+
+    def pressure_correction_divide(self, divisor, rng=None):
+        """pressure correction over `rng` + p / divisor into the second pressure array (one pass instead of two)"""
+        from .kernels import _range
+        U = self.U
+        _lib.check(_lib.lib().ocn_make_pressure_correction_divide(self.grid.local.handle, U[0].data, U[1].data, U[2].data, self.p.data,
+                                                                  self.p2.data, float(divisor), _range(rng)))
+
+    def swap_pressure(self):
+        self.p.data, self.p2.data = self.p2.data, self.p.data
 
     def divide_pressure(self, divisor):
         _lib.check(_lib.lib().ocn_divide_interior(self.grid.local.handle, self.p.data, float(divisor)))
@@ -687,19 +698,28 @@ def make_pressure_correction(model, Δt, start_halo_exchange=False):
     b, ctx = model.backend, model.ctx
     g = model.grid.local
     dtp = max(np.finfo(np.float64).eps, Δt)
+    fused = hasattr(b, "pressure_correction_divide")     # p / Δt written by the correction pass itself (second array, swapped in)
     if not (start_halo_exchange and ctx.partitioned and getattr(model, "early_exchange", True) and model.async_halos is not False and
             g.Nx > 2 * g.Hx and hasattr(b, "pack_x")):
-        b.pressure_correction()
-        b.divide_pressure(dtp)
+        if fused:
+            b.pressure_correction_divide(dtp)
+            b.swap_pressure()
+        else:
+            b.pressure_correction()
+            b.divide_pressure(dtp)
         return
     Nx, Ny, Nz, Hx = g.Nx, g.Ny, g.Nz, g.Hx
-    b.pressure_correction((1, Hx, 1, Ny, 1, Nz))
-    b.pressure_correction((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))
+    pc = (lambda r: b.pressure_correction_divide(dtp, r)) if fused else b.pressure_correction
+    pc((1, Hx, 1, Ny, 1, Nz))
+    pc((Nx - Hx + 1, Nx, 1, Ny, 1, Nz))
     b.fill_local_halos(b.U, False)                       # the strips' y / z halos (corners ride along in the buffers)
     ws, es, wr, er = b.pack_x(b.U)
     model._halos_in_flight = ctx.exchange_start(ws, es, wr, er)
-    b.pressure_correction((Hx + 1, Nx - Hx, 1, Ny, 1, Nz))
-    b.divide_pressure(dtp)
+    pc((Hx + 1, Nx - Hx, 1, Ny, 1, Nz))
+    if fused:
+        b.swap_pressure()
+    else:
+        b.divide_pressure(dtp)
 
 
 def set_model(model, enforce_incompressibility=True, **kwargs):
