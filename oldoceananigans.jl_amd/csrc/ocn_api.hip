@@ -765,11 +765,11 @@ extern "C" int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const do
 // pressure source term / correction
 // ---------------------------------------------------------------------------------------------------------------------
 static int source_term(const DGrid &g, const double *u, const double *v, const double *w, void *rhs, bool weight, bool real_out = false,
-                       long sj = 0, long sk = 0, bool pad = false) {
+                       long sj = 0, long sk = 0, bool pad = false, bool wrap = false) {
     if (sj == 0) { sj = g.Nx; sk = (long)g.Nx * g.Ny; }
     if (real_out)
         hipLaunchKernelGGL(source_term_kernel<true>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, pad);
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, pad, wrap);
     else
         hipLaunchKernelGGL(source_term_kernel<false>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
                            make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, false);
@@ -2359,8 +2359,11 @@ static int pressure_step(ocn_model_s *m, double dt) {
         return make_pressure_correction(m, dt);
     }
     const DGrid &g = m->grid->d;
-    if ((rc = fill_halo_regions(m->grid, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr))) return rc;
-    if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], s->rrhs, s->kind == 1, true))) return rc;
+    // triply periodic: the divergence reads its upper neighbours at the wrapped interior index, so fill_halo_regions!(velocities)
+    // (pressure_correction.jl:10) is not needed here -- update_state! fills every halo again before anything else reads one
+    const bool ppp = g.tx == OCN_PERIODIC && g.ty == OCN_PERIODIC && g.tz == OCN_PERIODIC;
+    if (!ppp && (rc = fill_halo_regions(m->grid, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr))) return rc;
+    if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], s->rrhs, s->kind == 1, true, 0, 0, false, ppp))) return rc;
     if ((rc = poisson_solve_real_split(s))) return rc;
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     hipLaunchKernelGGL(pressure_correction_dense_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, m->U[0], LOC_U),

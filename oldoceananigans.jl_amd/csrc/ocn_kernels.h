@@ -714,18 +714,21 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 template <bool REAL_OUT>
 // rhs element (i, j, k) is stored at (i-1) + sj*(j-1) + sk*(k-1); `pad` (real output only): the row has one extra, zero,
 // element after i = Nx (odd local Nx on the distributed solver's paired-column layout)
+// wrap (triply periodic grids only): the upper neighbours are read at their wrapped INTERIOR index instead of the halo, so the
+// velocity halo fill that precedes the solve in the reference can be left to the next update_state! (same values by construction)
 __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, void *rhs, bool weight_by_dz,
-                                                          long sj, long sk, bool pad) {
+                                                          long sj, long sk, bool pad, bool wrap = false) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
     const int kk = k - 1 + g.Hz;
     const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
+    const int ip = (wrap && i == g.Nx) ? 1 : i + 1, jp = (wrap && j == g.Ny) ? 1 : j + 1, kp = (wrap && k == g.Nz) ? 1 : k + 1;
     // δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49)
-    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(i + 1, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
-    double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, j + 1, k) - ay * v.at(i, j, k);
-    double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, k + 1) - az * w.at(i, j, k);
+    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(ip, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
+    double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, jp, k) - ay * v.at(i, j, k);
+    double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, kp) - az * w.at(i, j, k);
     double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
     double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
     const long q = (long)(i - 1) + sj * (j - 1) + sk * (k - 1);
