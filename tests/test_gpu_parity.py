@@ -740,3 +740,29 @@ def test_simulation_run_loop(ocn, arch):
     sim.callbacks["record"] = ocn.Callback(lambda s: times.append(s.model.clock.time), ocn.TimeInterval(0.7))
     ocn.run(sim)
     assert np.allclose(times, [0.0, 0.7, 1.4], rtol=1e-14, atol=0) and np.isclose(model.clock.time, 2.0, rtol=1e-14)
+
+
+@pytest.mark.parametrize("size,zb", [((20, 8, 8), False), ((36, 16, 10), True), ((64, 32, 16), False), ((10, 64, 12), True)])
+def test_split_pressure_step_equals_library_plans(ocn, arch, size, zb):
+    """the model's pressure step in split form (1-D x plans on 128-B-padded rows + the LDS column-FFT kernel for y + one kernel for the
+    correction and p / Δt from the dense solution; option split_solve) against the 2-D library plans + separate kernels: same fields"""
+    topo = (ocn.Periodic, ocn.Periodic, ocn.Bounded if zb else ocn.Periodic)
+    z = tanh_faces(size[2]) if zb else (0.0, 1.0)
+    outs = []
+    for split in (1, 0):
+        ocn.set_option("split_solve", split)
+        try:
+            grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo)
+            model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+            ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, 5))
+            for _ in range(3):
+                ocn.time_step(model, 0.1 * grid.Δxᶜᵃᵃ / 0.6)
+            outs.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent()})
+            div = ocn.max_abs_divergence(model)
+            assert div < 1e-12
+            del model
+        finally:
+            ocn.set_option("split_solve", 1)
+    for name in outs[0]:
+        a, b = outs[0][name][3:-3, 3:-3, 3:-3], outs[1][name][3:-3, 3:-3, 3:-3]
+        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-30), name
