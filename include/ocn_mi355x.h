@@ -326,8 +326,17 @@ int ocn_model_set_amd(ocn_model_t model, double Cnu, const double *Ckappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
 /* name.side = FluxBoundaryCondition((ξ, η, t, φ, p) -> a + b φ, field_dependencies = dep); dep at the location of `name` */
 int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, double a, double b, const char *dep);
-/* library-wide knobs: "real_fft" (1: D2Z/Z2D pressure solve, 0: the reference's complex-to-complex), "c2r_strided",
- * "fused_ty", "fused_kchunk", "fused_minw" (fused tendency kernel geometry) */
+/* library-wide knobs (no reference equivalent; the defaults are the tuned values, 0 / 1 unless noted):
+ *   pressure solve: "real_fft" (1: D2Z/Z2D, 0: the reference's complex-to-complex), "c2r_strided", "fused_zfft" (z FFT + divide +
+ *     inverse z FFT as one LDS pass), "split_solve" (model time-step: 1-D x plans on 128-B-padded rows + LDS column-FFT kernel for y +
+ *     pressure correction and p/Δt from the dense solution);
+ *   x-slab solve: "dist_substructured" (1: gathered interface solve, 0: the reference's two transposes), "dist_zfirst" (z-fastest
+ *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform);
+ *   fused tendency kernel: "fused_ty" (tile rows 3 | 7), "fused_kchunk" (levels per workgroup, 0 = automatic), "fused_minw",
+ *     "fused_zwin" (register z-windows), "fused_lds" (LDS-tile variant), "fused_xcd" (XCD-aware tile order; measured: no effect);
+ *   halo fills: "fused_halo" (one launch per periodic fill).
+ * Model options (ocn_model_set_option): "tendency_impl" (1 fused, 0 per-field kernels), "swap_tendencies", "fuse_substep",
+ * "fused_epilogue", "use_graph" (hipGraph replay of the RK3 step; measured: no gain, default 0), "profile". */
 int ocn_set_option(const char *key, int value);
 /* sum of the event-timed tendency evaluations since the last read (ms) and their count; synchronous. This is the
  * measurement hook the reference lacks (it is profiled externally with nsys, .buildkite/pipeline-benchmarks.yml:57) */
