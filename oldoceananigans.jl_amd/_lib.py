@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libocn_mi355x.so")
+SO_PATH = os.environ.get("OCN_LIB") or os.path.join(_HERE, "csrc", "libocn_mi355x.so")   # OCN_LIB: experiments with alternative builds
 _lib = None
 
 

@@ -4,6 +4,7 @@
 #include "../../include/ocn_mi355x.h"
 #include "ocn_kernels.h"
 #include "ocn_tendency_fused.h"
+#include "ocn_tendency_roles.h"
 #include "ocn_tendency_lds.h"
 #include <hipfft/hipfft.h>
 #include <cmath>
@@ -500,8 +501,12 @@ extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v,
     return launch_tendency<F_C>(grid->d, u, v, w, c, Gc, range);
 }
 
+// tendency implementation of the raw entry points: 0 per-field kernels (the reference's launch structure), 1 all-fields flux-sharing
+// kernel (ocn_tendency_fused.h), 2 one-field-per-workgroup flux-sharing kernel (ocn_tendency_roles.h, default)
+static int g_tendency_impl = 2;
+
 static bool fused_path(const DGrid &g, const int *range, int ntr, int impl) {
-    return impl == 1 && fused_tendency_supported(g, range) && ntr <= 3;
+    return (impl == 1 || impl == 2) && fused_tendency_supported(g, range) && ntr <= 3;
 }
 
 static int compute_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr,
@@ -511,7 +516,8 @@ static int compute_tendencies(const DGrid &g, const double *u, const double *v, 
     if (fused_path(g, range, ntr, impl)) {
         int rc = check_range(g, range, nullptr);
         if (rc) return rc;
-        rc = launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub);
+        rc = impl == 2 ? launch_role_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub)
+                       : launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub);
         if (rc) return fail(rc, "fused tendency launch failed");
         KERNEL_CHECK();
         return OCN_OK;
@@ -532,7 +538,7 @@ extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const do
     if (!grid || !u || !v || !w || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
         (ntracers > 0 && (!tracers || !Gc)))
         return fail(OCN_EINVAL, "invalid argument");
-    int rc = compute_tendencies(grid->d, u, v, w, tracers, ntracers, Gu, Gv, Gw, Gc, range, 1);
+    int rc = compute_tendencies(grid->d, u, v, w, tracers, ntracers, Gu, Gv, Gw, Gc, range, g_tendency_impl ? g_tendency_impl : 1);
     if (rc) return rc;
     KERNEL_CHECK();
     return OCN_OK;
@@ -688,10 +694,11 @@ extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double 
     if (!grid || !fields || !Gn || !next || ntracers < 0 || ntracers > 3 || (has_zeta && !Gm)) return fail(OCN_EINVAL, "invalid argument");
     for (int f = 0; f < 3 + ntracers; ++f)
         if (!fields[f] || !Gn[f] || !next[f] || (has_zeta && !Gm[f])) return fail(OCN_EINVAL, "NULL field pointer");
-    if (!fused_path(grid->d, range, ntracers, 1))
+    const int impl = g_tendency_impl ? g_tendency_impl : 1;
+    if (!fused_path(grid->d, range, ntracers, impl))
         return fail(OCN_ENOTSUP, "the fused tendency + substep pass needs Periodic / FullyConnected x and y");
     const FusedSubstep sub{next, has_zeta ? Gm : Gn, dt, gamma, zeta, has_zeta ? 1 : 0};
-    return compute_tendencies(grid->d, fields[0], fields[1], fields[2], fields + 3, ntracers, Gn[0], Gn[1], Gn[2], Gn + 3, range, 1, &sub);
+    return compute_tendencies(grid->d, fields[0], fields[1], fields[2], fields + 3, ntracers, Gn[0], Gn[1], Gn[2], Gn + 3, range, impl, &sub);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2066,7 +2073,7 @@ struct ocn_model_s {
     double time = 0, last_dt = INFINITY, last_stage_dt = INFINITY;
     int64_t iteration = 0;
     int stage = 1;
-    int tendency_impl = 1;
+    int tendency_impl = 2;
     int swap_tendencies = 1;
     // live kernel timing for bench.py's roofline block: hipEvent pairs on the launch stream around every tendency
     // evaluation (the dominant kernel), resolved by ocn_model_profile_read
@@ -2174,7 +2181,10 @@ extern "C" int ocn_set_option(const char *key, int value) {
     g_epoch += 1;
     if (!strcmp(key, "real_fft")) { g_real_fft = value; return OCN_OK; }
     if (!strcmp(key, "c2r_strided")) { g_c2r_strided = value; return OCN_OK; }
+    if (!strcmp(key, "tendency_impl")) { if (value < 0 || value > 2) return fail(OCN_EINVAL, "tendency_impl is 0, 1 or 2"); g_tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
+    if (!strcmp(key, "role_ldspad")) { g_role_ldspad = value; return OCN_OK; }
+    if (!strcmp(key, "role_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "role_kchunk must be >= 0 (0 = automatic)"); g_role_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
     if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }

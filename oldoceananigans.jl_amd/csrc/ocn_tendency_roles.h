@@ -1,0 +1,436 @@
+// ocn_tendency_roles.h -- flux-sharing WENO-5 tendency kernel, one FIELD per workgroup ("roles").
+//
+// Same contract and the same IEEE operation sequence per flux as ocn_tendency_fused.h (compute_nonhydrostatic_tendencies.jl:49-163,
+// upwind_biased_advective_fluxes.jl:23-121): every face flux is evaluated once and handed to the neighbouring cell, a workgroup owns a
+// 64 x TY column tile and marches along z with the z-window of its field in registers, low-side x / y fluxes go through LDS.
+//
+// What changes is the decomposition of the work. The all-fields kernel keeps the z-windows of 5 fields (60 VGPRs) plus the state
+// of 15 reconstructions per thread: 206 VGPRs, 2 waves per SIMD, 78 spilled SGPRs (22 FP64 constants + 44 pointers). Here a
+// workgroup evaluates the three fluxes of ONE field (role u, v, w or tracer t) on its tile: one 6-deep z-window (two more 4-deep
+// ones for w), 3 reconstructions per cell and plane, < 128 VGPRs => two 8-wave workgroups per CU, 4 waves per SIMD, 15.6 KB of
+// LDS per workgroup and a hot loop of ~5 KB of code per role. The (3 + ntracers) role workgroups of one (tile, z-chunk) pair are
+// dispatched back to back onto the same XCD (blocks b and b + 8 share an XCD under the observed round-robin placement; a pure
+// speed choice), so the velocity planes all of them read are fetched into that XCD's L2 once.
+//
+// Addressing: a plane's base address is a scalar (SGPR pair, advanced by one plane per iteration on the scalar unit); a thread
+// carries loop-invariant 32-bit byte offsets of its six y-window rows; x neighbours are immediate offsets. No vector instruction is
+// spent on addresses inside the loop.
+#pragma once
+#include "ocn_tendency_fused.h"
+
+#ifndef OCN_ROLE_WAVES
+#define OCN_ROLE_WAVES 6      // waves per SIMD the register allocation must allow (8-wave workgroups: 4 = two per CU, 6 = three)
+#endif
+enum { ROLE_U = 0, ROLE_V = 1, ROLE_W = 2, ROLE_C = 3 };
+
+template <int NF>
+struct RoleArgs {
+    const double *U[NF];       // u, v, w, tracers
+    double *G[NF];
+    double *Un[NF];            // fused RK3 substep of the next stage (see FusedArgs)
+    const double *Gm[NF];
+    int s1;                    // x-row stride (elements)
+    unsigned s2;               // plane stride (elements)
+    long off;                  // (Hx-1) + s1 (Hy-1)
+    Range6 r;                  // cell range of the launch
+    int wk0;                   // first level whose w tendency is stored (exclude_periphery on Bounded z)
+    int kchunk, ntile_x, ntile, npair, band;
+    int has_zeta;
+    double dt, gamma, zeta;
+};
+
+// Buffer addressing (MUBUF): descriptor of the whole parent array (4 SGPRs) + scalar plane offset + per-thread 32-bit byte offset
+// + 12-bit immediate: buffer_load_dwordx2 v, voff, s[rsrc], soff offen offset:IMM. The per-thread offsets are biased by -24 B so
+// that the six x-neighbours are the immediates 0 .. 40.
+typedef __amdgpu_buffer_rsrc_t Rsrc;
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Rsrc make_rsrc(const void *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0xFFFFFFFFu, 0x00020000);   // raw buffer, no range clamp in use
+}
+template <int IMM> __device__ __forceinline__ double ldb(Rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + (unsigned)IMM), (int)soff, 0));
+}
+template <int IMM> __device__ __forceinline__ void stb(Rsrc r, unsigned voff, unsigned soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)(voff + (unsigned)IMM), (int)soff, 0);
+}
+
+// per-thread loop-invariant offsets: c = byte offset of (i - 3, j); r[n] = byte offset of (i - 3, j - 3 + n)
+struct ColOff { unsigned c, r[6]; };
+
+// x-direction windows around column i: immediates 0 .. 40 (centre 24)
+template <bool OWN> __device__ __forceinline__ Win6 xwin6(Rsrc b, unsigned so, const ColOff &o, double centre) {
+    Win6 w;
+    w.s[0] = ldb<0>(b, o.c, so); w.s[1] = ldb<8>(b, o.c, so); w.s[2] = ldb<16>(b, o.c, so);
+    w.s[3] = OWN ? centre : ldb<24>(b, o.c, so);
+    w.s[4] = ldb<32>(b, o.c, so); w.s[5] = ldb<40>(b, o.c, so);
+    return w;
+}
+__device__ __forceinline__ Win6 xwin4(Rsrc b, unsigned so, const ColOff &o) {
+    Win6 w;
+    w.s[0] = 0.0; w.s[5] = 0.0;
+    w.s[1] = ldb<8>(b, o.c, so); w.s[2] = ldb<16>(b, o.c, so); w.s[3] = ldb<24>(b, o.c, so); w.s[4] = ldb<32>(b, o.c, so);
+    return w;
+}
+template <bool OWN> __device__ __forceinline__ Win6 ywin6(Rsrc b, unsigned so, const ColOff &o, double centre) {
+    Win6 w;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) w.s[n] = (OWN && n == 3) ? centre : ldb<24>(b, n == 3 ? o.c : o.r[n], so);
+    return w;
+}
+__device__ __forceinline__ Win6 ywin4(Rsrc b, unsigned so, const ColOff &o) {
+    Win6 w;
+    w.s[0] = 0.0; w.s[5] = 0.0;
+#pragma unroll
+    for (int n = 1; n < 5; ++n) w.s[n] = ldb<24>(b, n == 3 ? o.c : o.r[n], so);
+    return w;
+}
+// z-direction 4-window (levels k-2 .. k+1) straight from memory (edge wave of role w only)
+__device__ __forceinline__ Win6 zwin4(Rsrc b, unsigned so, const ColOff &o, unsigned s2) {
+    Win6 w;
+    w.s[0] = 0.0; w.s[5] = 0.0;
+    w.s[1] = ldb<24>(b, o.c, so - 2u * s2); w.s[2] = ldb<24>(b, o.c, so - s2); w.s[3] = ldb<24>(b, o.c, so); w.s[4] = ldb<24>(b, o.c, so + s2);
+    return w;
+}
+
+// per-plane scalar state of a workgroup
+struct PlaneCtx {
+    Rsrc u, v, w, q;           // u, v, w and the role's own field
+    unsigned so;               // byte offset of plane k
+    unsigned s2;               // plane stride in bytes
+    double axk, ayk;
+    const double *axz, *ayz;   // Ax, Ay at levels k-2 ..
+};
+
+// ---- loads and arithmetic of the three low-side fluxes of field ROLE at (i, j, k), kept apart so that a row wave can issue the
+// loads of plane k + 1 before the barrier that ends plane k (they are in flight while the workgroup synchronises) ----
+// z-flux inputs besides the own z-window: the advecting w along x (role u) / along y (role v), indices 1 .. 4; w at the face (tracers)
+template <int ROLE> __device__ __forceinline__ Win6 load_zin(const PlaneCtx &p, unsigned so, const ColOff &o) {
+    if (ROLE == ROLE_U) return xwin4(p.w, so, o);
+    if (ROLE == ROLE_V) return ywin4(p.w, so, o);
+    Win6 w;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) w.s[n] = 0.0;
+    if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.w, o.c, so);
+    return w;
+}
+template <int ROLE>
+__device__ __forceinline__ double z_flux(const DGrid &g, const Win6 &zin, int i, int j, int k, const Win6 &qz) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    const double az = g.az;
+    if (ROLE == ROLE_U) {
+        const double wt = sym4(zin, az, bx, i, false, g.Nx);                         // advective_momentum_flux_Wu :39-45
+        return wt * bias6(qz, wt > 0, bz, k, false, g.Nz);
+    } else if (ROLE == ROLE_V) {
+        const double wt = sym4(zin, az, by, j, false, g.Ny);                         // Wv :63-69
+        return wt * bias6(qz, wt > 0, bz, k, false, g.Nz);
+    } else if (ROLE == ROLE_W) {
+        const double wt = sym4(qz, az, bz, k - 1, true, g.Nz);                       // Ww :87-93
+        return wt * bias6(qz, wt > 0, bz, k - 1, true, g.Nz);
+    } else {
+        const double w0 = zin.s[3];                                                  // advective_tracer_flux_z :115-121
+        return az * w0 * bias6(qz, w0 > 0, bz, k, false, g.Nz);
+    }
+}
+// x-flux: own field along x (qx) + the advecting u: along y (role v, indices 1 .. 4), along z (role w), at the face (tracers)
+template <int ROLE> __device__ __forceinline__ Win6 load_xaux(const PlaneCtx &p, const ColOff &o) {
+    if (ROLE == ROLE_V) return ywin4(p.u, p.so, o);
+    Win6 w;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) w.s[n] = 0.0;
+    if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.u, o.c, p.so);
+    return w;
+}
+template <int ROLE>
+__device__ __forceinline__ double x_flux(const DGrid &g, const PlaneCtx &p, const Win6 &qx, const Win6 &aux, int i, int j, int k) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    if (ROLE == ROLE_U) {
+        const double ut = sym4(qx, p.axk, bx, i - 1, true, g.Nx);                    // advective_momentum_flux_Uu :23-29
+        return ut * bias6(qx, ut > 0, bx, i - 1, true, g.Nx);
+    } else if (ROLE == ROLE_V) {
+        const double ut = sym4(aux, p.axk, by, j, false, g.Ny);                      // Uv :47-53
+        return ut * bias6(qx, ut > 0, bx, i, false, g.Nx);
+    } else if (ROLE == ROLE_W) {
+        const double ut = sym4z(aux, p.axz, bz, k, false, g.Nz);                     // Uw :71-77
+        return ut * bias6(qx, ut > 0, bx, i, false, g.Nx);
+    } else {
+        const double u0 = aux.s[3];                                                  // advective_tracer_flux_x :99-105
+        return p.axk * u0 * bias6(qx, u0 > 0, bx, i, false, g.Nx);
+    }
+}
+// y-flux: own field along y (qy) + the advecting v: along x (role u), along z (role w), at the face (tracers)
+template <int ROLE> __device__ __forceinline__ Win6 load_yaux(const PlaneCtx &p, const ColOff &o) {
+    if (ROLE == ROLE_U) return xwin4(p.v, p.so, o);
+    Win6 w;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) w.s[n] = 0.0;
+    if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.v, o.c, p.so);
+    return w;
+}
+template <int ROLE>
+__device__ __forceinline__ double y_flux(const DGrid &g, const PlaneCtx &p, const Win6 &qy, const Win6 &aux, int i, int j, int k) {
+    const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
+    if (ROLE == ROLE_U) {
+        const double vt = sym4(aux, p.ayk, bx, i, false, g.Nx);                      // advective_momentum_flux_Vu :31-37
+        return vt * bias6(qy, vt > 0, by, j, false, g.Ny);
+    } else if (ROLE == ROLE_V) {
+        const double vt = sym4(qy, p.ayk, by, j - 1, true, g.Ny);                    // Vv :55-61
+        return vt * bias6(qy, vt > 0, by, j - 1, true, g.Ny);
+    } else if (ROLE == ROLE_W) {
+        const double vt = sym4z(aux, p.ayz, bz, k, false, g.Nz);                     // Vw :79-85
+        return vt * bias6(qy, vt > 0, by, j, false, g.Ny);
+    } else {
+        const double v0 = aux.s[3];                                                  // advective_tracer_flux_y :107-113
+        return p.ayk * v0 * bias6(qy, v0 > 0, by, j, false, g.Ny);
+    }
+}
+
+// One workgroup = TY row waves + one edge wave, all working on field `fidx`. A row wave owns R consecutive rows of the tile (R = 2:
+// half as many barriers, LDS round trips and edge fluxes per cell, and the y-windows of its two rows share five of their six rows);
+// the edge wave evaluates the y-fluxes of the row above the tile and the x-fluxes of the column right of it (one lane per row).
+template <int ROLE, int TY, int R, bool SUB, typename Args>
+__device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const int fidx, const int i0, const int j0, const int kc0,
+                                           const int kc1, double (*FX)[TY * R][66], double (*FY)[TY * R + 1][64]) {
+    constexpr int NR = TY * R;                        // rows per tile
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const bool edge = wave == TY;
+    const int i = i0 + lane;
+    const int row0 = edge ? NR : wave * R;            // first tile row of this wave (edge wave: the row above the tile)
+    const int j = j0 + row0;
+    const bool flux_i = !edge && i <= a.r.i1 + 1, cell_i = !edge && i <= a.r.i1;
+    const bool edge_y = edge && i <= a.r.i1 && j <= a.r.j1 + 1;
+    const int ie = i0 + 64, je = j0 + lane;
+    const bool edge_x = edge && lane < NR && ie <= a.r.i1 + 1 && je <= a.r.j1;
+
+    const unsigned s1 = 8u * (unsigned)a.s1, s2 = 8u * a.s2;         // byte strides
+    const int Hz = g.Hz;
+    // byte offsets inside a plane, biased by -3 columns: yo[m] = (i - 3, j - 3 + m), m = 0 .. R + 4 (rows of the y-windows of the R
+    // own rows); the edge wave's second job is column i0 + 64 of row j0 + lane
+    unsigned yo[R + 5];
+#pragma unroll
+    for (int m = 0; m < R + 5; ++m) yo[m] = 8u * (unsigned)(a.off + i - 3 + (long)a.s1 * (j - 3 + m));
+    unsigned ce = 8u * (unsigned)(a.off + ie - 3 + (long)a.s1 * je);
+
+    PlaneCtx p;
+    p.u = make_rsrc(a.U[0]); p.v = make_rsrc(a.U[1]); p.w = make_rsrc(a.U[2]);
+    p.q = ROLE == ROLE_U ? p.u : (ROLE == ROLE_V ? p.v : (ROLE == ROLE_W ? p.w : make_rsrc(a.U[fidx])));
+    p.s2 = s2;
+    p.so = s2 * (unsigned)(kc0 - 1 + Hz);             // plane of level kc0
+    // the streams touched once per cell (tendency out, previous tendency in, next-stage field out): plain plane pointers, level k - 1
+    char *Gk = reinterpret_cast<char *>(a.G[fidx]) + (size_t)p.so - s2 + 24;
+    char *Unk = SUB ? reinterpret_cast<char *>(a.Un[fidx]) + (size_t)p.so - s2 + 24 : nullptr;
+    const char *Gmk = SUB ? reinterpret_cast<const char *>(a.Gm[fidx]) + (size_t)p.so - s2 + 24 : nullptr;
+
+    double fz_prev[R];
+    Win6 qz[R], uz4[R], vz4[R];                       // own 6-deep z-windows; role w: u, v at levels k-2 .. k+1 (indices 1 .. 4)
+    bool flux_r[R], cell_r[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        fz_prev[r] = 0;
+        flux_r[r] = flux_i && j + r <= a.r.j1 + 1;
+        cell_r[r] = cell_i && j + r <= a.r.j1;
+#pragma unroll
+        for (int n = 0; n < 6; ++n) { qz[r].s[n] = 0; uz4[r].s[n] = 0; vz4[r].s[n] = 0; }
+        if (flux_r[r]) {
+#pragma unroll
+            for (int n = 0; n < 5; ++n) qz[r].s[n + 1] = ldb<24>(p.q, yo[r + 3], p.so + (unsigned)(n - 3) * s2);   // levels kc0-3 .. kc0+1
+            if (ROLE == ROLE_W) {
+#pragma unroll
+                for (int n = 1; n < 4; ++n) {                                                                      // levels kc0-2 .. kc0
+                    uz4[r].s[n + 1] = ldb<24>(p.u, yo[r + 3], p.so + (unsigned)(n - 3) * s2);
+                    vz4[r].s[n + 1] = ldb<24>(p.v, yo[r + 3], p.so + (unsigned)(n - 3) * s2);
+                }
+            }
+        }
+    }
+
+    for (int k = kc0; k <= kc1 + 1; ++k) {
+        const bool last = k == kc1 + 1;               // peeled plane: only the z-fluxes closing the cells of level kc1
+        const int buf = k & 1;
+        const long pk = (long)(k - 1 + Hz);
+        p.axk = g.ax[pk]; p.ayk = g.ay[pk];
+        p.axz = g.ax + pk - 2; p.ayz = g.ay + pk - 2;
+        // keep the 32-bit offsets opaque per iteration, so that `offset + constant` stays inside the loop and folds into the immediate
+#pragma unroll
+        for (int m = 0; m < R + 5; ++m) asm volatile("" : "+v"(yo[m]));
+        if (!edge) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!flux_r[r]) continue;
+                ColOff o;
+                o.c = yo[r + 3];
+#pragma unroll
+                for (int n = 0; n < 6; ++n) o.r[n] = yo[r + n];
+                const bool close_cell = k > kc0 && cell_r[r];
+                double gm = 0;
+                if (SUB && a.has_zeta && close_cell) gm = *reinterpret_cast<const double *>(Gmk + o.c);
+#pragma unroll
+                for (int n = 0; n < 5; ++n) qz[r].s[n] = qz[r].s[n + 1];
+                qz[r].s[5] = ldb<24>(p.q, o.c, p.so + 2u * s2);
+                if (ROLE == ROLE_W) {
+#pragma unroll
+                    for (int n = 1; n < 4; ++n) { uz4[r].s[n] = uz4[r].s[n + 1]; vz4[r].s[n] = vz4[r].s[n + 1]; }
+                    uz4[r].s[4] = ldb<24>(p.u, o.c, p.so + s2);
+                    vz4[r].s[4] = ldb<24>(p.v, o.c, p.so + s2);
+                }
+                // ---- z-flux through the bottom face of cell k, then close cell k-1 ----
+                const double fz = z_flux<ROLE>(g, load_zin<ROLE>(p, p.so, o), i, j + r, k, qz[r]);
+                if (close_cell) {
+                    const int pb = buf ^ 1;
+                    const long pkm = pk - 1;
+                    const double vinv = ROLE == ROLE_W ? g.vinv_f[pkm] : g.vinv_c[pkm];
+                    const double dx = FX[pb][row0 + r][lane + 1] - FX[pb][row0 + r][lane];
+                    const double dy = FY[pb][row0 + r + 1][lane] - FY[pb][row0 + r][lane];
+                    const double div = vinv * ((dx + dy) + (fz - fz_prev[r]));
+                    const double Gn = -div + 0.0;
+                    if (ROLE != ROLE_W || k - 1 >= a.wk0) {
+                        *reinterpret_cast<double *>(Gk + o.c) = Gn;
+                        if (SUB) {
+                            // rk3_substep_field! of the next stage on the cell just closed (runge_kutta_3.jl:212-226)
+                            double Uv = qz[r].s[2];
+                            if (a.has_zeta) Uv += a.dt * (a.gamma * Gn + a.zeta * gm);
+                            else            Uv += a.dt * a.gamma * Gn;
+                            *reinterpret_cast<double *>(Unk + o.c) = Uv;
+                        }
+                    }
+                }
+                fz_prev[r] = fz;
+                if (!last) {
+                    // ---- low-side x- and y-flux of plane k -> LDS ----
+                    const Win6 qx = xwin6<true>(p.q, p.so, o, qz[r].s[3]);
+                    FX[buf][row0 + r][lane] = x_flux<ROLE>(g, p, qx, ROLE == ROLE_W ? uz4[r] : load_xaux<ROLE>(p, o), i, j + r, k);
+                    const Win6 qy = ywin6<true>(p.q, p.so, o, qz[r].s[3]);
+                    FY[buf][row0 + r][lane] = y_flux<ROLE>(g, p, qy, ROLE == ROLE_W ? vz4[r] : load_yaux<ROLE>(p, o), i, j + r, k);
+                }
+            }
+        } else if (!last) {
+            if (edge_y) {
+                ColOff o;
+                o.c = yo[3];
+#pragma unroll
+                for (int n = 0; n < 6; ++n) o.r[n] = yo[n];
+                const Win6 qy = ywin6<false>(p.q, p.so, o, 0.0);
+                const Win6 aux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
+                FY[buf][NR][lane] = y_flux<ROLE>(g, p, qy, aux, i, j, k);
+            }
+            if (edge_x) {
+                asm volatile("" : "+v"(ce));
+                ColOff e;
+                e.c = ce;
+#pragma unroll
+                for (int n = 0; n < 6; ++n) e.r[n] = e.c + (unsigned)(n - 3) * s1;
+                const Win6 qxe = xwin6<false>(p.q, p.so, e, 0.0);
+                const Win6 aux = ROLE == ROLE_W ? zwin4(p.u, p.so, e, s2) : load_xaux<ROLE>(p, e);
+                FX[buf][lane][64] = x_flux<ROLE>(g, p, qxe, aux, ie, je, k);
+            }
+        }
+        p.so += s2;
+        Gk += s2;
+        if (SUB) { Unk += s2; Gmk += s2; }
+        if (!last) __syncthreads();
+    }
+}
+
+template <int NTR, int TY, int R, bool BZ, bool SUB>
+__global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_kernel(DGrid gin, RoleArgs<3 + NTR> a) {
+    constexpr int NF = 3 + NTR;
+    __shared__ double FX[2][TY * R][66];            // low-side x-fluxes of columns 0..64 (65 used, padded)
+    __shared__ double FY[2][TY * R + 1][64];        // low-side y-fluxes of rows 0..TY R
+
+    DGrid g = gin;
+    g.tx = 0; g.ty = 0; g.tz = BZ ? 1 : 0;          // compile-time topology (x, y Periodic / FullyConnected is a launch precondition)
+
+    // Blocks d and d + 8 share an XCD (observed round-robin placement). Each XCD works through a contiguous band of (tile, chunk)
+    // pairs -- neighbouring tiles, whose halo columns / rows overlap, meet in one L2 -- and the NF roles of a pair take
+    // consecutive slots of that XCD, so the planes all roles read arrive in that L2 once.
+    const unsigned d = blockIdx.x, xcd = d & 7u, slot = d >> 3;
+    const unsigned role = slot % NF, pair = xcd * (unsigned)a.band + slot / NF;
+    if (slot / NF >= (unsigned)a.band || pair >= (unsigned)a.npair) return;
+    const unsigned tile = pair % (unsigned)a.ntile, chunk = pair / (unsigned)a.ntile;
+    const int i0 = a.r.i0 + (int)(tile % (unsigned)a.ntile_x) * 64, j0 = a.r.j0 + (int)(tile / (unsigned)a.ntile_x) * (TY * R);
+    const int kc0 = a.r.k0 + (int)chunk * a.kchunk;
+    const int kc1 = min(kc0 + a.kchunk - 1, a.r.k1);
+    if (role == 0) role_march<ROLE_U, TY, R, SUB>(g, a, 0, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 1) role_march<ROLE_V, TY, R, SUB>(g, a, 1, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 2) role_march<ROLE_W, TY, R, SUB>(g, a, 2, i0, j0, kc0, kc1, FX, FY);
+    else role_march<ROLE_C, TY, R, SUB>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
+}
+
+static int g_role_kchunk = 0;      // 0: automatic
+static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgroup (bytes) to limit the workgroups per CU
+
+// Work per launch in plane-iterations: blocks x (kchunk + 1) spread over the resident workgroups (3 per CU at <= 80 VGPRs); smaller chunks balance the
+// tail, every chunk pays one extra z-flux plane and the window priming loads.
+static inline int pick_role_kchunk(long tiles_roles, int nz) {
+    int best = nz;
+    double best_cost = -1;
+    const long slots = (OCN_ROLE_WAVES >= 6 ? 3L : 2L) * g_num_cus;
+    for (int kc = 8; kc <= 64; ++kc) {
+        if (kc > nz && kc != 8) break;
+        const int nchunk = (nz + kc - 1) / kc;
+        const int kce = (nz + nchunk - 1) / nchunk;            // balanced chunk length
+        const long blocks = tiles_roles * nchunk;
+        const double per_block = kce + 1.5;
+        const double cost = (double)blocks * per_block / slots + per_block;   // perfectly spread work + one block of tail
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = kce; }
+    }
+    return best;
+}
+
+template <int NTR, int TY, int R>
+static int launch_roles_t(const DGrid &g, hipStream_t stream, RoleArgs<3 + NTR> &a, bool sub) {
+    constexpr int NF = 3 + NTR;
+    const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
+    if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
+    a.ntile_x = (nx + 63) / 64;
+    a.ntile = a.ntile_x * ((ny + TY * R - 1) / (TY * R));
+    a.kchunk = g_role_kchunk > 0 ? g_role_kchunk : pick_role_kchunk((long)a.ntile * NF, nz);
+    const int nchunk = (nz + a.kchunk - 1) / a.kchunk;
+    a.npair = a.ntile * nchunk;
+    a.band = (a.npair + 7) / 8;
+    const unsigned nblocks = (unsigned)a.band * 8u * NF;
+    const dim3 blk(64 * (TY + 1));
+#define OCN_LAUNCH_ROLES(BZV, SUBV) hipLaunchKernelGGL((role_tendency_kernel<NTR, TY, R, BZV, SUBV>), dim3(nblocks), blk, (size_t)g_role_ldspad, stream, g, a)
+    if (g.tz != 0) { if (sub) OCN_LAUNCH_ROLES(true, true); else OCN_LAUNCH_ROLES(true, false); }
+    else           { if (sub) OCN_LAUNCH_ROLES(false, true); else OCN_LAUNCH_ROLES(false, false); }
+#undef OCN_LAUNCH_ROLES
+    return 0;
+}
+
+template <int NTR>
+static int launch_roles_n(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w, const double *const *tr,
+                          double *Gu, double *Gv, double *Gw, double *const *Gc, const int *range, const FusedSubstep *sub) {
+    constexpr int NF = 3 + NTR;
+    RoleArgs<NF> a;
+    a.U[0] = u; a.U[1] = v; a.U[2] = w; a.G[0] = Gu; a.G[1] = Gv; a.G[2] = Gw;
+    for (int t = 0; t < NTR; ++t) { a.U[3 + t] = tr[t]; a.G[3 + t] = Gc[t]; }
+    a.has_zeta = sub ? sub->has_zeta : 0;
+    a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
+    for (int f = 0; f < NF; ++f) { a.Un[f] = sub ? sub->Un[f] : nullptr; a.Gm[f] = sub ? sub->Gm[f] : nullptr; }
+    const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;
+    a.s1 = Px;
+    a.s2 = (unsigned)((long)Px * Py);
+    a.off = (g.Hx - 1) + (long)Px * (g.Hy - 1);
+    if (range) {
+        a.r = Range6{range[0], range[1], range[2], range[3], range[4], range[5]};
+        a.wk0 = a.r.k0;                                   // KernelParameters launches ignore exclude_periphery
+    } else {
+        a.r = Range6{1, g.Nx, 1, g.Ny, 1, g.Nz};
+        a.wk0 = (g.tz != 0 && g.Nz > 1) ? 2 : 1;          // exclude_periphery: w tendencies start at k = 2 on Bounded z
+    }
+    // R = 2 rows per row wave is implemented (template parameter) and bit-identical, but measured slower at 256^3 (1.70 vs 1.52 ms at
+    // four waves per SIMD): only R = 1 is instantiated
+    return launch_roles_t<NTR, 7, 1>(g, stream, a, sub != nullptr);
+}
+
+static inline int launch_role_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,
+                                       const double *const *tr, int ntr, double *Gu, double *Gv, double *Gw, double *const *Gc,
+                                       const int *range, const FusedSubstep *sub = nullptr) {
+    switch (ntr) {
+        case 0: return launch_roles_n<0>(g, stream, u, v, w, tr, Gu, Gv, Gw, Gc, range, sub);
+        case 1: return launch_roles_n<1>(g, stream, u, v, w, tr, Gu, Gv, Gw, Gc, range, sub);
+        case 2: return launch_roles_n<2>(g, stream, u, v, w, tr, Gu, Gv, Gw, Gc, range, sub);
+        case 3: return launch_roles_n<3>(g, stream, u, v, w, tr, Gu, Gv, Gw, Gc, range, sub);
+        default: return -2;
+    }
+}

@@ -42,8 +42,9 @@ def test_tendencies_match_oracle(ocn, oracle, arch, topology):
     set_both(ocn, m_gpu, m_cpu, seed=11, enforce_incompressibility=False)
     ocn.update_state(m_gpu, True)
     m_cpu.update_state(True)
-    # per-field kernels (the reference's launch structure), fused register-window kernel, fused LDS-tile kernel
-    for impl, lds in ((0, 0), (1, 0), (1, 1)):
+    # per-field kernels (the reference's launch structure), all-fields register-window kernel, its LDS-tile variant, the
+    # one-field-per-workgroup kernel (the default)
+    for impl, lds in ((0, 0), (1, 0), (1, 1), (2, 0)):
         m_gpu.set_option("tendency_impl", impl)
         m_gpu.set_option("fused_lds", lds)
         for n in m_gpu.fields():
@@ -54,6 +55,7 @@ def test_tendencies_match_oracle(ocn, oracle, arch, topology):
             G_cpu = m_cpu.field("G" + cn)
             assert np.array_equal(G_gpu, G_cpu), (impl, lds, n, np.abs(G_gpu - G_cpu).max())
     m_gpu.set_option("fused_lds", 0)
+    m_gpu.set_option("tendency_impl", 2)
 
 
 @pytest.mark.parametrize("topology,stretched", [(TOPOS[0], False), (TOPOS[1], True), (TOPOS[1], False),
@@ -266,8 +268,9 @@ def test_model_with_boundary_conditions_matches_oracle(ocn, oracle, arch):
         ocn.NonhydrostaticModel(grid=g_gpu, boundary_conditions={"T": _fbcs(ocn, dict(west=("Flux", 1.0)))})
 
 
+@pytest.mark.parametrize("impl", [1, 2])
 @pytest.mark.parametrize("topology", TOPOS)
-def test_fused_substep_is_bit_identical_to_separate_kernels(ocn, arch, topology):
+def test_fused_substep_is_bit_identical_to_separate_kernels(ocn, arch, topology, impl):
     """RK3 substeps of stages 2 and 3 fused into the preceding tendency evaluation (second set of prognostic arrays, swapped
     twice per step) against rk3_substep! as its own launch: same IEEE operation order => identical bits, stable pointers"""
     size = (64, 20, 18)
@@ -276,6 +279,7 @@ def test_fused_substep_is_bit_identical_to_separate_kernels(ocn, arch, topology)
     for fuse in (1, 0):
         grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
         model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+        model.set_option("tendency_impl", impl)
         model.set_option("fuse_substep", fuse)
         assert model.get_option("fuse_substep_active") == fuse and model.get_option("fused_tendency_active") == 1
         from helpers import smooth_state
