@@ -36,11 +36,14 @@ FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL = 80.0
 V100_PUBLISHED_CELL_UPDATES = 256 ** 3 / 56.444e-3   # 256^3 F64 WENO 56.444 ms on a V100 (v0.58.8)
 
 
+PROFILE_TAG = {1: "r01", 2: "r02"}      # committed rocprofv3 summaries of the all-fields kernel (round 1) and the role kernel
+
+
 def measured_traffic(tendency_impl, N):
     """HBM bytes per tendency launch from the committed rocprofv3 PMC passes (profiles/, FETCH_SIZE and WRITE_SIZE collected
     in separate runs and calibrated as MI355X_MICROARCH.md prescribes); None when no profile matches this configuration"""
-    path = os.path.join(ROOT, "profiles", "r01_tendency_traffic.json")
-    if tendency_impl != 1 or N != 256 or not os.path.exists(path):
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG.get(tendency_impl, 'none')}_tendency_traffic.json")
+    if N != 256 or not os.path.exists(path):
         return None
     try:
         return float(json.load(open(path))["hbm_bytes_per_launch"])
@@ -48,20 +51,36 @@ def measured_traffic(tendency_impl, N):
         return None
 
 
+# Measured issue cost of the instruction classes of the WENO flux on MI355X (tools/valu_rates.hip, profiles/r02_valu_rates.txt):
+# ns per wave64 instruction per SIMD with 4 waves resident, every SIMD of the chip busy -- i.e. at the clock the chip HOLDS under
+# that load (1.8-2.3 GHz by class), not at the 2.4 GHz of the data sheet. FP64 mul / fma / add issue every 4 cycles.
+VALU_NS = {"SQ_INSTS_VALU_FMA_F64": 2.27, "SQ_INSTS_VALU_MUL_F64": 2.32, "SQ_INSTS_VALU_ADD_F64": 1.99, "SQ_INSTS_VALU_CVT": 1.75,
+           "SQ_INSTS_VALU_FMA_F32": 1.19, "SQ_INSTS_VALU_INT32": 1.11, "SQ_INSTS_VALU_TRANS_F32": 3.44, "SQ_INSTS_VALU_TRANS_F64": 6.94}
+VALU_NS_OTHER = 1.5               # selects, 64-bit moves, compares (1.1-1.9 measured)
+
+
 def measured_valu(tendency_impl, N, t_launch):
-    """FP64 issue-side roofline of the same kernel (its binding roof): VALU wave-instructions per launch from the
-    committed SQ_INSTS_VALU pass over the live launch time, against 256 CUs x 4 SIMDs x one wave64 FP64 instruction per
-    4 cycles x 2.4 GHz"""
-    path = os.path.join(ROOT, "profiles", "r01_tendency_valu.json")
-    if tendency_impl != 1 or N != 256 or not os.path.exists(path) or not t_launch:
+    """Issue-side roofline of the same kernel (its binding roof): the VALU wave-instructions per launch by class
+    (committed SQ_INSTS_VALU* passes) priced with the measured per-class issue cost -> the time the instruction stream needs on
+    1024 fully busy SIMDs; frac = that floor / the live launch time"""
+    path = os.path.join(ROOT, "profiles", f"{PROFILE_TAG.get(tendency_impl, 'none')}_tendency_valu.json")
+    if N != 256 or not os.path.exists(path) or not t_launch:
         return None
     try:
-        n = float(json.load(open(path))["counters_per_launch"]["SQ_INSTS_VALU"])
+        c = json.load(open(path))["counters_per_launch"]
+        n = float(c["SQ_INSTS_VALU"])
     except (OSError, ValueError, KeyError):
         return None
-    peak = 256 * 4 * 2.4e9 / 4 / 1e9
-    return {"wave_instructions_per_launch": n, "achieved": n / t_launch / 1e9, "peak": peak, "unit": "G wave-instr/s",
-            "frac": n / t_launch / 1e9 / peak, "source": "profiles/r01_tendency_valu.json (rocprofv3 --pmc SQ_INSTS_VALU)"}
+    classed = {k: float(c[k]) for k in VALU_NS if k in c}
+    if classed:
+        floor_s = (sum(v * VALU_NS[k] for k, v in classed.items()) + (n - sum(classed.values())) * VALU_NS_OTHER) * 1e-9 / 1024
+        weighting = "measured FP64 / FP32 / conversion / transcendental / integer mix x measured issue cost per class"
+    else:                          # round-1 profile: total only -- every instruction at the FP64 rate
+        floor_s = n * 2.3e-9 / 1024
+        weighting = "all instructions priced as FP64 (no class counters in this profile)"
+    return {"wave_instructions_per_launch": n, "per_cell": n * 64 / float(N) ** 3, "issue_floor_ms": 1e3 * floor_s,
+            "achieved": n / t_launch / 1e9, "peak": n / floor_s / 1e9, "unit": "G wave-instr/s", "frac": floor_s / t_launch,
+            "weighting": weighting, "source": os.path.relpath(path, ROOT) + " + profiles/r02_valu_rates.txt"}
 
 
 def initial_state(ocn, model, seed=1234):
@@ -141,7 +160,8 @@ def main():
     ap.add_argument("--global-size", type=int, default=0,
                     help="fixed GLOBAL grid G^3 split into x-slabs over the ranks (strong scaling; 512 = BASELINE.json configs[3] at "
                          "--gpus 8). Default 0: weak scaling, --size^3 cells per GPU, global (size*N) x size x size")
-    ap.add_argument("--tendency-impl", type=int, default=1)
+    ap.add_argument("--tendency-impl", type=int, default=2,
+                    help="2: one field per workgroup (default); 1: all-fields kernel of round 1; 0: per-field kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="ppp", choices=["ppp", "ppb_stretched", "ppb_physics", "ppb_amd"],
                     help="ppp: BASELINE.json configs[1] (the metric's configuration, default); ppb_stretched: configs[2], "
@@ -271,15 +291,15 @@ def main():
         "dtype": "f64", "data": "synthetic; SELF-LOOP: one rank running the N > 1 code path with device copies instead of RCCL transfers" if (distributed and os.environ.get("OCN_SELF_LOOP") == "1" and world == 1)
         else "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
         else "synthetic; REHEARSAL on one card over gloo + host staging: not a measurement",
-        "config": {"workload": (f"{gshape} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
-                                "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing " +
-                                ("(BASELINE.json configs[3] grid)" if args.global_size == 512 else
-                                 "(fixed global grid)" if args.global_size else
-                                 "(BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU: {N}^3 cells on each of {world} x-slabs; "
-                                                                "at 8 GPUs the cell count of configs[3]'s 512^3") + ")"))
+        "config": {"workload": (("BASELINE.json configs[3] grid: " if args.global_size == 512 else
+                                 "fixed global grid: " if args.global_size else
+                                 "BASELINE.json configs[1]" + ("" if world == 1 else f" per GPU ({N}^3 cells on each of {world} x-slabs; "
+                                                               "at 8 GPUs the cell count of configs[3]'s 512^3)") + ": ") +
+                                f"{gshape} triply-periodic NonhydrostaticModel, WENO(order=5), tracers (T,S), "
+                                "RK3, FFT Poisson solve, closure/buoyancy/coriolis = nothing")
                    if args.workload == "ppp" else
-                   (f"{N * world}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), tracers (T,S), RK3, "
-                    "Fourier-tridiagonal Poisson solve (BASELINE.json configs[2])" +
+                   ("BASELINE.json configs[2]: " + f"{N * world}x{N}x{N // 2} (Periodic, Periodic, Bounded) tanh-stretched z, WENO(order=5), "
+                    "tracers (T,S), RK3, Fourier-tridiagonal Poisson solve" +
                     ("; + ScalarDiffusivity, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (SURVEY 8f.1 physics)"
                      if args.workload == "ppb_physics" else
                      "; + AnisotropicMinimumDissipation, linear SeawaterBuoyancy, Flux / Gradient boundary conditions (the physics of "
@@ -291,13 +311,16 @@ def main():
                    "dt": dt, "max_abs_divergence_after_run": div,
                    "vs_baseline_note": "published 56.444 ms on V100 (Oceananigans v0.58.8, docs/src/appendix/"
                                        "benchmarks.md:128); older version without RK3/2 tracers -- context only"},
-        "roofline": {"kernel": "fused WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS) [+ RK3 substep of the next stage on 2 of 3 launches]"
-                     if args.tendency_impl == 1
+        "roofline": {"kernel": ("role_tendency_kernel: " if args.tendency_impl == 2 else "fused_tendency_kernel: ") +
+                     "flux-sharing WENO-5 tendency evaluation (Gu, Gv, Gw, GT, GS), one launch [+ RK3 substep of the next stage on 2 of 3 launches]"
+                     if args.tendency_impl in (1, 2)
                      else "per-field WENO-5 tendency kernels (5 launches)",
                      "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     # the strict accounting of SURVEY.md 8(d): 80 B/cell on every launch, substep traffic not counted
+                     "frac_80B": TENDENCY_BYTES_PER_CELL * cells_per_gpu / t_launch / 1e9 / HBM_PEAK_GBS if tend_n else None,
                      "traffic": measured_traffic(args.tendency_impl, N) if world == 1 and args.workload == "ppp" else None,
-                     "traffic_source": "profiles/r01_tendency_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                     "traffic_source": f"profiles/{PROFILE_TAG.get(args.tendency_impl, 'none')}_tendency_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                      "algorithmic_bytes_per_launch": bytes_per_cell * cells_per_gpu,
                      "algorithmic_bytes_note": ("average over the 3 launches of a time-step: 80 B/cell (tendencies) + 80 B/cell on the 2 "
                                                 "launches that carry the fused RK3 substep of the next stage") if fused_substep

@@ -13,7 +13,8 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+suffix = sys.argv[2] if len(sys.argv) > 2 else "256cubed"      # name of the workload in the output files
 N = 256
 cells = float(N) ** 3
 out = os.path.join(ROOT, "gpurun_out")
@@ -33,7 +34,7 @@ def short(name):
 bench_line = [l for l in open(os.path.join(out, f"{tag}_stats.log")) if l.startswith('{"metric"')]
 bench = json.loads(bench_line[0]) if bench_line else {}
 rows = list(csv.DictReader(open(one(f"{tag}_stats/**/*kernel_stats.csv"))))
-dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_256cubed.csv")
+dst = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{suffix}.csv")
 with open(dst, "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline  (MI355X, 256^3)\n")
     if bench:
@@ -59,7 +60,7 @@ sub = "rk3_substep_kernel"
 known_read, known_write = 80.0, 40.0          # B/cell of the stage-1 substep (U, Gn read; U written)
 cal_f = known_read / (sum(fetch[sub]) / len(fetch[sub]) / cells) if fetch.get(sub) else 1.6
 cal_w = known_write / (sum(write[sub]) / len(write[sub]) / cells) if write.get(sub) else 1.0
-dst = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_256cubed.csv")
+dst = os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic_{suffix}.csv")
 tend = None
 with open(dst, "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 3 --warmup 1, MI355X 256^3\n")
@@ -70,13 +71,18 @@ with open(dst, "w") as f:
         fr = sum(fetch[k]) / len(fetch[k]) / cells
         wr = sum(write[k]) / len(write[k]) / cells if write.get(k) else float("nan")
         f.write(f"\"{k}\",{len(fetch[k])},{fr:.1f},{wr:.1f},{fr * cal_f:.1f}\n")
-        if "fused_tendency_kernel" in k and tend is None:
-            tend = (k, sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k]))
+        if "tendency_kernel<" in k:
+            tend = (tend or []) + [(k, len(fetch[k]), sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k]))]
 print("wrote", dst)
 if tend:
     dst = os.path.join(ROOT, "profiles", f"{tag}_tendency_traffic.json")
-    json.dump({"kernel": tend[0], "fetch_bytes_per_launch_raw": tend[1], "write_bytes_per_launch_raw": tend[2],
-               "fetch_calibration": cal_f, "hbm_bytes_per_launch": tend[1] * cal_f + tend[2],
+    nl = sum(t[1] for t in tend)
+    fr, wr = sum(t[1] * t[2] for t in tend) / nl, sum(t[1] * t[3] for t in tend) / nl
+    json.dump({"kernel": " + ".join(t[0] for t in tend), "launches": {t[0]: t[1] for t in tend},
+               "per_instantiation": {t[0]: {"fetch_bytes_per_launch_raw": t[2], "write_bytes_per_launch_raw": t[3],
+                                            "hbm_bytes_per_launch": t[2] * cal_f + t[3]} for t in tend},
+               "fetch_bytes_per_launch_raw": fr, "write_bytes_per_launch_raw": wr,
+               "fetch_calibration": cal_f, "hbm_bytes_per_launch": fr * cal_f + wr,
                "note": "average over all launches of the run (2 of 3 launches per time-step carry the fused RK3 substep); FETCH_SIZE x "
                        "calibration (rk3_substep_kernel, same 8-B/lane streaming pattern) + WRITE_SIZE; counts Infinity-Cache hits "
                        "too (MI355X_MICROARCH.md HBM section)"}, open(dst, "w"), indent=1)
@@ -88,13 +94,25 @@ if vfile:
     acc = defaultdict(lambda: defaultdict(list))
     for r in csv.DictReader(open(vfile[0])):
         acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    k = [k for k in acc if "fused_tendency_kernel" in k]
+    k = [k for k in acc if "tendency_kernel<" in k]
     if k:
-        c = {n: sum(v) / len(v) for n, v in acc[k[0]].items()}
+        merged = defaultdict(list)    # all instantiations (with / without the fused substep): launch-weighted average
+        for kk in k:
+            for n, v in acc[kk].items():
+                merged[n] += v
+        c = {n: sum(v) / len(v) for n, v in merged.items()}
+        mfile = sorted(glob.glob(os.path.join(out, f"{tag}_mix/**/*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
+        if mfile:                     # instruction classes of the same kernels (a second pass: 8 SQ counters per pass)
+            macc = defaultdict(list)
+            for r in csv.DictReader(open(mfile[0])):
+                if short(r["Kernel_Name"]) in k:
+                    macc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            c.update({n: sum(v) / len(v) for n, v in macc.items()})
         dst = os.path.join(ROOT, "profiles", f"{tag}_tendency_valu.json")
-        json.dump({"kernel": k[0], "counters_per_launch": c,
+        json.dump({"kernel": " + ".join(k), "counters_per_launch": c,
                    "valu_wave_instructions_per_cell": c.get("SQ_INSTS_VALU", 0) * 64 / cells,
-                   "note": "rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE, averaged over the launches of "
-                           "bench.py --steps 3; a wave64 FP64 instruction occupies a SIMD for 4 cycles (16 lanes/cycle)"},
+                   "note": "rocprofv3 --pmc passes (SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY "
+                           "SQ_WAIT_INST_ANY SQ_WAVES; instruction classes in a second pass), averaged over the launches of bench.py "
+                           "--steps 3 (2 of 3 launches carry the fused RK3 substep); SQ cycle counters are in quad-cycles"},
                   open(dst, "w"), indent=1)
         print("wrote", dst)
