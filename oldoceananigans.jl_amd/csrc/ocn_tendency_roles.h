@@ -262,8 +262,6 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
 #pragma unroll
                 for (int n = 0; n < 6; ++n) o.r[n] = yo[r + n];
                 const bool close_cell = k > kc0 && cell_r[r];
-                double gm = 0;
-                if (SUB && a.has_zeta && close_cell) gm = *reinterpret_cast<const double *>(Gmk + o.c);
 #pragma unroll
                 for (int n = 0; n < 5; ++n) qz[r].s[n] = qz[r].s[n + 1];
                 qz[r].s[5] = ldb<24>(p.q, o.c, p.so + 2u * s2);
@@ -274,7 +272,12 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
                     vz4[r].s[4] = ldb<24>(p.v, o.c, p.so + s2);
                 }
                 // ---- z-flux through the bottom face of cell k, then close cell k-1 ----
-                const double fz = z_flux<ROLE>(g, load_zin<ROLE>(p, p.so, o), i, j + r, k, qz[r]);
+                const Win6 zin = load_zin<ROLE>(p, p.so, o);
+                // the previous tendency of the cell about to be closed: a cold line, issued behind the loads the z-flux waits for
+                // (loads return in issue order: issued first it held up every wait of the iteration, 1.48 -> 1.42 ms per launch)
+                double gm = 0;
+                if (SUB && a.has_zeta && close_cell) gm = *reinterpret_cast<const double *>(Gmk + o.c);
+                const double fz = z_flux<ROLE>(g, zin, i, j + r, k, qz[r]);
                 if (close_cell) {
                     const int pb = buf ^ 1;
                     const long pkm = pk - 1;

@@ -17,7 +17,7 @@ variants = [(1, 7, 0, 0), (2, 1, 0, 0), (2, 1, 16, 0), (2, 1, 32, 0)]
 for impl, ty, kc, dbg in variants:
     model.set_option("tendency_impl", impl)
     if impl == 2:
-        model.set_option("role_kchunk", kc); model.set_option("role_rows", ty)
+        model.set_option("role_kchunk", kc)
     for n in flds:
         model.tendency(n).set_parent(np.zeros(model.tendency(n).shape))
     ocn.update_state(model, True); ocn.synchronize()
