@@ -4,7 +4,7 @@
 #   -fhip-fp32-correctly-rounded-divide-sqrt : exact Float32 reciprocal in newton_div
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="$here/libocn_mi355x.so"
+out="${OCN_OUT:-$here/libocn_mi355x.so}"   # OCN_OUT / OCN_EXTRA_FLAGS: alternative builds for A/B timing (tools/)
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared \
     -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math \

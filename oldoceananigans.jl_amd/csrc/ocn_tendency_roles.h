@@ -21,6 +21,9 @@
 #ifndef OCN_ROLE_WAVES
 #define OCN_ROLE_WAVES 6      // waves per SIMD the register allocation must allow (8-wave workgroups: 4 = two per CU, 6 = three)
 #endif
+#ifndef OCN_ROLE_ABLATE
+#define OCN_ROLE_ABLATE 0     // timing experiments only (WRONG RESULTS when non-zero): 1 hot z-window load, 2 no previous-tendency load,
+#endif                        // 4 no stores, 8 x / y windows from registers, 16 no barrier, 32 idle edge wave
 enum { ROLE_U = 0, ROLE_V = 1, ROLE_W = 2, ROLE_C = 3 };
 
 template <int NF>
@@ -44,8 +47,17 @@ struct RoleArgs {
 // that the six x-neighbours are the immediates 0 .. 40.
 typedef __amdgpu_buffer_rsrc_t Rsrc;
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+// num_records = 2 GiB (parent arrays are smaller: checked on the host): a per-thread offset with bit 31 set is OUT OF RANGE, the
+// hardware drops such a store and returns 0 for such a load. Lanes that must not access memory get that bit (ROLE_OOB) instead
+// of a branch around the instruction -- the instruction stream between two waits stays free of control flow, which is what lets
+// the compiler count the younger operations exactly (s_waitcnt vmcnt(n)).
+// per-level metric tables are read-only for the kernel's lifetime: addressed through the constant address space, their
+// (wave-uniform) elements come in through the scalar cache instead of as vector loads that occupy VGPRs and the vmcnt queue
+typedef const double __attribute__((address_space(4))) *KTab;
+__device__ __forceinline__ KTab ktab(const double *p) { return (KTab)p; }
+#define ROLE_OOB 0x80000000u
 __device__ __forceinline__ Rsrc make_rsrc(const void *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, 0xFFFFFFFFu, 0x00020000);   // raw buffer, no range clamp in use
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)ROLE_OOB, 0x00020000);   // raw buffer
 }
 template <int IMM> __device__ __forceinline__ double ldb(Rsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + (unsigned)IMM), (int)soff, 0));
@@ -54,8 +66,10 @@ template <int IMM> __device__ __forceinline__ void stb(Rsrc r, unsigned voff, un
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)(voff + (unsigned)IMM), (int)soff, 0);
 }
 
-// per-thread loop-invariant offsets: c = byte offset of (i - 3, j); r[n] = byte offset of (i - 3, j - 3 + n)
-struct ColOff { unsigned c, r[6]; };
+// per-thread loop-invariant offset: c = byte offset of (i - 3, j) inside a plane; sr[n] = scalar byte offset of row j - 3 + n
+// relative to row j, folded into the scalar offset of the access (n = 3 is the own row). The per-thread state of all six rows of a
+// y-window is ONE VGPR; the row displacement rides on the scalar unit.
+struct ColOff { unsigned c; unsigned s1; };     // s1 = row stride in bytes (wave-uniform)
 
 // x-direction windows around column i: immediates 0 .. 40 (centre 24)
 template <bool OWN> __device__ __forceinline__ Win6 xwin6(Rsrc b, unsigned so, const ColOff &o, double centre) {
@@ -74,14 +88,14 @@ __device__ __forceinline__ Win6 xwin4(Rsrc b, unsigned so, const ColOff &o) {
 template <bool OWN> __device__ __forceinline__ Win6 ywin6(Rsrc b, unsigned so, const ColOff &o, double centre) {
     Win6 w;
 #pragma unroll
-    for (int n = 0; n < 6; ++n) w.s[n] = (OWN && n == 3) ? centre : ldb<24>(b, n == 3 ? o.c : o.r[n], so);
+    for (int n = 0; n < 6; ++n) w.s[n] = (OWN && n == 3) ? centre : ldb<24>(b, o.c, so + (unsigned)(n - 3) * o.s1);
     return w;
 }
 __device__ __forceinline__ Win6 ywin4(Rsrc b, unsigned so, const ColOff &o) {
     Win6 w;
     w.s[0] = 0.0; w.s[5] = 0.0;
 #pragma unroll
-    for (int n = 1; n < 5; ++n) w.s[n] = ldb<24>(b, n == 3 ? o.c : o.r[n], so);
+    for (int n = 1; n < 5; ++n) w.s[n] = ldb<24>(b, o.c, so + (unsigned)(n - 3) * o.s1);
     return w;
 }
 // z-direction 4-window (levels k-2 .. k+1) straight from memory (edge wave of role w only)
@@ -101,8 +115,7 @@ struct PlaneCtx {
     const double *axz, *ayz;   // Ax, Ay at levels k-2 ..
 };
 
-// ---- loads and arithmetic of the three low-side fluxes of field ROLE at (i, j, k), kept apart so that a row wave can issue the
-// loads of plane k + 1 before the barrier that ends plane k (they are in flight while the workgroup synchronises) ----
+// ---- loads and arithmetic of the three low-side fluxes of field ROLE at (i, j, k) ----
 // z-flux inputs besides the own z-window: the advecting w along x (role u) / along y (role v), indices 1 .. 4; w at the face (tracers)
 template <int ROLE> __device__ __forceinline__ Win6 load_zin(const PlaneCtx &p, unsigned so, const ColOff &o) {
     if (ROLE == ROLE_U) return xwin4(p.w, so, o);
@@ -184,63 +197,62 @@ __device__ __forceinline__ double y_flux(const DGrid &g, const PlaneCtx &p, cons
     }
 }
 
-// One workgroup = TY row waves + one edge wave, all working on field `fidx`. A row wave owns R consecutive rows of the tile (R = 2:
-// half as many barriers, LDS round trips and edge fluxes per cell, and the y-windows of its two rows share five of their six rows);
-// the edge wave evaluates the y-fluxes of the row above the tile and the x-fluxes of the column right of it (one lane per row).
-template <int ROLE, int TY, int R, bool SUB, typename Args>
+// One workgroup = TY row waves + one edge wave, all working on field `fidx`. A row wave owns one row of the tile (two rows per wave
+// were implemented and measured slower: 1.70 vs 1.52 ms); the edge wave evaluates the y-fluxes of the row above the tile and the
+// x-fluxes of the column right of it (one lane per row).
+//
+// Order of the memory operations of a row wave within one plane. gfx950 counts loads AND stores with one in-order counter (vmcnt):
+// a wait for any load also waits for every older operation. The operations with long latencies -- the first touch of plane k + 3
+// of the own field, the previous tendency, the stores of the cell just closed -- are therefore issued together as the YOUNGEST
+// operations of the plane, right behind the loads of the y-window, so that no wait of this plane includes them: they have the
+// arithmetic of the y-flux, the barrier and the first loads of the next plane to complete. The new element of the z-window
+// arrives one plane ahead of its use (qn), the previous tendency of the cell closed in the next plane likewise (gmn).
+template <int ROLE, int TY, bool SUB, typename Args>
 __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const int fidx, const int i0, const int j0, const int kc0,
-                                           const int kc1, double (*FX)[TY * R][66], double (*FY)[TY * R + 1][64]) {
-    constexpr int NR = TY * R;                        // rows per tile
+                                           const int kc1, double (*FX)[TY][66], double (*FY)[TY + 1][64]) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const bool edge = wave == TY;
     const int i = i0 + lane;
-    const int row0 = edge ? NR : wave * R;            // first tile row of this wave (edge wave: the row above the tile)
+    const int row0 = wave;                            // tile row of this wave (edge wave: the row above the tile)
     const int j = j0 + row0;
-    const bool flux_i = !edge && i <= a.r.i1 + 1, cell_i = !edge && i <= a.r.i1;
+    const bool flux_r = !edge && i <= a.r.i1 + 1 && j <= a.r.j1 + 1, cell_r = !edge && i <= a.r.i1 && j <= a.r.j1;
     const bool edge_y = edge && i <= a.r.i1 && j <= a.r.j1 + 1;
     const int ie = i0 + 64, je = j0 + lane;
-    const bool edge_x = edge && lane < NR && ie <= a.r.i1 + 1 && je <= a.r.j1;
+    const bool edge_x = edge && lane < TY && ie <= a.r.i1 + 1 && je <= a.r.j1;
 
-    const unsigned s1 = 8u * (unsigned)a.s1, s2 = 8u * a.s2;         // byte strides
+    const unsigned s2 = 8u * a.s2;                    // plane stride in bytes
     const int Hz = g.Hz;
-    // byte offsets inside a plane, biased by -3 columns: yo[m] = (i - 3, j - 3 + m), m = 0 .. R + 4 (rows of the y-windows of the R
-    // own rows); the edge wave's second job is column i0 + 64 of row j0 + lane
-    unsigned yo[R + 5];
-#pragma unroll
-    for (int m = 0; m < R + 5; ++m) yo[m] = 8u * (unsigned)(a.off + i - 3 + (long)a.s1 * (j - 3 + m));
-    unsigned ce = 8u * (unsigned)(a.off + ie - 3 + (long)a.s1 * je);
+    ColOff o, e;                                      // (i - 3, j); the edge wave's second job: column i0 + 64 of row j0 + lane
+    o.s1 = e.s1 = 8u * (unsigned)a.s1;
+    o.c = 8u * (unsigned)(a.off + i - 3 + (long)a.s1 * j);
+    e.c = 8u * (unsigned)(a.off + ie - 3 + (long)a.s1 * je);
 
     PlaneCtx p;
     p.u = make_rsrc(a.U[0]); p.v = make_rsrc(a.U[1]); p.w = make_rsrc(a.U[2]);
     p.q = ROLE == ROLE_U ? p.u : (ROLE == ROLE_V ? p.v : (ROLE == ROLE_W ? p.w : make_rsrc(a.U[fidx])));
     p.s2 = s2;
     p.so = s2 * (unsigned)(kc0 - 1 + Hz);             // plane of level kc0
-    // the streams touched once per cell (tendency out, previous tendency in, next-stage field out): plain plane pointers, level k - 1
-    char *Gk = reinterpret_cast<char *>(a.G[fidx]) + (size_t)p.so - s2 + 24;
-    char *Unk = SUB ? reinterpret_cast<char *>(a.Un[fidx]) + (size_t)p.so - s2 + 24 : nullptr;
-    const char *Gmk = SUB ? reinterpret_cast<const char *>(a.Gm[fidx]) + (size_t)p.so - s2 + 24 : nullptr;
+    // the streams touched once per cell: tendency out, previous tendency in (a.Gm is the tendency array itself when the substep has
+    // no zeta: loaded and not used), next-stage field out
+    const Rsrc rG = make_rsrc(a.G[fidx]), rUn = make_rsrc(SUB ? a.Un[fidx] : a.G[fidx]), rGm = make_rsrc(SUB ? a.Gm[fidx] : a.G[fidx]);
+    const unsigned cell_off = cell_r ? 0u : ROLE_OOB;
 
-    double fz_prev[R];
-    Win6 qz[R], uz4[R], vz4[R];                       // own 6-deep z-windows; role w: u, v at levels k-2 .. k+1 (indices 1 .. 4)
-    bool flux_r[R], cell_r[R];
+    double fz_prev = 0, qn = 0, gmn = 0, un = 0, vn = 0;
+    Win6 qz, uz4, vz4;                                // own 6-deep z-window; role w: u, v at levels k-2 .. k+1 (indices 1 .. 4)
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        fz_prev[r] = 0;
-        flux_r[r] = flux_i && j + r <= a.r.j1 + 1;
-        cell_r[r] = cell_i && j + r <= a.r.j1;
+    for (int n = 0; n < 6; ++n) { qz.s[n] = 0; uz4.s[n] = 0; vz4.s[n] = 0; }
+    if (flux_r) {
 #pragma unroll
-        for (int n = 0; n < 6; ++n) { qz[r].s[n] = 0; uz4[r].s[n] = 0; vz4[r].s[n] = 0; }
-        if (flux_r[r]) {
+        for (int n = 0; n < 5; ++n) qz.s[n + 1] = ldb<24>(p.q, o.c, p.so + (unsigned)(n - 3) * s2);   // levels kc0-3 .. kc0+1
+        qn = ldb<24>(p.q, o.c, p.so + 2u * s2);                                                        // level kc0+2
+        if (ROLE == ROLE_W) {
 #pragma unroll
-            for (int n = 0; n < 5; ++n) qz[r].s[n + 1] = ldb<24>(p.q, yo[r + 3], p.so + (unsigned)(n - 3) * s2);   // levels kc0-3 .. kc0+1
-            if (ROLE == ROLE_W) {
-#pragma unroll
-                for (int n = 1; n < 4; ++n) {                                                                      // levels kc0-2 .. kc0
-                    uz4[r].s[n + 1] = ldb<24>(p.u, yo[r + 3], p.so + (unsigned)(n - 3) * s2);
-                    vz4[r].s[n + 1] = ldb<24>(p.v, yo[r + 3], p.so + (unsigned)(n - 3) * s2);
-                }
+            for (int n = 1; n < 4; ++n) {                                                              // levels kc0-2 .. kc0
+                uz4.s[n + 1] = ldb<24>(p.u, o.c, p.so + (unsigned)(n - 3) * s2);
+                vz4.s[n + 1] = ldb<24>(p.v, o.c, p.so + (unsigned)(n - 3) * s2);
             }
+            un = ldb<24>(p.u, o.c, p.so + s2); vn = ldb<24>(p.v, o.c, p.so + s2);                      // level kc0+1
         }
     }
 
@@ -248,97 +260,88 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
         const bool last = k == kc1 + 1;               // peeled plane: only the z-fluxes closing the cells of level kc1
         const int buf = k & 1;
         const long pk = (long)(k - 1 + Hz);
-        p.axk = g.ax[pk]; p.ayk = g.ay[pk];
+        p.axk = ktab(g.ax)[pk]; p.ayk = ktab(g.ay)[pk];
         p.axz = g.ax + pk - 2; p.ayz = g.ay + pk - 2;
         // keep the 32-bit offsets opaque per iteration, so that `offset + constant` stays inside the loop and folds into the immediate
-#pragma unroll
-        for (int m = 0; m < R + 5; ++m) asm volatile("" : "+v"(yo[m]));
+        asm volatile("" : "+v"(o.c));
         if (!edge) {
+            if (flux_r) {
+                const bool close_cell = k > kc0 && cell_r;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                if (!flux_r[r]) continue;
-                ColOff o;
-                o.c = yo[r + 3];
-#pragma unroll
-                for (int n = 0; n < 6; ++n) o.r[n] = yo[r + n];
-                const bool close_cell = k > kc0 && cell_r[r];
-#pragma unroll
-                for (int n = 0; n < 5; ++n) qz[r].s[n] = qz[r].s[n + 1];
-                qz[r].s[5] = ldb<24>(p.q, o.c, p.so + 2u * s2);
+                for (int n = 0; n < 5; ++n) qz.s[n] = qz.s[n + 1];
+                qz.s[5] = qn;
                 if (ROLE == ROLE_W) {
 #pragma unroll
-                    for (int n = 1; n < 4; ++n) { uz4[r].s[n] = uz4[r].s[n + 1]; vz4[r].s[n] = vz4[r].s[n + 1]; }
-                    uz4[r].s[4] = ldb<24>(p.u, o.c, p.so + s2);
-                    vz4[r].s[4] = ldb<24>(p.v, o.c, p.so + s2);
+                    for (int n = 1; n < 4; ++n) { uz4.s[n] = uz4.s[n + 1]; vz4.s[n] = vz4.s[n + 1]; }
+                    uz4.s[4] = un; vz4.s[4] = vn;
                 }
                 // ---- z-flux through the bottom face of cell k, then close cell k-1 ----
                 const Win6 zin = load_zin<ROLE>(p, p.so, o);
-                // the previous tendency of the cell about to be closed: a cold line, issued behind the loads the z-flux waits for
-                // (loads return in issue order: issued first it held up every wait of the iteration, 1.48 -> 1.42 ms per launch)
-                double gm = 0;
-                if (SUB && a.has_zeta && close_cell) gm = *reinterpret_cast<const double *>(Gmk + o.c);
-                const double fz = z_flux<ROLE>(g, zin, i, j + r, k, qz[r]);
+                const double fz = z_flux<ROLE>(g, zin, i, j, k, qz);
+                double Gn = 0, Uv = 0;
+                bool store = false;
                 if (close_cell) {
                     const int pb = buf ^ 1;
                     const long pkm = pk - 1;
-                    const double vinv = ROLE == ROLE_W ? g.vinv_f[pkm] : g.vinv_c[pkm];
-                    const double dx = FX[pb][row0 + r][lane + 1] - FX[pb][row0 + r][lane];
-                    const double dy = FY[pb][row0 + r + 1][lane] - FY[pb][row0 + r][lane];
-                    const double div = vinv * ((dx + dy) + (fz - fz_prev[r]));
-                    const double Gn = -div + 0.0;
-                    if (ROLE != ROLE_W || k - 1 >= a.wk0) {
-                        *reinterpret_cast<double *>(Gk + o.c) = Gn;
-                        if (SUB) {
-                            // rk3_substep_field! of the next stage on the cell just closed (runge_kutta_3.jl:212-226)
-                            double Uv = qz[r].s[2];
-                            if (a.has_zeta) Uv += a.dt * (a.gamma * Gn + a.zeta * gm);
-                            else            Uv += a.dt * a.gamma * Gn;
-                            *reinterpret_cast<double *>(Unk + o.c) = Uv;
-                        }
+                    const double vinv = ROLE == ROLE_W ? ktab(g.vinv_f)[pkm] : ktab(g.vinv_c)[pkm];
+                    const double dx = FX[pb][row0][lane + 1] - FX[pb][row0][lane];
+                    const double dy = FY[pb][row0 + 1][lane] - FY[pb][row0][lane];
+                    const double div = vinv * ((dx + dy) + (fz - fz_prev));
+                    Gn = -div + 0.0;
+                    store = (ROLE != ROLE_W || k - 1 >= a.wk0) && (!(OCN_ROLE_ABLATE & 4) || Gn == 1.2345);
+                    if (SUB) {
+                        // rk3_substep_field! of the next stage on the cell just closed (runge_kutta_3.jl:212-226)
+                        Uv = qz.s[2];
+                        if (a.has_zeta) Uv += a.dt * (a.gamma * Gn + a.zeta * gmn);
+                        else            Uv += a.dt * a.gamma * Gn;
                     }
                 }
-                fz_prev[r] = fz;
+                fz_prev = fz;
                 if (!last) {
-                    // ---- low-side x- and y-flux of plane k -> LDS ----
-                    const Win6 qx = xwin6<true>(p.q, p.so, o, qz[r].s[3]);
-                    FX[buf][row0 + r][lane] = x_flux<ROLE>(g, p, qx, ROLE == ROLE_W ? uz4[r] : load_xaux<ROLE>(p, o), i, j + r, k);
-                    const Win6 qy = ywin6<true>(p.q, p.so, o, qz[r].s[3]);
-                    FY[buf][row0 + r][lane] = y_flux<ROLE>(g, p, qy, ROLE == ROLE_W ? vz4[r] : load_yaux<ROLE>(p, o), i, j + r, k);
+                    // ---- low-side x-flux of plane k -> LDS ----
+                    const Win6 qx = (OCN_ROLE_ABLATE & 8) ? qz : xwin6<true>(p.q, p.so, o, qz.s[3]);
+                    FX[buf][row0][lane] = x_flux<ROLE>(g, p, qx, ROLE == ROLE_W ? uz4 : load_xaux<ROLE>(p, o), i, j, k);
+                    // ---- y-window loads, then the long-latency operations as the youngest of the plane, then the y-flux ----
+                    const Win6 qy = (OCN_ROLE_ABLATE & 8) ? qz : ywin6<true>(p.q, p.so, o, qz.s[3]);
+                    const Win6 yaux = ROLE == ROLE_W ? vz4 : load_yaux<ROLE>(p, o);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned st = o.c | (store ? 0u : ROLE_OOB);
+                    stb<24>(rG, st, p.so - s2, Gn);                                                  // level k - 1
+                    if (SUB) stb<24>(rUn, st, p.so - s2, Uv);
+                    qn = ldb<24>(p.q, o.c, (OCN_ROLE_ABLATE & 1) ? p.so : p.so + 3u * s2);
+                    if (ROLE == ROLE_W) { un = ldb<24>(p.u, o.c, p.so + 2u * s2); vn = ldb<24>(p.v, o.c, p.so + 2u * s2); }
+                    if (SUB && !(OCN_ROLE_ABLATE & 2)) gmn = ldb<24>(rGm, o.c | cell_off, p.so);    // level k: closed in plane k + 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    FY[buf][row0][lane] = y_flux<ROLE>(g, p, qy, yaux, i, j, k);
+                } else {
+                    const unsigned st = o.c | (store ? 0u : ROLE_OOB);
+                    stb<24>(rG, st, p.so - s2, Gn);
+                    if (SUB) stb<24>(rUn, st, p.so - s2, Uv);
                 }
             }
-        } else if (!last) {
+        } else if (!last && !(OCN_ROLE_ABLATE & 32)) {
             if (edge_y) {
-                ColOff o;
-                o.c = yo[3];
-#pragma unroll
-                for (int n = 0; n < 6; ++n) o.r[n] = yo[n];
                 const Win6 qy = ywin6<false>(p.q, p.so, o, 0.0);
                 const Win6 aux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
-                FY[buf][NR][lane] = y_flux<ROLE>(g, p, qy, aux, i, j, k);
+                FY[buf][TY][lane] = y_flux<ROLE>(g, p, qy, aux, i, j, k);
             }
             if (edge_x) {
-                asm volatile("" : "+v"(ce));
-                ColOff e;
-                e.c = ce;
-#pragma unroll
-                for (int n = 0; n < 6; ++n) e.r[n] = e.c + (unsigned)(n - 3) * s1;
+                asm volatile("" : "+v"(e.c));
                 const Win6 qxe = xwin6<false>(p.q, p.so, e, 0.0);
                 const Win6 aux = ROLE == ROLE_W ? zwin4(p.u, p.so, e, s2) : load_xaux<ROLE>(p, e);
                 FX[buf][lane][64] = x_flux<ROLE>(g, p, qxe, aux, ie, je, k);
             }
         }
         p.so += s2;
-        Gk += s2;
-        if (SUB) { Unk += s2; Gmk += s2; }
-        if (!last) __syncthreads();
+        if (!last && !(OCN_ROLE_ABLATE & 16)) __syncthreads();
     }
 }
 
-template <int NTR, int TY, int R, bool BZ, bool SUB>
+template <int NTR, int TY, bool BZ, bool SUB>
 __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_kernel(DGrid gin, RoleArgs<3 + NTR> a) {
     constexpr int NF = 3 + NTR;
-    __shared__ double FX[2][TY * R][66];            // low-side x-fluxes of columns 0..64 (65 used, padded)
-    __shared__ double FY[2][TY * R + 1][64];        // low-side y-fluxes of rows 0..TY R
+    __shared__ double FX[2][TY][66];                // low-side x-fluxes of columns 0..64 (65 used, padded)
+    __shared__ double FY[2][TY + 1][64];            // low-side y-fluxes of rows 0..TY R
 
     DGrid g = gin;
     g.tx = 0; g.ty = 0; g.tz = BZ ? 1 : 0;          // compile-time topology (x, y Periodic / FullyConnected is a launch precondition)
@@ -350,13 +353,13 @@ __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_k
     const unsigned role = slot % NF, pair = xcd * (unsigned)a.band + slot / NF;
     if (slot / NF >= (unsigned)a.band || pair >= (unsigned)a.npair) return;
     const unsigned tile = pair % (unsigned)a.ntile, chunk = pair / (unsigned)a.ntile;
-    const int i0 = a.r.i0 + (int)(tile % (unsigned)a.ntile_x) * 64, j0 = a.r.j0 + (int)(tile / (unsigned)a.ntile_x) * (TY * R);
+    const int i0 = a.r.i0 + (int)(tile % (unsigned)a.ntile_x) * 64, j0 = a.r.j0 + (int)(tile / (unsigned)a.ntile_x) * TY;
     const int kc0 = a.r.k0 + (int)chunk * a.kchunk;
     const int kc1 = min(kc0 + a.kchunk - 1, a.r.k1);
-    if (role == 0) role_march<ROLE_U, TY, R, SUB>(g, a, 0, i0, j0, kc0, kc1, FX, FY);
-    else if (role == 1) role_march<ROLE_V, TY, R, SUB>(g, a, 1, i0, j0, kc0, kc1, FX, FY);
-    else if (role == 2) role_march<ROLE_W, TY, R, SUB>(g, a, 2, i0, j0, kc0, kc1, FX, FY);
-    else role_march<ROLE_C, TY, R, SUB>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
+    if (role == 0) role_march<ROLE_U, TY, SUB>(g, a, 0, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 1) role_march<ROLE_V, TY, SUB>(g, a, 1, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 2) role_march<ROLE_W, TY, SUB>(g, a, 2, i0, j0, kc0, kc1, FX, FY);
+    else role_march<ROLE_C, TY, SUB>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
 }
 
 static int g_role_kchunk = 0;      // 0: automatic
@@ -380,20 +383,20 @@ static inline int pick_role_kchunk(long tiles_roles, int nz) {
     return best;
 }
 
-template <int NTR, int TY, int R>
+template <int NTR, int TY>
 static int launch_roles_t(const DGrid &g, hipStream_t stream, RoleArgs<3 + NTR> &a, bool sub) {
     constexpr int NF = 3 + NTR;
     const int nx = a.r.i1 - a.r.i0 + 1, ny = a.r.j1 - a.r.j0 + 1, nz = a.r.k1 - a.r.k0 + 1;
     if (nx <= 0 || ny <= 0 || nz <= 0) return 0;
     a.ntile_x = (nx + 63) / 64;
-    a.ntile = a.ntile_x * ((ny + TY * R - 1) / (TY * R));
+    a.ntile = a.ntile_x * ((ny + TY - 1) / TY);
     a.kchunk = g_role_kchunk > 0 ? g_role_kchunk : pick_role_kchunk((long)a.ntile * NF, nz);
     const int nchunk = (nz + a.kchunk - 1) / a.kchunk;
     a.npair = a.ntile * nchunk;
     a.band = (a.npair + 7) / 8;
     const unsigned nblocks = (unsigned)a.band * 8u * NF;
     const dim3 blk(64 * (TY + 1));
-#define OCN_LAUNCH_ROLES(BZV, SUBV) hipLaunchKernelGGL((role_tendency_kernel<NTR, TY, R, BZV, SUBV>), dim3(nblocks), blk, (size_t)g_role_ldspad, stream, g, a)
+#define OCN_LAUNCH_ROLES(BZV, SUBV) hipLaunchKernelGGL((role_tendency_kernel<NTR, TY, BZV, SUBV>), dim3(nblocks), blk, (size_t)g_role_ldspad, stream, g, a)
     if (g.tz != 0) { if (sub) OCN_LAUNCH_ROLES(true, true); else OCN_LAUNCH_ROLES(true, false); }
     else           { if (sub) OCN_LAUNCH_ROLES(false, true); else OCN_LAUNCH_ROLES(false, false); }
 #undef OCN_LAUNCH_ROLES
@@ -421,9 +424,7 @@ static int launch_roles_n(const DGrid &g, hipStream_t stream, const double *u, c
         a.r = Range6{1, g.Nx, 1, g.Ny, 1, g.Nz};
         a.wk0 = (g.tz != 0 && g.Nz > 1) ? 2 : 1;          // exclude_periphery: w tendencies start at k = 2 on Bounded z
     }
-    // R = 2 rows per row wave is implemented (template parameter) and bit-identical, but measured slower at 256^3 (1.70 vs 1.52 ms at
-    // four waves per SIMD): only R = 1 is instantiated
-    return launch_roles_t<NTR, 7, 1>(g, stream, a, sub != nullptr);
+    return launch_roles_t<NTR, 7>(g, stream, a, sub != nullptr);
 }
 
 static inline int launch_role_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,
