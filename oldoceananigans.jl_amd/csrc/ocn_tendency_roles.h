@@ -24,6 +24,12 @@
 #ifndef OCN_ROLE_ABLATE
 #define OCN_ROLE_ABLATE 0     // timing experiments only (WRONG RESULTS when non-zero): 1 hot z-window load, 2 no previous-tendency load,
 #endif                        // 4 no stores, 8 x / y windows from registers, 16 no barrier, 32 idle edge wave
+#ifndef OCN_ROLE_STORE_AUX
+#define OCN_ROLE_STORE_AUX 2   // cache policy bits of the tendency / next-stage stores (1 sc0, 2 nt, 16 sc1)
+#endif
+#ifndef OCN_ROLE_GM_AUX
+#define OCN_ROLE_GM_AUX 0      // cache policy bits of the previous-tendency load (read once)
+#endif
 enum { ROLE_U = 0, ROLE_V = 1, ROLE_W = 2, ROLE_C = 3 };
 
 template <int NF>
@@ -62,8 +68,11 @@ __device__ __forceinline__ Rsrc make_rsrc(const void *p) {
 template <int IMM> __device__ __forceinline__ double ldb(Rsrc r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + (unsigned)IMM), (int)soff, 0));
 }
+template <int IMM> __device__ __forceinline__ double ldb_once(Rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)(voff + (unsigned)IMM), (int)soff, OCN_ROLE_GM_AUX));
+}
 template <int IMM> __device__ __forceinline__ void stb(Rsrc r, unsigned voff, unsigned soff, double v) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)(voff + (unsigned)IMM), (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, v), r, (int)(voff + (unsigned)IMM), (int)soff, OCN_ROLE_STORE_AUX);
 }
 
 // per-thread loop-invariant offset: c = byte offset of (i - 3, j) inside a plane; sr[n] = scalar byte offset of row j - 3 + n
@@ -197,6 +206,14 @@ __device__ __forceinline__ double y_flux(const DGrid &g, const PlaneCtx &p, cons
     }
 }
 
+// Workgroup barrier for the LDS flux exchange only: __syncthreads() carries a release fence that drains the vector-memory queue
+// (s_waitcnt vmcnt(0)) -- exactly the stores and prefetches that are meant to stay in flight across it. Nothing the workgroup's
+// waves exchange goes through global memory, so the LDS counter is all this barrier has to wait for.
+__device__ __forceinline__ void vmov(double &dst, const double &src) { asm volatile("v_mov_b64 %0, %1" : "=v"(dst) : "v"(src)); }
+__device__ __forceinline__ void role_barrier() {
+    if (!(OCN_ROLE_ABLATE & 16)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // One workgroup = TY row waves + one edge wave, all working on field `fidx`. A row wave owns one row of the tile (two rows per wave
 // were implemented and measured slower: 1.70 vs 1.52 ms); the edge wave evaluates the y-fluxes of the row above the tile and the
 // x-fluxes of the column right of it (one lane per row).
@@ -238,102 +255,135 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     const Rsrc rG = make_rsrc(a.G[fidx]), rUn = make_rsrc(SUB ? a.Un[fidx] : a.G[fidx]), rGm = make_rsrc(SUB ? a.Gm[fidx] : a.G[fidx]);
     const unsigned cell_off = cell_r ? 0u : ROLE_OOB;
 
-    double fz_prev = 0, qn = 0, gmn = 0, un = 0, vn = 0;
-    Win6 qz, uz4, vz4;                                // own 6-deep z-window; role w: u, v at levels k-2 .. k+1 (indices 1 .. 4)
+    double fz_prev = 0, qn = 0, gmn = 0;
+    Win6 qz;                                          // own 6-deep z-window (role w reads the z-windows of u, v from memory:
+                                                      // kept in registers they cost 20 VGPRs and spilled)
 #pragma unroll
-    for (int n = 0; n < 6; ++n) { qz.s[n] = 0; uz4.s[n] = 0; vz4.s[n] = 0; }
+    for (int n = 0; n < 6; ++n) qz.s[n] = 0;
     if (flux_r) {
 #pragma unroll
         for (int n = 0; n < 5; ++n) qz.s[n + 1] = ldb<24>(p.q, o.c, p.so + (unsigned)(n - 3) * s2);   // levels kc0-3 .. kc0+1
         qn = ldb<24>(p.q, o.c, p.so + 2u * s2);                                                        // level kc0+2
-        if (ROLE == ROLE_W) {
-#pragma unroll
-            for (int n = 1; n < 4; ++n) {                                                              // levels kc0-2 .. kc0
-                uz4.s[n + 1] = ldb<24>(p.u, o.c, p.so + (unsigned)(n - 3) * s2);
-                vz4.s[n + 1] = ldb<24>(p.v, o.c, p.so + (unsigned)(n - 3) * s2);
-            }
-            un = ldb<24>(p.u, o.c, p.so + s2); vn = ldb<24>(p.v, o.c, p.so + s2);                      // level kc0+1
-        }
     }
 
-    for (int k = kc0; k <= kc1 + 1; ++k) {
-        const bool last = k == kc1 + 1;               // peeled plane: only the z-fluxes closing the cells of level kc1
+    // The edge wave and the row waves run SEPARATE loops over the same planes (one barrier per plane in each): loop-carried values
+    // of one kind of wave never meet the other's in a control-flow join, where the register allocator would place copies that
+    // wait for the prefetches.
+    if (edge) {
+        for (int k = kc0; k <= kc1; ++k) {
+            const int buf = k & 1;
+            const long pk = (long)(k - 1 + Hz);
+            p.axk = ktab(g.ax)[pk]; p.ayk = ktab(g.ay)[pk];
+            p.axz = g.ax + pk - 2; p.ayz = g.ay + pk - 2;
+            asm volatile("" : "+v"(o.c));
+            if (edge_y && !(OCN_ROLE_ABLATE & 32)) {
+                const Win6 qy = ywin6<false>(p.q, p.so, o, 0.0);
+                const Win6 aux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
+                FY[buf][TY][lane] = y_flux<ROLE>(g, p, qy, aux, i, j, k);
+            }
+            if (edge_x && !(OCN_ROLE_ABLATE & 32)) {
+                asm volatile("" : "+v"(e.c));
+                const Win6 qxe = xwin6<false>(p.q, p.so, e, 0.0);
+                const Win6 aux = ROLE == ROLE_W ? zwin4(p.u, p.so, e, s2) : load_xaux<ROLE>(p, e);
+                FX[buf][lane][64] = x_flux<ROLE>(g, p, qxe, aux, ie, je, k);
+            }
+            p.so += s2;
+            role_barrier();
+        }
+        return;
+    }
+    if (j > a.r.j1 + 1) {                             // a row wave entirely above the range (wave-uniform): barriers only
+        for (int k = kc0; k <= kc1; ++k) role_barrier();
+        return;
+    }
+    // Lanes right of the range get the out-of-range bit instead of a branch: their loads return 0, their stores are dropped,
+    // their fluxes land in LDS columns no cell reads. The plane loop below has no divergent control flow around loop-carried values.
+    if (!flux_r) o.c |= ROLE_OOB;
+
+    // z-flux through the bottom face of cell k, then the closing of cell k - 1 (tendency + the next stage's substep): values only,
+    // the stores are placed by the caller
+    double Gn = 0, Uv = 0;
+    bool store = false;
+    double gm = 0;
+    Win6 zin;
+    auto z_loads = [&]() {
+        // The z-windows slide by one level, the prefetched level enters at the top. Written as explicit moves at THIS point of the
+        // instruction stream (behind the barrier): left to the register allocator the rotation of the loop-carried window is
+        // resolved at the end of the previous plane, where the copy of the prefetched value waits for it (vmcnt(0)) before the barrier.
+#pragma unroll
+        for (int n = 0; n < 5; ++n) vmov(qz.s[n], qz.s[n + 1]);
+        vmov(qz.s[5], qn);
+        if (SUB) vmov(gm, gmn);
+        zin = load_zin<ROLE>(p, p.so, o);
+    };
+    auto z_compute = [&](const int k, const int buf, const long pk) {
+        const double fz = z_flux<ROLE>(g, zin, i, j, k, qz);
+        const int pb = buf ^ 1;
+        const long pkm = pk - 1;
+        const double vinv = ROLE == ROLE_W ? ktab(g.vinv_f)[pkm] : ktab(g.vinv_c)[pkm];
+        const double dx = FX[pb][row0][lane + 1] - FX[pb][row0][lane];
+        const double dy = FY[pb][row0 + 1][lane] - FY[pb][row0][lane];
+        const double div = vinv * ((dx + dy) + (fz - fz_prev));
+        Gn = -div + 0.0;
+        store = cell_r && k > kc0 && (ROLE != ROLE_W || k - 1 >= a.wk0) && (!(OCN_ROLE_ABLATE & 4) || Gn == 1.2345);
+        if (SUB) {
+            // rk3_substep_field! of the next stage on the cell just closed (runge_kutta_3.jl:212-226)
+            Uv = qz.s[2];
+            if (a.has_zeta) Uv += a.dt * (a.gamma * Gn + a.zeta * gm);
+            else            Uv += a.dt * a.gamma * Gn;
+        }
+        fz_prev = fz;
+    };
+    auto stores = [&]() {
+        const unsigned st = o.c | (store ? 0u : ROLE_OOB);
+        stb<24>(rG, st, (OCN_ROLE_ABLATE & 64) ? s2 * 3u : p.so - s2, Gn);                             // level k - 1
+        if (SUB) stb<24>(rUn, st, (OCN_ROLE_ABLATE & 64) ? s2 * 3u : p.so - s2, Uv);
+    };
+
+    for (int k = kc0; k <= kc1; ++k) {
         const int buf = k & 1;
         const long pk = (long)(k - 1 + Hz);
         p.axk = ktab(g.ax)[pk]; p.ayk = ktab(g.ay)[pk];
         p.axz = g.ax + pk - 2; p.ayz = g.ay + pk - 2;
         // keep the 32-bit offsets opaque per iteration, so that `offset + constant` stays inside the loop and folds into the immediate
         asm volatile("" : "+v"(o.c));
-        if (!edge) {
-            if (flux_r) {
-                const bool close_cell = k > kc0 && cell_r;
-#pragma unroll
-                for (int n = 0; n < 5; ++n) qz.s[n] = qz.s[n + 1];
-                qz.s[5] = qn;
-                if (ROLE == ROLE_W) {
-#pragma unroll
-                    for (int n = 1; n < 4; ++n) { uz4.s[n] = uz4.s[n + 1]; vz4.s[n] = vz4.s[n + 1]; }
-                    uz4.s[4] = un; vz4.s[4] = vn;
-                }
-                // ---- z-flux through the bottom face of cell k, then close cell k-1 ----
-                const Win6 zin = load_zin<ROLE>(p, p.so, o);
-                const double fz = z_flux<ROLE>(g, zin, i, j, k, qz);
-                double Gn = 0, Uv = 0;
-                bool store = false;
-                if (close_cell) {
-                    const int pb = buf ^ 1;
-                    const long pkm = pk - 1;
-                    const double vinv = ROLE == ROLE_W ? ktab(g.vinv_f)[pkm] : ktab(g.vinv_c)[pkm];
-                    const double dx = FX[pb][row0][lane + 1] - FX[pb][row0][lane];
-                    const double dy = FY[pb][row0 + 1][lane] - FY[pb][row0][lane];
-                    const double div = vinv * ((dx + dy) + (fz - fz_prev));
-                    Gn = -div + 0.0;
-                    store = (ROLE != ROLE_W || k - 1 >= a.wk0) && (!(OCN_ROLE_ABLATE & 4) || Gn == 1.2345);
-                    if (SUB) {
-                        // rk3_substep_field! of the next stage on the cell just closed (runge_kutta_3.jl:212-226)
-                        Uv = qz.s[2];
-                        if (a.has_zeta) Uv += a.dt * (a.gamma * Gn + a.zeta * gmn);
-                        else            Uv += a.dt * a.gamma * Gn;
-                    }
-                }
-                fz_prev = fz;
-                if (!last) {
-                    // ---- low-side x-flux of plane k -> LDS ----
-                    const Win6 qx = (OCN_ROLE_ABLATE & 8) ? qz : xwin6<true>(p.q, p.so, o, qz.s[3]);
-                    FX[buf][row0][lane] = x_flux<ROLE>(g, p, qx, ROLE == ROLE_W ? uz4 : load_xaux<ROLE>(p, o), i, j, k);
-                    // ---- y-window loads, then the long-latency operations as the youngest of the plane, then the y-flux ----
-                    const Win6 qy = (OCN_ROLE_ABLATE & 8) ? qz : ywin6<true>(p.q, p.so, o, qz.s[3]);
-                    const Win6 yaux = ROLE == ROLE_W ? vz4 : load_yaux<ROLE>(p, o);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const unsigned st = o.c | (store ? 0u : ROLE_OOB);
-                    stb<24>(rG, st, p.so - s2, Gn);                                                  // level k - 1
-                    if (SUB) stb<24>(rUn, st, p.so - s2, Uv);
-                    qn = ldb<24>(p.q, o.c, (OCN_ROLE_ABLATE & 1) ? p.so : p.so + 3u * s2);
-                    if (ROLE == ROLE_W) { un = ldb<24>(p.u, o.c, p.so + 2u * s2); vn = ldb<24>(p.v, o.c, p.so + 2u * s2); }
-                    if (SUB && !(OCN_ROLE_ABLATE & 2)) gmn = ldb<24>(rGm, o.c | cell_off, p.so);    // level k: closed in plane k + 1
-                    __builtin_amdgcn_sched_barrier(0);
-                    FY[buf][row0][lane] = y_flux<ROLE>(g, p, qy, yaux, i, j, k);
-                } else {
-                    const unsigned st = o.c | (store ? 0u : ROLE_OOB);
-                    stb<24>(rG, st, p.so - s2, Gn);
-                    if (SUB) stb<24>(rUn, st, p.so - s2, Uv);
-                }
-            }
-        } else if (!last && !(OCN_ROLE_ABLATE & 32)) {
-            if (edge_y) {
-                const Win6 qy = ywin6<false>(p.q, p.so, o, 0.0);
-                const Win6 aux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
-                FY[buf][TY][lane] = y_flux<ROLE>(g, p, qy, aux, i, j, k);
-            }
-            if (edge_x) {
-                asm volatile("" : "+v"(e.c));
-                const Win6 qxe = xwin6<false>(p.q, p.so, e, 0.0);
-                const Win6 aux = ROLE == ROLE_W ? zwin4(p.u, p.so, e, s2) : load_xaux<ROLE>(p, e);
-                FX[buf][lane][64] = x_flux<ROLE>(g, p, qxe, aux, ie, je, k);
-            }
-        }
+        // Issue order of a plane: [z inputs] z-flux + closing arithmetic [x-window, stores] x-flux [y-window, prefetches] y-flux,
+        // barrier. (Issuing the x- / y-window loads one flux earlier was tried: 16 more VGPRs, no gain at six waves per SIMD.)
+        z_loads();
+        Win6 qx, xaux, qy, yaux;
+        auto x_loads = [&]() {
+            qx = (OCN_ROLE_ABLATE & 8) ? qz : xwin6<true>(p.q, p.so, o, qz.s[3]);
+            xaux = ROLE == ROLE_W ? zwin4(p.u, p.so, o, s2) : load_xaux<ROLE>(p, o);
+        };
+        auto y_loads = [&]() {
+            qy = (OCN_ROLE_ABLATE & 8) ? qz : ywin6<true>(p.q, p.so, o, qz.s[3]);
+            yaux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
+        };
+        auto prefetches = [&]() {
+            qn = ldb<24>(p.q, o.c, (OCN_ROLE_ABLATE & 1) ? p.so : p.so + 3u * s2);
+            if (SUB && !(OCN_ROLE_ABLATE & 2)) gmn = ldb_once<24>(rGm, o.c | cell_off, p.so);          // level k: closed in plane k + 1
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        z_compute(k, buf, pk);
+        __builtin_amdgcn_sched_barrier(0);
+        x_loads();
+        stores();
+        __builtin_amdgcn_sched_barrier(0);
+        FX[buf][row0][lane] = x_flux<ROLE>(g, p, qx, xaux, i, j, k);
+        __builtin_amdgcn_sched_barrier(0);
+        y_loads();
+        prefetches();
+        __builtin_amdgcn_sched_barrier(0);
+        FY[buf][row0][lane] = y_flux<ROLE>(g, p, qy, yaux, i, j, k);
         p.so += s2;
-        if (!last && !(OCN_ROLE_ABLATE & 16)) __syncthreads();
+        role_barrier();
+    }
+    // peeled plane kc1 + 1: only the z-fluxes that close the cells of level kc1
+    {
+        const int k = kc1 + 1;
+        z_loads();
+        z_compute(k, k & 1, (long)(k - 1 + Hz));
+        stores();
     }
 }
 
@@ -370,7 +420,7 @@ static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgro
 static inline int pick_role_kchunk(long tiles_roles, int nz) {
     int best = nz;
     double best_cost = -1;
-    const long slots = (OCN_ROLE_WAVES >= 6 ? 3L : 2L) * g_num_cus;
+    const long slots = (long)(OCN_ROLE_WAVES / 2) * g_num_cus;
     for (int kc = 8; kc <= 64; ++kc) {
         if (kc > nz && kc != 8) break;
         const int nchunk = (nz + kc - 1) / kc;
