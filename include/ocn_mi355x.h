@@ -46,6 +46,7 @@ extern "C" {
 typedef struct ocn_grid_s *ocn_grid_t;
 typedef struct ocn_poisson_s *ocn_poisson_t;
 typedef struct ocn_model_s *ocn_model_t;
+typedef struct ocn_dist_s *ocn_dist_t;
 
 /* ---------------------------------------------------------------- runtime (src/Architectures.jl:35-123) ---------- */
 int ocn_init(int device_id);                                  /* device!(arch, id) */
@@ -349,6 +350,57 @@ int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatche
  * nsamples pseudo-random significands with exponents exp_lo..exp_hi; returns the number of differing results */
 int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, int exp_hi, unsigned long long seed,
                           unsigned long long *mismatches);
+
+/* ---------------------------------------------------------------- distributed: communicator + partitioned model -- */
+/* `Distributed(GPU(); partition = Partition(R))` (DistributedComputations/distributed_architectures.jl:166-302): one process per
+ * GPU, x-slabs, ring neighbours with periodic wrap (:391-434). The library owns the communicator: RCCL over xGMI
+ * (ncclCommInitRank; librccl is opened at run time by the first of these calls, single-GPU users never load it). Bootstrap as
+ * with NCCL: rank 0 calls ocn_dist_unique_id, the caller carries the 128 bytes to every rank (MPI_Bcast, a TCP store, a file),
+ * every rank calls ocn_dist_create after ocn_init(local device). Halo transfers run on the library's communication stream
+ * between two events: kernels launched afterwards overlap them; the host never synchronises (the reference calls sync_device!
+ * before every MPI call, halo_communication.jl:181, distributed_transpose.jl:187). */
+int ocn_dist_unique_id(void *id128);
+int ocn_dist_create(ocn_dist_t *dist, const void *id128, int world, int rank);
+/* The same architecture object over collectives the CALLER supplies -- the seam for MPI.jl in a Julia binder (the reference's
+ * own transport), and what the tests use to run R ranks on one card. All buffers are device pointers; `stream` is the library's
+ * compute stream (a hipStream_t): the callbacks must order their transfers behind the work already on it and make later work on
+ * it wait for them (or synchronise). exchange_start/_wait: `count` doubles per side, what leaves through the west side arrives in the
+ * west neighbour's east halo (MPI.Isend/Irecv! + Waitall, halo_communication.jl:300,326,164); all_to_all: piece r of `send`
+ * (`count_per_rank` doubles) goes to rank r (MPI.Alltoallv!, distributed_transpose.jl:185-191); all_gather: rank r's `count` doubles
+ * land at recv[r * count]; allreduce_max: host scalar in / out. Return 0 on success. */
+typedef struct {
+    int (*exchange_start)(void *user, const double *west_send, const double *east_send, double *west_recv, double *east_recv,
+                          size_t count, void *stream);
+    int (*exchange_wait)(void *user, void *stream);
+    int (*all_to_all)(void *user, const double *send, double *recv, size_t count_per_rank, void *stream);
+    int (*all_gather)(void *user, const double *send, double *recv, size_t count, void *stream);
+    int (*allreduce_max)(void *user, double *value);
+    void *user;
+} ocn_transport_t;
+int ocn_dist_create_transport(ocn_dist_t *dist, const ocn_transport_t *transport, int world, int rank);
+int ocn_dist_destroy(ocn_dist_t dist);
+int ocn_dist_info(ocn_dist_t dist, int *world, int *rank, int *west, int *east);
+/* MEASUREMENT / TEST ONLY: a communicator of ONE rank treats x as partitioned with itself as both neighbours, so the complete
+ * N > 1 code path runs (and can be timed) on a one-GPU box; results equal the one-rank Periodic run. Set before model creation. */
+int ocn_dist_set_self_loop(ocn_dist_t dist, int enabled);
+/* the collectives themselves, for callers that orchestrate the stages on their own (send / recv of halo buffers,
+ * halo_communication.jl:170-187; transposes, distributed_transpose.jl:185-191) */
+int ocn_dist_exchange_start(ocn_dist_t dist, const double *west_send, const double *east_send, double *west_recv, double *east_recv,
+                            size_t count);
+int ocn_dist_exchange_wait(ocn_dist_t dist);
+int ocn_dist_all_to_all(ocn_dist_t dist, const double *send, double *recv, size_t count_per_rank);
+int ocn_dist_all_gather(ocn_dist_t dist, const double *send, double *recv, size_t count);
+int ocn_dist_allreduce_max(ocn_dist_t dist, double *value);      /* synchronous */
+int ocn_dist_barrier(ocn_dist_t dist);                           /* synchronous */
+/* NonhydrostaticModel on a Distributed architecture: `local_grid` is this rank's slab (x topology OCN_CONNECTED when x is
+ * partitioned: distributed_grids.jl:339-346), `Lx_global` the extent of the global domain along x. The returned handle is an
+ * ocn_model_t: every ocn_model_* call works on it (set_option also takes "async_halos" -1 automatic / 0 / 1, "thin_halos",
+ * "early_exchange", "strip_width"); ocn_model_time_step runs the partitioned RK3 step -- fill_halo_regions! with the x exchange
+ * (halo_communication.jl:87-110), the interior / buffer split (Models/interleave_communication_and_computation.jl:9-67) or the
+ * exchange started from make_pressure_correction!, and solve! of the distributed solvers
+ * (distributed_fft_based_poisson_solver.jl:141-178, distributed_fft_tridiagonal_solver.jl:153-257) -- entirely inside the library. */
+int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global);
+int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus
 }

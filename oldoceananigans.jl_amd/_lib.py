@@ -33,7 +33,34 @@ class BC(C.Structure):
     """ocn_bc_t"""
     _fields_ = [("kind", C.c_int), ("value", C.c_double)]
 
+class Transport(C.Structure):
+    """ocn_transport_t: caller-supplied collectives (device addresses as integers)"""
+    EXCHANGE_START = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    EXCHANGE_WAIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+    ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    ALLREDUCE_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+
+
+Transport._fields_ = [("exchange_start", Transport.EXCHANGE_START), ("exchange_wait", Transport.EXCHANGE_WAIT),
+                      ("all_to_all", Transport.ALL_TO_ALL), ("all_gather", Transport.ALL_GATHER),
+                      ("allreduce_max", Transport.ALLREDUCE_MAX), ("user", C.c_void_p)]
+
 SYMBOLS = {
+    "ocn_dist_unique_id": (C.c_int, [_vp]),
+    "ocn_dist_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int]),
+    "ocn_dist_create_transport": (C.c_int, [_pp, C.POINTER(Transport), C.c_int, C.c_int]),
+    "ocn_dist_destroy": (C.c_int, [_vp]),
+    "ocn_dist_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "ocn_dist_set_self_loop": (C.c_int, [_vp, C.c_int]),
+    "ocn_dist_exchange_start": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
+    "ocn_dist_exchange_wait": (C.c_int, [_vp]),
+    "ocn_dist_all_to_all": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "ocn_dist_all_gather": (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    "ocn_dist_allreduce_max": (C.c_int, [_vp, _dp]),
+    "ocn_dist_barrier": (C.c_int, [_vp]),
+    "ocn_dist_model_create": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double]),
+    "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_sync": (C.c_int, []),
     "ocn_last_error": (C.c_char_p, []),

@@ -2031,8 +2031,11 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
 // ---------------------------------------------------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------------------------------------------------
+struct DistModel;
+static void dist_model_free(DistModel *dm);
 struct ocn_model_s {
     ocn_grid_t grid;
+    DistModel *dm = nullptr;                // x-slab partition (ocn_dist.h): communicator, distributed solver, halo buffers
     int ntr, nf;
     double *U[OCN_MAX_FIELDS], *Gn[OCN_MAX_FIELDS], *Gm[OCN_MAX_FIELDS];
     // second set of prognostic arrays: the substeps of stages 2 and 3 are fused into the preceding tendency evaluation and
@@ -2092,12 +2095,12 @@ extern "C" int ocn_model_destroy(ocn_model_t m) {
     for (int t = 0; t < OCN_MAX_FIELDS; ++t) hipFree(m->kappa_e[t]);
     hipFree(m->p); hipFree(m->blockmax);
     ocn_poisson_destroy(m->solver);
+    dist_model_free(m->dm);
     delete m;
     return OCN_OK;
 }
 
-extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
-    NEED_INIT();
+static int model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers, bool with_solver) {
     if (!model || !grid) return fail(OCN_EINVAL, "NULL argument");
     if (ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3) return fail(OCN_EINVAL, "ntracers must be in 0..%d", OCN_MAX_FIELDS - 3);
     ocn_model_s *m = new ocn_model_s();
@@ -2129,10 +2132,16 @@ extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracer
         hipError_t e = dev_alloc((void **)&m->blockmax, 1024 * sizeof(double));
         if (e != hipSuccess) rc = fail((int)e, "hipMalloc: %s", hipGetErrorString(e));
     }
-    if (!rc) rc = ocn_poisson_create(&m->solver, grid, -1);
+    if (!rc && with_solver) rc = ocn_poisson_create(&m->solver, grid, -1);
     if (rc) { ocn_model_destroy(m); return rc; }
     *model = m;
     return OCN_OK;
+}
+
+extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
+    NEED_INIT();
+    if (grid && grid->d.tx == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected x direction needs ocn_dist_model_create");
+    return model_create(model, grid, ntracers, true);
 }
 
 static int field_lookup(ocn_model_s *m, const char *name, double ***slot, int **loc) {
@@ -2199,6 +2208,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     return fail(OCN_EINVAL, "unknown option %s", key);
 }
 
+static int dist_model_set_option(ocn_model_s *m, const char *key, int value);
 extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
     m->epoch += 1;
@@ -2208,6 +2218,7 @@ extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!strcmp(key, "fuse_substep")) { m->fuse_substep = value; return OCN_OK; }
     if (!strcmp(key, "fused_epilogue")) { m->fused_epilogue = value; return OCN_OK; }
     if (!strcmp(key, "profile")) { m->profile = value; m->events_used = 0; return OCN_OK; }
+    if (dist_model_set_option(m, key, value) == OCN_OK) return OCN_OK;
     return ocn_set_option(key, value);
 }
 
@@ -2276,14 +2287,22 @@ extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) 
 }
 
 // update_state! (update_nonhydrostatic_model_state.jl:20-56), closure / buoyancy / forcing = nothing
+static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub);
+static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub, const int *amd_range);
 static int update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub = nullptr) {
-    const DGrid &g = m->grid->d;
+    if (m->dm) return dist_update_state(m, compute_tend, sub);
     int rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, /*fill_open_bcs=*/false, m->any_bc ? m->bcs : nullptr);
     if (rc) return rc;
+    return update_state_tail(m, compute_tend, sub, nullptr);
+}
+// everything of update_state! that follows the halo fill of the prognostic fields
+static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub, const int *amd_range) {
+    const DGrid &g = m->grid->d;
+    int rc;
     // compute_auxiliaries!: compute_diffusivities! over :xyz (update_nonhydrostatic_model_state.jl:58-69), then
     // fill_halo_regions!(model.diffusivity_fields; only_local_halos = true) (:44) with the default ccc conditions
     if (m->has_amd) {
-        if ((rc = amd_diffusivities(g, m->Cnu, m->Ckappa, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu_e, m->kappa_e))) return rc;
+        if ((rc = amd_diffusivities(g, m->Cnu, m->Ckappa, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->nu_e, m->kappa_e, amd_range))) return rc;
         double *K[OCN_MAX_FIELDS];
         int kl[OCN_MAX_FIELDS][3];
         K[0] = m->nu_e;
@@ -2361,7 +2380,9 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
 // compute_pressure_correction! + make_pressure_correction! (pressure_correction.jl:8-53). With a split solver the inverse transform
 // leaves the solution in a dense real array and ONE kernel corrects u, v, w from it and writes p / Δt⁺ into the haloed pressure field
 // (was: strided C2R into the field, halo fill, correction kernel, divide kernel).
-static int pressure_step(ocn_model_s *m, double dt) {
+static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow);
+static int pressure_step(ocn_model_s *m, double dt, bool tendencies_follow = true) {
+    if (m->dm) return dist_pressure_step(m, dt, tendencies_follow);
     int rc;
     ocn_poisson_s *s = m->solver;
     if (!(s->split && g_split_solve && g_real_fft && !s->general)) {
@@ -2521,7 +2542,7 @@ extern "C" int ocn_model_set_finalize(ocn_model_t m, int enforce_incompressibili
     if (rc) return rc;
     if ((rc = update_state(m, false))) return rc;
     if (enforce_incompressibility) {
-        if ((rc = pressure_step(m, 1.0))) return rc;
+        if ((rc = pressure_step(m, 1.0, false))) return rc;
         if ((rc = update_state(m, false))) return rc;
     }
     return OCN_OK;
@@ -2597,7 +2618,7 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     // graphs: not on the first step (it also evaluates the initial tendencies), not while tendency launches are being timed, and only
     // on a stream the library owns (a borrowed stream may be the legacy default stream, which cannot be captured)
-    if (!m->use_graph || m->profile || m->iteration == 0 || !g_stream_owned) return rk3_time_step(m, dt);
+    if (!m->use_graph || m->profile || m->iteration == 0 || !g_stream_owned || m->dm) return rk3_time_step(m, dt);
     if (m->graph_exec && m->graph_dt == dt && m->graph_epoch == m->epoch * 1000003ull + g_epoch) {
         hipError_t e = hipGraphLaunch(m->graph_exec, g_stream);
         if (e != hipSuccess) return fail((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));
@@ -2706,6 +2727,8 @@ extern "C" int ocn_model_profile_read(ocn_model_t m, double *tendency_ms, int *c
 
 // debug / test hook: number of significands (of 2^23) in the binade 2^(exponent) for which the fast Float32 reciprocal
 // differs from the IEEE divide
+#include "ocn_dist.h"
+
 extern "C" int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatches) {
     NEED_INIT();
     if (!mismatches || exponent < -120 || exponent > 120) return fail(OCN_EINVAL, "invalid argument");

@@ -1,0 +1,495 @@
+// ocn_dist.h -- the communicator and the partitioned time-step INSIDE the library (included by ocn_api.hip behind the model code).
+//
+// Reference: src/DistributedComputations/ -- `Distributed(arch; partition = Partition(R))` (distributed_architectures.jl:166-302),
+// send / recv of halo buffers with the two x neighbours (halo_communication.jl:170-187,300,326), MPI.Alltoallv! of the transposes
+// (distributed_transpose.jl:185-191), the distributed solvers' solve! (distributed_fft_based_poisson_solver.jl:141-178,
+// distributed_fft_tridiagonal_solver.jl:153-257) and the interior / buffer split of
+// Models/interleave_communication_and_computation.jl:9-67.
+//
+// One process per GPU. The product transport is RCCL over xGMI: the library owns the communicator (ncclCommInitRank, the unique id
+// comes from the caller's bootstrap), halo transfers run on the library's communication stream between two events, so kernels
+// launched afterwards on the compute stream overlap them; the small collectives of the pressure solve run on the compute stream
+// itself. librccl is opened at run time (dlopen) the first time a communicator is asked for: single-GPU users never load it.
+// A second transport takes the collectives as caller-supplied function pointers (ocn_transport_t): what an MPI.jl binder would plug
+// in, and what the tests use to run R ranks on one card (threads) or over gloo.
+#pragma once
+#include <dlfcn.h>
+
+// ---- RCCL, resolved at run time (rccl.h: ncclResult_t = int, ncclComm_t = opaque pointer, ncclUniqueId = 128 bytes) ----
+typedef struct { char internal[128]; } ocn_nccl_id;
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ocn_nccl_id *) = nullptr;
+    int (*CommInitRank)(void **, int, ocn_nccl_id, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+enum { OCN_NCCL_FLOAT64 = 8, OCN_NCCL_MAX = 2 };      // ncclDouble, ncclMax (rccl.h)
+
+static int rccl_load() {
+    if (g_rccl.handle) return OCN_OK;
+    const char *names[] = {getenv("OCN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!h) return fail(OCN_ESTATE, "librccl could not be opened (%s); set OCN_RCCL_LIB", dlerror());
+#define OCN_RCCL_SYM(field, name) \
+    if (!(*(void **)(&g_rccl.field) = dlsym(h, name))) { dlclose(h); return fail(OCN_ESTATE, "librccl lacks %s", name); }
+    OCN_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    OCN_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    OCN_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    OCN_RCCL_SYM(Send, "ncclSend");
+    OCN_RCCL_SYM(Recv, "ncclRecv");
+    OCN_RCCL_SYM(GroupStart, "ncclGroupStart");
+    OCN_RCCL_SYM(GroupEnd, "ncclGroupEnd");
+    OCN_RCCL_SYM(AllGather, "ncclAllGather");
+    OCN_RCCL_SYM(AllReduce, "ncclAllReduce");
+    OCN_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef OCN_RCCL_SYM
+    g_rccl.handle = h;
+    return OCN_OK;
+}
+#define NCCL_TRY(call)                                                                                           \
+    do {                                                                                                         \
+        int _r = (call);                                                                                         \
+        if (_r != 0) return fail(1000 + _r, "%s: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+    } while (0)
+
+struct ocn_dist_s {
+    int world = 1, rank = 0, west = 0, east = 0;
+    int kind = 0;                       // 0 RCCL, 1 caller-supplied transport
+    void *comm = nullptr;               // ncclComm_t
+    hipStream_t comm_stream = nullptr;  // halo transfers (overlap with kernels on the compute stream)
+    hipEvent_t ready = nullptr, done = nullptr;
+    ocn_transport_t tr = {};
+    double *scalar = nullptr;           // device scratch of the scalar reductions
+    bool in_flight = false;
+    bool self_loop = false;             // ONE rank that is its own west and east neighbour (see ocn_dist_set_self_loop)
+};
+
+extern "C" int ocn_dist_unique_id(void *id128) {
+    if (!id128) return fail(OCN_EINVAL, "NULL argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ocn_nccl_id id;
+    NCCL_TRY(g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_destroy(ocn_dist_t d) {
+    if (!d) return OCN_OK;
+    if (d->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(d->comm);
+    if (d->ready) hipEventDestroy(d->ready);
+    if (d->done) hipEventDestroy(d->done);
+    if (d->comm_stream) hipStreamDestroy(d->comm_stream);
+    hipFree(d->scalar);
+    delete d;
+    return OCN_OK;
+}
+
+static int dist_common_init(ocn_dist_s *d, int world, int rank) {
+    d->world = world; d->rank = rank;
+    d->west = (rank - 1 + world) % world;          // periodic wrap of the x neighbours (distributed_architectures.jl:391-434)
+    d->east = (rank + 1) % world;
+    HIP_TRY(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
+    HIP_TRY(dev_alloc((void **)&d->scalar, 2 * sizeof(double)));
+    return OCN_OK;
+}
+
+// Distributed(GPU(); partition = Partition(world)) with the library's own RCCL communicator. `id128`: the 128-byte ncclUniqueId made by
+// ocn_dist_unique_id on rank 0 and carried to every rank by the caller's bootstrap (MPI_Bcast, a TCP store, a file).
+extern "C" int ocn_dist_create(ocn_dist_t *dist, const void *id128, int world, int rank) {
+    NEED_INIT();
+    if (!dist || !id128 || world < 1 || rank < 0 || rank >= world) return fail(OCN_EINVAL, "invalid argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ocn_dist_s *d = new ocn_dist_s();
+    d->kind = 0;
+    if ((rc = dist_common_init(d, world, rank))) { ocn_dist_destroy(d); return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&d->comm_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { ocn_dist_destroy(d); return fail((int)e, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    ocn_nccl_id id;
+    memcpy(&id, id128, sizeof(id));
+    int r = g_rccl.CommInitRank(&d->comm, world, id, rank);
+    if (r != 0) { ocn_dist_destroy(d); return fail(1000 + r, "ncclCommInitRank: %s", g_rccl.GetErrorString(r)); }
+    *dist = d;
+    return OCN_OK;
+}
+
+// the same architecture object over a caller-supplied transport (MPI.jl in a Julia binder; threads or gloo in the tests)
+extern "C" int ocn_dist_create_transport(ocn_dist_t *dist, const ocn_transport_t *transport, int world, int rank) {
+    NEED_INIT();
+    if (!dist || !transport || world < 1 || rank < 0 || rank >= world) return fail(OCN_EINVAL, "invalid argument");
+    if (!transport->exchange_start || !transport->exchange_wait || !transport->all_to_all || !transport->all_gather || !transport->allreduce_max)
+        return fail(OCN_EINVAL, "every entry of ocn_transport_t must be set");
+    ocn_dist_s *d = new ocn_dist_s();
+    d->kind = 1;
+    d->tr = *transport;
+    int rc = dist_common_init(d, world, rank);
+    if (rc) { ocn_dist_destroy(d); return rc; }
+    *dist = d;
+    return OCN_OK;
+}
+
+// MEASUREMENT / TEST ONLY: a communicator of ONE rank treats x as partitioned with itself as both neighbours, so the complete N > 1
+// code path (FullyConnected x, pack / exchange / unpack, thin exchanges, gathered interface solve or transposes) runs -- and its
+// local cost can be timed -- on a one-GPU box. The result equals the one-rank Periodic run. Set before the model is created.
+extern "C" int ocn_dist_set_self_loop(ocn_dist_t d, int enabled) {
+    if (!d) return fail(OCN_EINVAL, "NULL argument");
+    if (enabled && d->world != 1) return fail(OCN_EINVAL, "self_loop needs a communicator of one rank");
+    d->self_loop = enabled != 0;
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_info(ocn_dist_t d, int *world, int *rank, int *west, int *east) {
+    if (!d) return fail(OCN_EINVAL, "NULL argument");
+    if (world) *world = d->world;
+    if (rank) *rank = d->rank;
+    if (west) *west = d->west;
+    if (east) *east = d->east;
+    return OCN_OK;
+}
+
+// MPI.Isend / Irecv! with both x neighbours (halo_communication.jl:300,326): `count` doubles per side. The transfers are ordered
+// behind everything already on the compute stream and run on the communication stream; kernels launched next overlap them.
+extern "C" int ocn_dist_exchange_start(ocn_dist_t d, const double *west_send, const double *east_send, double *west_recv, double *east_recv,
+                                       size_t count) {
+    NEED_INIT();
+    if (!d || !west_send || !east_send || !west_recv || !east_recv) return fail(OCN_EINVAL, "NULL argument");
+    if (d->in_flight) return fail(OCN_ESTATE, "an exchange is already in flight");
+    if (d->kind == 1) {
+        int rc = d->tr.exchange_start(d->tr.user, west_send, east_send, west_recv, east_recv, count, (void *)g_stream);
+        if (rc) return fail(rc, "transport exchange_start failed");
+        d->in_flight = true;
+        return OCN_OK;
+    }
+    HIP_TRY(hipEventRecord(d->ready, g_stream));
+    HIP_TRY(hipStreamWaitEvent(d->comm_stream, d->ready, 0));
+    // one group: the pairing is unambiguous even when both neighbours are the same rank (R = 2) or this rank itself (R = 1) --
+    // what leaves through the west side arrives in the west neighbour's EAST halo
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.Send(west_send, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
+    NCCL_TRY(g_rccl.Recv(east_recv, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
+    NCCL_TRY(g_rccl.Send(east_send, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
+    NCCL_TRY(g_rccl.Recv(west_recv, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    HIP_TRY(hipEventRecord(d->done, d->comm_stream));
+    d->in_flight = true;
+    return OCN_OK;
+}
+
+// MPI.Waitall (halo_communication.jl:164-165): later work on the compute stream waits for the transfers; the host does not
+extern "C" int ocn_dist_exchange_wait(ocn_dist_t d) {
+    NEED_INIT();
+    if (!d) return fail(OCN_EINVAL, "NULL argument");
+    if (!d->in_flight) return OCN_OK;
+    d->in_flight = false;
+    if (d->kind == 1) {
+        int rc = d->tr.exchange_wait(d->tr.user, (void *)g_stream);
+        return rc ? fail(rc, "transport exchange_wait failed") : OCN_OK;
+    }
+    HIP_TRY(hipStreamWaitEvent(g_stream, d->done, 0));
+    return OCN_OK;
+}
+
+// MPI.Alltoallv! with equal counts (distributed_transpose.jl:185-191): piece r of `send` (count doubles) goes to rank r
+extern "C" int ocn_dist_all_to_all(ocn_dist_t d, const double *send, double *recv, size_t count_per_rank) {
+    NEED_INIT();
+    if (!d || !send || !recv) return fail(OCN_EINVAL, "NULL argument");
+    if (d->kind == 1) {
+        int rc = d->tr.all_to_all(d->tr.user, send, recv, count_per_rank, (void *)g_stream);
+        return rc ? fail(rc, "transport all_to_all failed") : OCN_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    for (int r = 0; r < d->world; ++r) {
+        NCCL_TRY(g_rccl.Send(send + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
+        NCCL_TRY(g_rccl.Recv(recv + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
+    }
+    NCCL_TRY(g_rccl.GroupEnd());
+    return OCN_OK;
+}
+
+// MPI.Allgather of equal pieces: rank r's `count` doubles land at recv[r * count] on every rank
+extern "C" int ocn_dist_all_gather(ocn_dist_t d, const double *send, double *recv, size_t count) {
+    NEED_INIT();
+    if (!d || !send || !recv) return fail(OCN_EINVAL, "NULL argument");
+    if (d->kind == 1) {
+        int rc = d->tr.all_gather(d->tr.user, send, recv, count, (void *)g_stream);
+        return rc ? fail(rc, "transport all_gather failed") : OCN_OK;
+    }
+    NCCL_TRY(g_rccl.AllGather(send, recv, count, OCN_NCCL_FLOAT64, d->comm, g_stream));
+    return OCN_OK;
+}
+
+// all_reduce(max, value) over the ranks; synchronises the host (diagnostics, CFL, the bench's timing)
+extern "C" int ocn_dist_allreduce_max(ocn_dist_t d, double *value) {
+    NEED_INIT();
+    if (!d || !value) return fail(OCN_EINVAL, "NULL argument");
+    if (d->kind == 1) {
+        int rc = d->tr.allreduce_max(d->tr.user, value);
+        return rc ? fail(rc, "transport allreduce_max failed") : OCN_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(d->scalar, value, sizeof(double), hipMemcpyHostToDevice, g_stream));
+    NCCL_TRY(g_rccl.AllReduce(d->scalar, d->scalar + 1, 1, OCN_NCCL_FLOAT64, OCN_NCCL_MAX, d->comm, g_stream));
+    HIP_TRY(hipMemcpyAsync(value, d->scalar + 1, sizeof(double), hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    return OCN_OK;
+}
+
+extern "C" int ocn_dist_barrier(ocn_dist_t d) {
+    double v = 0.0;
+    return ocn_dist_allreduce_max(d, &v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the partitioned model: NonhydrostaticModel on Distributed(GPU(); partition = Partition(R)) (x-slabs)
+// ---------------------------------------------------------------------------------------------------------------------
+struct DistModel {
+    ocn_dist_t dist = nullptr;
+    ocn_dist_poisson_t solver = nullptr;
+    double *ws = nullptr, *es = nullptr, *wr = nullptr, *er = nullptr;     // halo buffers: Hx columns of every prognostic field per side
+    size_t slab_total = 0;
+    double *p2 = nullptr;                                                   // receives p / dt from the correction passes, swapped in
+    double *buf_a = nullptr, *buf_b = nullptr;                              // the solver's payload / gathered or send / recv buffers
+    size_t payload = 0, nbuf = 0;
+    bool halos_in_flight = false;
+    int async_halos = -1;       // -1 automatic (slab wide enough for whole-tile strips), 0 off, 1 on
+    int thin_halos = 1;         // pressure step: exchange the ONE column that is read (u[Nx+1], p[0]) instead of Hx columns
+    int early_exchange = 1;     // start update_state!'s exchange from make_pressure_correction!
+    int strip_width = 0;        // 0 automatic
+    bool partitioned() const { return dist->world > 1 || dist->self_loop; }
+};
+
+static void dist_model_free(DistModel *dm) {
+    if (!dm) return;
+    ocn_dist_poisson_destroy(dm->solver);
+    hipFree(dm->ws); hipFree(dm->es); hipFree(dm->wr); hipFree(dm->er); hipFree(dm->p2); hipFree(dm->buf_a);
+    if (dm->buf_b != dm->buf_a) hipFree(dm->buf_b);
+    delete dm;
+}
+
+static size_t dist_slab(const DGrid &g, const int loc[3], int depth) {
+    int P[3];
+    parent_size(g, loc, P);
+    return (size_t)depth * P[1] * P[2];
+}
+
+// fill_halo_regions! of partitioned fields (halo_communication.jl:87-110): local boundary conditions first
+// (boundary_condition_ordering.jl: the communication condition last), then the x exchange of `nx` leading fields, `depth` columns
+static int dist_fill_halo_regions(ocn_model_s *m, double *const *fields, const int (*locs)[3], int n, bool fill_open,
+                                  const ocn_bc_t (*bcs)[6], int nx = -1, int depth = 0) {
+    DistModel *dm = m->dm;
+    int rc = fill_halo_regions(m->grid, fields, locs, n, fill_open, bcs);
+    if (rc || !dm->partitioned()) return rc;
+    const DGrid &g = m->grid->d;
+    if (nx < 0) nx = n;
+    if (depth <= 0) depth = g.Hx;
+    size_t count = 0;
+    for (int f = 0; f < nx; ++f) count += dist_slab(g, locs[f], depth);
+    if ((rc = x_halo_buffers(g, fields, locs, nx, dm->ws, dm->es, true, depth))) return rc;
+    if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, count))) return rc;
+    if ((rc = ocn_dist_exchange_wait(dm->dist))) return rc;
+    return x_halo_buffers(g, fields, locs, nx, dm->wr, dm->er, false, depth);
+}
+
+// solve_for_pressure! + solve!(::DistributedFFTBasedPoissonSolver | ::DistributedFourierTridiagonalPoissonSolver)
+static int dist_solve_for_pressure(ocn_model_s *m) {
+    DistModel *dm = m->dm;
+    ocn_dist_poisson_s *s = dm->solver;
+    int rc;
+    if ((rc = ocn_dist_poisson_source_term(s, m->U[0], m->U[1], m->U[2]))) return rc;
+    if (s->sub) {
+        // z Periodic: substructured solve along the partitioned direction -- local transforms and sweeps, one small all-gather
+        if ((rc = ocn_dist_poisson_forward_local(s))) return rc;
+        if (dm->partitioned()) {
+            if ((rc = ocn_dist_all_gather(dm->dist, dm->buf_a, dm->buf_b, 2 * dm->payload))) return rc;
+        } else
+            HIP_TRY(hipMemcpyAsync(dm->buf_b, dm->buf_a, 2 * dm->payload * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
+        return ocn_dist_poisson_backward_local(s, m->p);
+    }
+    const size_t per_rank = 2 * dm->nbuf / (size_t)dm->dist->world;
+    if ((rc = ocn_dist_poisson_forward_yz(s))) return rc;
+    if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_y_to_x!
+    if ((rc = ocn_dist_poisson_solve_x(s))) return rc;
+    if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_x_to_y!
+    return ocn_dist_poisson_backward_yz(s, m->p);
+}
+
+// compute_pressure_correction! (pressure_correction.jl:8-20). Of the x halos only ONE column is read before update_state! fills
+// everything again: u[Nx+1] by the divergence, p[0] by the correction. The reference's generic fills move Hx columns of u, v, w and of
+// p here; `thin_halos` exchanges the one column of u and of p -- identical results in every cell that is read.
+static int dist_compute_pressure_correction(ocn_model_s *m) {
+    DistModel *dm = m->dm;
+    const bool thin = dm->thin_halos != 0;
+    int rc = dist_fill_halo_regions(m, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr, thin ? 1 : 3, thin ? 1 : 0);
+    if (rc) return rc;
+    if ((rc = dist_solve_for_pressure(m))) return rc;
+    double *pp[1] = {m->p};
+    const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
+    return dist_fill_halo_regions(m, pp, pl, 1, true, nullptr, 1, thin ? 1 : 0);
+}
+
+// make_pressure_correction! (pressure_correction.jl:40-53); the correction passes write p / dt into the second pressure array.
+// start_halo_exchange (tendencies are evaluated next): correct the two Hx-wide boundary strips first, fill their y / z halos, pack
+// them and START the x exchange of the coming update_state!; the interior correction runs while the halos are in flight.
+static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_halo_exchange) {
+    DistModel *dm = m->dm;
+    const DGrid &g = m->grid->d;
+    const double dtp = std::fmax(2.220446049250313e-16, dt);
+    int rc;
+    auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], m->p, range, dm->p2, dtp); };
+    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx)) {
+        if ((rc = pc(nullptr))) return rc;
+        std::swap(m->p, dm->p2);
+        return OCN_OK;
+    }
+    const int west[6] = {1, g.Hx, 1, g.Ny, 1, g.Nz}, east[6] = {g.Nx - g.Hx + 1, g.Nx, 1, g.Ny, 1, g.Nz};
+    const int mid[6] = {g.Hx + 1, g.Nx - g.Hx, 1, g.Ny, 1, g.Nz};
+    if ((rc = pc(west)) || (rc = pc(east))) return rc;
+    if ((rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, false, m->any_bc ? m->bcs : nullptr))) return rc;   // the strips' y / z halos
+    if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->ws, dm->es, true))) return rc;
+    if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, dm->slab_total))) return rc;
+    dm->halos_in_flight = true;
+    if ((rc = pc(mid))) return rc;
+    std::swap(m->p, dm->p2);
+    return OCN_OK;
+}
+
+static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub, const int *amd_range);
+
+// update_state! (update_nonhydrostatic_model_state.jl:20-56) with the interior / buffer split of
+// interleave_communication_and_computation.jl:9-67 when the exchange overlaps the interior tendencies
+static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub) {
+    DistModel *dm = m->dm;
+    const DGrid &g = m->grid->d;
+    const ocn_bc_t(*bcs)[6] = m->any_bc ? m->bcs : nullptr;
+    // eddy diffusivities at i = 0 and Nx + 1 are evaluated by the rank itself from the exchanged halos (the numbers a serial
+    // Periodic grid's fill copies from the other side): no exchange of the diffusivity fields
+    const int ext = dm->partitioned() ? 1 : 0;
+    const int amd_range[6] = {1 - ext, g.Nx + ext, 1, g.Ny, 1, g.Nz};
+    int rc;
+    if (dm->halos_in_flight) {
+        // the x exchange was started by make_pressure_correction!: finish the local fills (all columns are final now), take the
+        // halos, then everything in one piece
+        dm->halos_in_flight = false;
+        if ((rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, false, bcs))) return rc;
+        if ((rc = ocn_dist_exchange_wait(dm->dist))) return rc;
+        if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->wr, dm->er, false))) return rc;
+        return update_state_tail(m, compute_tend, sub, amd_range);
+    }
+    const bool physics = has_physics(m) || m->any_flux_bc || m->any_linear_flux;
+    const bool overlap = dm->async_halos < 0 ? g.Nx >= 3 * 64 : dm->async_halos != 0;
+    if (!compute_tend || !dm->partitioned() || !overlap || g.Nx <= 2 * g.Hx || physics) {
+        if ((rc = dist_fill_halo_regions(m, m->U, m->loc, m->nf, false, bcs))) return rc;
+        return update_state_tail(m, compute_tend, sub, amd_range);
+    }
+    // start the exchange, compute the interior that does not depend on x halos, finish, compute the two strips. The reference's strips
+    // are Hx wide; the tendency kernel works on 64-lane tiles, so the strips are one tile wide whenever that leaves a tile of interior.
+    int W = dm->strip_width > 0 ? dm->strip_width : (g.Nx >= 3 * 64 ? 64 : g.Hx);
+    if (!(g.Hx <= W && 2 * W < g.Nx)) return fail(OCN_EINVAL, "strip width %d must satisfy Hx <= W < Nx / 2", W);
+    if ((rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, false, bcs))) return rc;
+    if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->ws, dm->es, true))) return rc;
+    if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, dm->slab_total))) return rc;
+    const int interior[6] = {W + 1, g.Nx - W, 1, g.Ny, 1, g.Nz}, ws[6] = {1, W, 1, g.Ny, 1, g.Nz}, es[6] = {g.Nx - W + 1, g.Nx, 1, g.Ny, 1, g.Nz};
+    auto tend = [&](const int *range) {
+        return compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, range,
+                                  m->tendency_impl, sub);
+    };
+    if ((rc = tend(interior))) return rc;                                  // ... while the halos fly (:27-67)
+    if ((rc = ocn_dist_exchange_wait(dm->dist))) return rc;                // synchronize_communication! (distributed_fields.jl:71-88)
+    if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->wr, dm->er, false))) return rc;
+    if ((rc = tend(ws)) || (rc = tend(es))) return rc;                     // compute_buffer_tendencies!
+    return OCN_OK;
+}
+
+static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow) {
+    int rc = dist_compute_pressure_correction(m);
+    if (rc) return rc;
+    return dist_make_pressure_correction(m, dt, tendencies_follow);
+}
+
+// NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected
+// (OCN_CONNECTED) when the direction is partitioned; `Lx_global`: extent of the global domain along x (the solver's eigenvalues)
+extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global) {
+    NEED_INIT();
+    if (!model || !local_grid || !dist) return fail(OCN_EINVAL, "NULL argument");
+    const DGrid &g = local_grid->d;
+    const bool part = dist->world > 1 || dist->self_loop;
+    if (part && g.tx != OCN_CONNECTED) return fail(OCN_EINVAL, "the local grid of a partitioned x direction must be FullyConnected in x");
+    if (!part && g.tx == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected x direction needs more than one rank");
+    int rc = model_create(model, local_grid, ntracers, /*with_solver=*/false);
+    if (rc) return rc;
+    ocn_model_s *m = *model;
+    DistModel *dm = new DistModel();
+    m->dm = dm;
+    dm->dist = dist;
+    auto bail = [&](int code) { ocn_model_destroy(m); *model = nullptr; return code; };
+    for (int f = 0; f < m->nf; ++f) dm->slab_total += dist_slab(g, m->loc[f], g.Hx);
+    double **bufs[4] = {&dm->ws, &dm->es, &dm->wr, &dm->er};
+    for (auto b : bufs) {
+        hipError_t e = dev_alloc((void **)b, dm->slab_total * sizeof(double));
+        if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(halo buffers): %s", hipGetErrorString(e)));
+        hipMemsetAsync(*b, 0, dm->slab_total * sizeof(double), g_stream);
+    }
+    {
+        int P[3];
+        parent_size(g, LOC_C, P);
+        const size_t bytes = (size_t)P[0] * P[1] * P[2] * sizeof(double);
+        hipError_t e = dev_alloc((void **)&dm->p2, bytes);
+        if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(p2): %s", hipGetErrorString(e)));
+        hipMemsetAsync(dm->p2, 0, bytes, g_stream);
+    }
+    if ((rc = ocn_dist_poisson_create(&dm->solver, local_grid, dist->world, dist->rank, Lx_global))) return bail(rc);
+    size_t n = 0;
+    ocn_dist_poisson_payload_size(dm->solver, &n);
+    if (n) {
+        dm->payload = n;
+        hipError_t e = dev_alloc((void **)&dm->buf_a, 2 * n * sizeof(double));
+        if (e == hipSuccess) e = dev_alloc((void **)&dm->buf_b, 2 * n * sizeof(double) * (size_t)dist->world);
+        if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(gather buffers): %s", hipGetErrorString(e)));
+        hipMemsetAsync(dm->buf_a, 0, 2 * n * sizeof(double), g_stream);
+        hipMemsetAsync(dm->buf_b, 0, 2 * n * sizeof(double) * (size_t)dist->world, g_stream);
+        if ((rc = ocn_dist_poisson_set_gather_buffers(dm->solver, dm->buf_a, dm->buf_b))) return bail(rc);
+    } else {
+        ocn_dist_poisson_buffer_size(dm->solver, &n);
+        dm->nbuf = n;
+        hipError_t e = dev_alloc((void **)&dm->buf_a, 2 * n * sizeof(double));
+        // one rank: the "transposes" are the identity -- alias the buffers instead of copying
+        if (!part) dm->buf_b = dm->buf_a;
+        else if (e == hipSuccess) e = dev_alloc((void **)&dm->buf_b, 2 * n * sizeof(double));
+        if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(transpose buffers): %s", hipGetErrorString(e)));
+        hipMemsetAsync(dm->buf_a, 0, 2 * n * sizeof(double), g_stream);
+        if (dm->buf_b != dm->buf_a) hipMemsetAsync(dm->buf_b, 0, 2 * n * sizeof(double), g_stream);
+        if ((rc = ocn_dist_poisson_set_buffers(dm->solver, dm->buf_a, dm->buf_b))) return bail(rc);
+    }
+    return OCN_OK;
+}
+
+static int dist_model_set_option(ocn_model_s *m, const char *key, int value) {
+    DistModel *dm = m->dm;
+    if (!dm) return -1;
+    if (!strcmp(key, "async_halos")) { dm->async_halos = value; return OCN_OK; }
+    if (!strcmp(key, "thin_halos")) { dm->thin_halos = value; return OCN_OK; }
+    if (!strcmp(key, "early_exchange")) { dm->early_exchange = value; return OCN_OK; }
+    if (!strcmp(key, "strip_width")) { dm->strip_width = value; return OCN_OK; }
+    return -1;
+}
+
+// global maximum of |div u| (test helper of the partitioned model)
+extern "C" int ocn_dist_model_max_abs_divergence(ocn_model_t m, double *value) {
+    NEED_INIT();
+    if (!m || !m->dm || !value) return fail(OCN_EINVAL, "not a distributed model");
+    int rc = dist_fill_halo_regions(m, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr);
+    if (rc) return rc;
+    if ((rc = ocn_max_abs_divergence(m->grid, m->U[0], m->U[1], m->U[2], value))) return rc;
+    return ocn_dist_allreduce_max(m->dm->dist, value);
+}

@@ -1,7 +1,11 @@
 """Distributed x-slab NonhydrostaticModel (reference: src/DistributedComputations/, src/Models/interleave_communication_and_computation.jl).
 
-MI355X-first design: ONE process per GPU; collectives are RCCL over xGMI issued through `torch.distributed`
-(backend "nccl" is RCCL on ROCm); all kernels and collectives are ordered on ONE HIP stream per rank (torch's current
+MI355X-first design: ONE process per GPU. The PRODUCT path keeps everything behind the C ABI: the library owns the RCCL
+communicator and runs the partitioned time-step itself (`Distributed`, `LibraryDistributedModel` at the end of this module ->
+ocn_dist_create / ocn_dist_model_create / ocn_model_time_step; no torch in the process). The classes in between are the
+host-orchestrated form of the same step, written against a small `backend` protocol: it is the TEST HARNESS (gloo world_size-2 CPU
+tests, virtual ranks on one card, host-staged rehearsals) and the place where the stage order can be read next to the reference's.
+There collectives go through `torch.distributed` and all kernels and collectives are ordered on ONE HIP stream per rank (torch's current
 stream, handed to the library with `ocn_set_stream`), so there is no host synchronisation on the hot path -- the
 reference calls `sync_device!` before every MPI call (halo_communication.jl:181, distributed_transpose.jl:187).
 
@@ -18,7 +22,6 @@ import ctypes as C
 import os
 
 import numpy as np
-import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so in this process (see init_process_group)
 
 from . import _lib
 from .advection import WENO
@@ -817,3 +820,156 @@ def max_abs_divergence(model):
                (w[H:-H, H:-H, H + 1:w.shape[2] - H + 1] - w[core]) / dz)
         local = float(np.abs(div).max())
     return ctx.allreduce_max(local)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# PRODUCT PATH: the communicator and the partitioned time-step inside libocn_mi355x.so (include/ocn_mi355x.h, distributed group)
+# ----------------------------------------------------------------------------------------------------------------------
+class Distributed:
+    """`Distributed(GPU(); partition = Partition(R))` (distributed_architectures.jl:166-302) with the communicator INSIDE the library:
+    RCCL (ocn_dist_create) or caller-supplied collectives (ocn_dist_create_transport). No torch in the process."""
+
+    def __init__(self, handle, rank, world, arch, self_loop=False, keepalive=None):
+        self.handle, self.rank, self.world, self.arch = handle, rank, world, arch
+        self.partition = Partition(world)
+        self.west, self.east = self.partition.neighbours(rank)
+        self.self_loop = bool(self_loop)
+        self._keepalive = keepalive            # ctypes callbacks of a transport must outlive the communicator
+
+    @property
+    def partitioned(self):
+        return self.world > 1 or self.self_loop
+
+    def allreduce_max(self, value):
+        v = C.c_double(float(value))
+        _lib.check(_lib.lib().ocn_dist_allreduce_max(self.handle, C.byref(v)))
+        return v.value
+
+    def barrier(self):
+        _lib.check(_lib.lib().ocn_dist_barrier(self.handle))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None:
+            _lib.lib().ocn_dist_destroy(self.handle)
+            self.handle = None
+
+    # -- construction --------------------------------------------------------------------------------------------
+    @classmethod
+    def rccl(cls, arch, unique_id, world, rank, self_loop=False):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ocn_dist_create(C.byref(h), unique_id, int(world), int(rank)))
+        if self_loop:
+            _lib.check(_lib.lib().ocn_dist_set_self_loop(h, 1))
+        return cls(h, rank, world, arch, self_loop)
+
+    @classmethod
+    def from_environment(cls, local_rank=None, self_loop=False):
+        """one process per GPU under `python -m torch.distributed.run` (or any launcher that exports RANK, WORLD_SIZE, LOCAL_RANK,
+        MASTER_ADDR, MASTER_PORT): rank 0 makes the ncclUniqueId, a one-shot TCP exchange carries it to the other ranks"""
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # this pool's driver only supports dmabuf IPC
+        from .architectures import GPU
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if local_rank is None:
+            local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        arch = GPU(local_rank)
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+        if world > 1:
+            uid = C.create_string_buffer(_broadcast_bytes(uid.raw if rank == 0 else None, rank, world), 128)
+        return cls.rccl(arch, uid, world, rank, self_loop)
+
+    @classmethod
+    def transport(cls, arch, collectives, world, rank, self_loop=False):
+        """collectives: an object with exchange_start(west_send, east_send, west_recv, east_recv, count), exchange_wait(),
+        all_to_all(send, recv, count_per_rank), all_gather(send, recv, count), allreduce_max(value) -> float; buffer arguments are
+        device addresses (int). This is the seam an MPI binder would use; the tests plug in threads sharing one card."""
+        T = _lib.Transport
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception:          # a Python exception must not unwind through C frames
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return wrapped
+
+        def allreduce(user, pvalue):
+            pvalue[0] = float(collectives.allreduce_max(pvalue[0]))
+
+        cbs = dict(
+            exchange_start=T.EXCHANGE_START(guard(lambda u, ws, es, wr, er, n, st: collectives.exchange_start(ws, es, wr, er, n))),
+            exchange_wait=T.EXCHANGE_WAIT(guard(lambda u, st: collectives.exchange_wait())),
+            all_to_all=T.ALL_TO_ALL(guard(lambda u, s_, r_, n, st: collectives.all_to_all(s_, r_, n))),
+            all_gather=T.ALL_GATHER(guard(lambda u, s_, r_, n, st: collectives.all_gather(s_, r_, n))),
+            allreduce_max=T.ALLREDUCE_MAX(guard(allreduce)))
+        t = T(user=None, **cbs)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ocn_dist_create_transport(C.byref(h), C.byref(t), int(world), int(rank)))
+        if self_loop:
+            _lib.check(_lib.lib().ocn_dist_set_self_loop(h, 1))
+        return cls(h, rank, world, arch, self_loop, keepalive=(t, cbs, collectives))
+
+
+def _broadcast_bytes(payload, rank, world, timeout=120.0):
+    """rank 0 -> everyone, over TCP on MASTER_ADDR : MASTER_PORT + 1 (the launcher's own store sits on MASTER_PORT)"""
+    import socket
+    import time
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1
+    if rank == 0:
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _peer = srv.accept()
+            conn.sendall(payload)
+            conn.close()
+        srv.close()
+        return payload
+    deadline = time.time() + timeout
+    while True:
+        try:
+            c = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() > deadline:
+                raise _lib.OcnError(f"rank {rank}: no unique id from rank 0 at {addr}:{port}")
+            time.sleep(0.05)
+    data = b""
+    while len(data) < 128:
+        chunk = c.recv(128 - len(data))
+        if not chunk:
+            raise _lib.OcnError("unique-id exchange: connection closed early")
+        data += chunk
+    c.close()
+    return data
+
+
+from .models import NonhydrostaticModel as _NonhydrostaticModel   # noqa: E402
+
+
+class LibraryDistributedModel(_NonhydrostaticModel):
+    """NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) whose time-step -- halo exchanges, interior / buffer split,
+    distributed pressure solve -- runs inside the library (ocn_dist_model_create). Same host API as NonhydrostaticModel:
+    ocn.time_step, ocn.set_model (LOCAL interior arrays), ocn.update_state, model.clock, Simulation."""
+
+    def __init__(self, grid, **kwargs):
+        if not isinstance(grid.ctx, Distributed):
+            raise TypeError("LibraryDistributedModel needs a grid on a `Distributed` architecture (communicator inside the library)")
+        self.ctx = grid.ctx
+        super().__init__(grid, **kwargs)
+
+    def _create_handle(self, grid, ntracers):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ocn_dist_model_create(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global)))
+        return h
+
+    def max_abs_divergence(self):
+        v = C.c_double()
+        _lib.check(_lib.lib().ocn_dist_model_max_abs_divergence(self.handle, C.byref(v)))
+        return v.value

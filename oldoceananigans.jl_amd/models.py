@@ -64,9 +64,7 @@ class NonhydrostaticModel:
         self.closure = closure
         self.grid, self.advection = grid, advection
         self.tracer_names = tuple(str(t) for t in (tracers if isinstance(tracers, (tuple, list)) else (tracers,)))
-        h = C.c_void_p()
-        _lib.check(_lib.lib().ocn_model_create(C.byref(h), grid.handle, len(self.tracer_names)))
-        self.handle = h
+        self.handle = self._create_handle(grid, len(self.tracer_names))
         self.clock = Clock(self)
         V = namedtuple("Velocities", "u v w")
         self.velocities = V(self._field("u"), self._field("v"), self._field("w"))
@@ -119,6 +117,11 @@ class NonhydrostaticModel:
                     continue
                 _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, self._cname(name).encode(), SIDES.index(side),
                                                                        KINDS[bc.classification], bc.condition))
+
+    def _create_handle(self, grid, ntracers):
+        h = C.c_void_p()
+        _lib.check(_lib.lib().ocn_model_create(C.byref(h), grid.handle, ntracers))
+        return h
 
     @property
     def architecture(self):
@@ -197,6 +200,8 @@ def time_step(model, Δt, euler=False):
 
 
 def max_abs_divergence(model):
+    if hasattr(model, "ctx") and hasattr(model, "max_abs_divergence"):       # partitioned model: global maximum
+        return model.max_abs_divergence()
     v = C.c_double()
     _lib.check(_lib.lib().ocn_model_max_abs_divergence(model.handle, C.byref(v)))
     return v.value

@@ -69,3 +69,63 @@ class LoopbackContext:
 
     def barrier(self):
         self.w.barrier_obj.wait()
+
+
+class PointerLoopbackWorld:
+    """The same rendezvous for the IN-LIBRARY partitioned model (ocn_dist_create_transport): the collectives arrive as raw device
+    addresses from the library's own orchestration; copies are the library's stream-ordered device copies (all virtual ranks share
+    the library's one compute stream, the barriers order the SUBMISSION of pack kernels and copies)."""
+
+    def __init__(self, R, lib):
+        self.R, self.lib = R, lib
+        self.barrier_obj = threading.Barrier(R)
+        self.slots = [None] * R
+        self.vals = [0.0] * R
+
+    def collectives(self, rank):
+        return PointerLoopback(self, rank)
+
+
+class PointerLoopback:
+    def __init__(self, world, rank):
+        self.w, self.rank, self.R = world, rank, world.R
+        self.west, self.east = (rank - 1) % world.R, (rank + 1) % world.R
+
+    def _copy(self, dst, src, ndoubles):
+        rc = self.w.lib.ocn_memcpy_d2d(dst, src, 8 * ndoubles)
+        assert rc == 0, rc
+
+    def exchange_start(self, ws, es, wr, er, n):
+        w = self.w
+        w.slots[self.rank] = (ws, es)
+        w.barrier_obj.wait()
+        self._copy(er, w.slots[self.east][0], n)      # east neighbour's west slab -> my east halo
+        self._copy(wr, w.slots[self.west][1], n)      # west neighbour's east slab -> my west halo
+        w.barrier_obj.wait()
+
+    def exchange_wait(self):
+        pass
+
+    def all_to_all(self, send, recv, n):
+        w = self.w
+        w.slots[self.rank] = send
+        w.barrier_obj.wait()
+        for s in range(self.R):
+            self._copy(recv + 8 * n * s, w.slots[s] + 8 * n * self.rank, n)
+        w.barrier_obj.wait()
+
+    def all_gather(self, send, recv, n):
+        w = self.w
+        w.slots[self.rank] = send
+        w.barrier_obj.wait()
+        for s in range(self.R):
+            self._copy(recv + 8 * n * s, w.slots[s], n)
+        w.barrier_obj.wait()
+
+    def allreduce_max(self, value):
+        w = self.w
+        w.vals[self.rank] = float(value)
+        w.barrier_obj.wait()
+        m = max(w.vals)
+        w.barrier_obj.wait()
+        return m

@@ -1,0 +1,215 @@
+"""GPU: the partitioned time-step INSIDE the library (include/ocn_mi355x.h, distributed group: ocn_dist_create, ocn_dist_model_create,
+ocn_model_time_step on a distributed model) -- the product's N > 1 path.
+
+  * over RCCL itself with a communicator of one rank that is its own neighbour (ocn_dist_set_self_loop): the whole partitioned code
+    path runs through ncclSend / ncclRecv / ncclAllGather on the one-GPU box, against the single-GPU model;
+  * with R virtual ranks (threads sharing the card) over the caller-supplied transport (ocn_dist_create_transport, tests/loopback.py),
+    against the single-GPU model: same-peer case R = 2, R = 4, odd local sizes, Bounded / stretched z (transposing
+    Fourier-tridiagonal solver), the configs[4] physics.
+
+Reference tests mirrored: test_distributed_models.jl:334-404 (rank ids in the halos), test_distributed_poisson_solvers.jl:70-163 and
+the distributed-vs-serial agreement of test_distributed_models.jl."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from dist_worker import analytic
+from test_gpu_distributed import _bcs, _closure, _tracers_and_buoyancy, _z_and_topology
+
+pytestmark = pytest.mark.gpu
+
+
+def _own_stream():
+    from oldoceananigans_jl_amd import _lib
+    _lib.check(_lib.lib().ocn_own_stream())
+
+
+def _single_gpu(ocn, arch, size, zkind, nsteps):
+    z, topo = _z_and_topology(ocn, zkind, size[2])
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
+                                    buoyancy=_tracers_and_buoyancy(ocn, zkind)[1], coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
+    ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
+    dt = 0.1 * grid.Δxᶜᵃᵃ / 0.6
+    for _ in range(nsteps):
+        ocn.time_step(model, dt)
+    out = {n: f.parent() for n, f in model.fields().items()}
+    out["p"] = model.pressures.pNHS.parent()
+    return out, model.clock.time, dt
+
+
+def _library_model(ocn, dist, ctx, size, zkind):
+    z, topo = _z_and_topology(ocn, zkind, size[2])
+    grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
+                                         buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
+                                         coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
+    ocn.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in model.fields().items()})
+    return grid, model
+
+
+def _compare(out, ref, r, nxl, size):
+    for name, a in out.items():
+        want = ref[name][3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]
+        scale = np.abs(ref[name]).max()
+        err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / scale
+        assert err <= 1e-12, (r, name, err, int(np.isnan(a).sum()))
+
+
+@pytest.mark.parametrize("size,zkind,substructured,async_halos", [
+    ((32, 16, 8), "periodic", 1, 1), ((32, 16, 8), "periodic", 0, 1), ((32, 12, 10), "stretched", 1, 1), ((384, 8, 8), "periodic", 1, -1),
+    ((32, 16, 8), "periodic", 1, 0)])
+def test_library_self_loop_over_rccl_equals_single_gpu(ocn, arch, size, zkind, substructured, async_halos):
+    """RCCL communicator of ONE rank that is its own west and east neighbour: pack / ncclSend + ncclRecv on the communication
+    stream / unpack, the exchange started from make_pressure_correction!, thin exchanges, ncclAllGather of the interface values (or
+    the two all-to-alls as grouped send / recv) -- the fields equal the single-GPU model's"""
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _own_stream()
+    ocn.set_option("dist_substructured", substructured)
+    try:
+        uid = C.create_string_buffer(128)
+        _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+        ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
+        grid, model = _library_model(ocn, dist, ctx, size, zkind)
+        assert grid.local.topology[0] is ocn.FullyConnected
+        model.set_option("async_halos", async_halos)
+        ref, time, dt = _single_gpu(ocn, arch, size, zkind, 3)
+        for _ in range(3):
+            ocn.time_step(model, dt)
+        assert model.clock.time == time and model.clock.iteration == 3
+        assert ocn.max_abs_divergence(model) < 5e-8
+        out = {n: f.parent() for n, f in model.fields().items()}
+        out["p"] = model.pressures.pNHS.parent()
+        model.close()
+        ctx.close()
+    finally:
+        ocn.set_option("dist_substructured", 1)
+    _compare(out, ref, 0, size[0], size)
+    for name in ("u", "v", "w", "T", "S"):      # the x halos hold bit-exact copies of the other side's interior columns
+        assert np.array_equal(out[name][:3, 3:-3, 3:-3], out[name][-6:-3, 3:-3, 3:-3]), name
+
+
+def test_library_collectives_over_rccl_world_1(ocn, arch):
+    """the raw collectives of the boundary with a one-rank RCCL communicator: an exchange swaps the sides (what leaves through the
+    west side arrives in the east halo), all-to-all / all-gather are copies, the reduction returns its argument"""
+    from oldoceananigans_jl_amd import _lib
+    L = _lib.lib()
+    _own_stream()
+    uid = C.create_string_buffer(128)
+    _lib.check(L.ocn_dist_unique_id(uid))
+    d = C.c_void_p()
+    _lib.check(L.ocn_dist_create(C.byref(d), uid, 1, 0))
+    w, r, we, ea = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    _lib.check(L.ocn_dist_info(d, C.byref(w), C.byref(r), C.byref(we), C.byref(ea)))
+    assert (w.value, r.value, we.value, ea.value) == (1, 0, 0, 0)
+    n = 1000
+    bufs = []
+    for _ in range(4):
+        p = C.c_void_p()
+        _lib.check(L.ocn_malloc(C.byref(p), 8 * n))
+        bufs.append(p)
+    ws, es, wr, er = bufs
+    a, b = np.arange(n, dtype=np.float64), -np.arange(n, dtype=np.float64)
+    _lib.check(L.ocn_memcpy_h2d(ws, a.ctypes.data, 8 * n))
+    _lib.check(L.ocn_memcpy_h2d(es, b.ctypes.data, 8 * n))
+    _lib.check(L.ocn_dist_exchange_start(d, ws, es, wr, er, n))
+    _lib.check(L.ocn_dist_exchange_wait(d))
+    got_w, got_e = np.empty(n), np.empty(n)
+    _lib.check(L.ocn_memcpy_d2h(got_w.ctypes.data, wr, 8 * n))
+    _lib.check(L.ocn_memcpy_d2h(got_e.ctypes.data, er, 8 * n))
+    assert np.array_equal(got_e, a) and np.array_equal(got_w, b)
+    _lib.check(L.ocn_dist_all_to_all(d, ws, wr, n))
+    _lib.check(L.ocn_dist_all_gather(d, es, er, n))
+    _lib.check(L.ocn_memcpy_d2h(got_w.ctypes.data, wr, 8 * n))
+    _lib.check(L.ocn_memcpy_d2h(got_e.ctypes.data, er, 8 * n))
+    assert np.array_equal(got_w, a) and np.array_equal(got_e, b)
+    v = C.c_double(-3.25)
+    _lib.check(L.ocn_dist_allreduce_max(d, C.byref(v)))
+    assert v.value == -3.25
+    _lib.check(L.ocn_dist_barrier(d))
+    for p in bufs:
+        _lib.check(L.ocn_free(p))
+    _lib.check(L.ocn_dist_destroy(d))
+
+
+def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options):
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    from loopback import PointerLoopbackWorld
+    world = PointerLoopbackWorld(R, _lib.lib())
+    results, errors = [None] * R, []
+    dt = 0.1 * (2.0 / size[0]) / 0.6
+
+    def worker(rank):
+        try:
+            ctx = dist.Distributed.transport(arch, world.collectives(rank), R, rank)
+            grid, model = _library_model(ocn, dist, ctx, size, zkind)
+            for k, v in options.items():
+                model.set_option(k, v)
+            for _ in range(nsteps):
+                ocn.time_step(model, dt)
+            div = ocn.max_abs_divergence(model)
+            out = {n: f.parent() for n, f in model.fields().items()}
+            out["p"] = model.pressures.pNHS.parent()
+            # test/test_distributed_models.jl:334-404: fields filled with the rank id; after update_state! the x halos hold the neighbours' ids
+            for n, f in enumerate(model.fields().values()):
+                f.set_parent(np.full(f.shape, 100.0 * n + rank))
+            ocn.update_state(model, False)
+            west, east = (rank - 1) % R, (rank + 1) % R
+            for n, f in enumerate(model.fields().values()):
+                a = f.parent()
+                assert np.all(a[:3, 3:-3, 3:-3] == 100 * n + west) and np.all(a[-3:, 3:-3, 3:-3] == 100 * n + east), (rank, n)
+            results[rank] = (out, div, model.clock.time)
+            model.close()
+            ctx.close()
+        except BaseException as e:          # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            world.barrier_obj.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return results
+
+
+@pytest.mark.parametrize("R,size,zkind,options", [
+    (2, (32, 16, 8), "periodic", {}),                                   # both neighbours are the same rank
+    (2, (32, 16, 8), "periodic", {"async_halos": 0}),
+    (2, (32, 16, 8), "periodic", {"early_exchange": 0, "async_halos": 1}),   # interior / buffer split with Hx-wide strips
+    (2, (32, 16, 8), "periodic", {"thin_halos": 0}),
+    (4, (36, 12, 10), "periodic", {}),                                  # odd local Nx (9)
+    (8, (64, 8, 8), "periodic", {}),                                    # the rank count of one MI355X node
+    (3, (24, 9, 6), "periodic", {}),
+    (2, (384, 8, 8), "periodic", {"early_exchange": 0, "async_halos": 1}),   # local Nx = 192: buffer strips one 64-lane tile wide
+    (2, (32, 16, 8), "bounded", {}),                                    # distributed Fourier-tridiagonal solver + ScalarDiffusivity + buoyancy
+    (8, (64, 8, 8), "stretched", {}),                                   # transposing solver over 8 ranks, Coriolis, boundary conditions
+    (4, (32, 12, 10), "amd", {}),                                       # the configs[4] physics
+])
+def test_library_virtual_ranks_match_single_gpu(ocn, arch, R, size, zkind, options):
+    _own_stream()
+    nsteps = 3
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options)
+    ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps)
+    nxl = size[0] // R
+    for r, (out, div, t) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, nxl, size)
+
+
+def test_library_transposing_solver_matches(ocn, arch):
+    """the all-to-all form of the periodic solver (option dist_substructured = 0) through the library's orchestration"""
+    _own_stream()
+    ocn.set_option("dist_substructured", 0)
+    try:
+        results = _run_library_ranks(ocn, arch, 4, (36, 12, 10), 3, "periodic", {})
+    finally:
+        ocn.set_option("dist_substructured", 1)
+    ref, time, _ = _single_gpu(ocn, arch, (36, 12, 10), "periodic", 3)
+    for r, (out, div, t) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, 9, (36, 12, 10))
