@@ -7,7 +7,9 @@
 
 N = 1: 256^3 triply periodic on one MI355X (BASELINE.json configs[1]).
 N > 1: launched by torch.distributed.run, one rank per GPU; x-slab decomposition, WEAK scaling (256^3 per GPU, i.e.
-       global (256 N) x 256 x 256), RCCL halo exchange + all-to-all transposes inside the pressure solve.
+       global (256 N) x 256 x 256). The library owns the RCCL communicator (ocn_dist_create; the ncclUniqueId travels over a
+       one-shot TCP exchange on MASTER_PORT + 1) and runs the partitioned step itself: halo send / recv on its communication
+       stream, one small all-gather per pressure solve. No torch in the process.
 
 Prints ONE JSON line on rank 0 (contract in the task statement): value = whole-job cell-updates/s with all inputs
 resident in HBM; "roofline" = the dominant kernel (fused WENO tendency evaluation) from HIP events recorded on the
@@ -179,20 +181,24 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    if world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1" or os.environ.get("OCN_SELF_LOOP") == "1":
+    # OCN_REHEARSE_ON_ONE_GPU=1 (test harness): all ranks share card 0, collectives staged through the host over gloo by the
+    # host-orchestrated form of the step (torch.distributed) -- exercises a multi-process run on a one-GPU box; not a measurement
+    rehearsal = os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
         import torch  # noqa: F401  -- must precede the first load of libocn_mi355x.so (see distributed.init_process_group)
     import oldoceananigans_jl_amd as ocn
     N = args.global_size if (args.global_size and world == 1) else args.size
     distributed = world > 1 or os.environ.get("OCN_FORCE_DISTRIBUTED") == "1" or os.environ.get("OCN_SELF_LOOP") == "1"
     if distributed:
         from oldoceananigans_jl_amd import distributed as dist
-        # OCN_REHEARSE_ON_ONE_GPU=1: all ranks share card 0, collectives staged through the host over gloo -- exercises this
-        # script's N > 1 path on a one-GPU box; the numbers it prints are not measurements
-        rehearsal = os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1"
-        # OCN_SELF_LOOP=1 (one rank): the rank is its own west / east neighbour -- the complete N > 1 code path with device copies
-        # in place of the RCCL transfers: the LOCAL cost of the partitioned path, measurable on a one-GPU box
+        # OCN_SELF_LOOP=1 (one rank): the rank is its own west / east neighbour -- the complete N > 1 code path, RCCL send / recv to
+        # itself included: the LOCAL cost of the partitioned path, measurable on a one-GPU box
         self_loop = os.environ.get("OCN_SELF_LOOP") == "1" and world == 1
-        ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=rehearsal, self_loop=self_loop)
+        if rehearsal:
+            ctx = dist.init_process_group(local_rank, rehearse_on_one_gpu=True)
+        else:
+            # the product path: the library owns the RCCL communicator and runs the partitioned step itself (no torch in the process)
+            ctx = dist.Distributed.from_environment(local_rank, self_loop=self_loop)
         arch = ctx.arch
         if args.global_size:
             G = args.global_size
@@ -203,13 +209,18 @@ def main():
                                                    topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
         else:
             grid = dist.DistributedRectilinearGrid(ctx, size=(N * world, N, N), extent=(float(world), 1.0, 1.0))
-        model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"),
-                                                    **workload_physics(ocn, args.workload))
-        model.fuse_substep = os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"
-        step = lambda dt: dist.time_step(model, dt)          # noqa: E731
+        if rehearsal:
+            model = dist.DistributedNonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"),
+                                                        **workload_physics(ocn, args.workload))
+            model.fuse_substep = os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"
+            step = lambda dt: dist.time_step(model, dt)          # noqa: E731
+            dist.set_model(model, **dist.local_initial_state(model, initial_state))
+        else:
+            model = dist.LibraryDistributedModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"), **workload_physics(ocn, args.workload))
+            model.set_option("fuse_substep", int(os.environ.get("OCN_FUSE_SUBSTEP", "1") != "0"))
+            step = lambda dt: ocn.time_step(model, dt)            # noqa: E731
+            ocn.set_model(model, **dist.local_initial_state(model, initial_state))
         barrier = ctx.barrier
-        vals = dist.local_initial_state(model, initial_state)
-        dist.set_model(model, **vals)
     else:
         arch = ocn.GPU(local_rank)
         physics = {}
@@ -264,13 +275,18 @@ def main():
               file=sys.stderr)
     tend_ms, tend_n = model.profile_read()
     model.set_option("profile", 0)
-    div = dist.max_abs_divergence(model) if distributed else ocn.max_abs_divergence(model)
+    div = dist.max_abs_divergence(model) if (distributed and rehearsal) else ocn.max_abs_divergence(model)
+    fused_substep = (model.fuse_substep_active() if (distributed and rehearsal) else model.get_option("fuse_substep_active") == 1)
 
     if distributed:
         elapsed = ctx.allreduce_max(elapsed)
         ctx.barrier()
-        model.backend.close()
-        ctx.dist.destroy_process_group()
+        if rehearsal:
+            model.backend.close()
+            ctx.dist.destroy_process_group()
+        else:
+            model.close()
+            ctx.close()
     if rank != 0:
         return
     cells = float(N) ** 3 * world * (1.0 if args.workload == "ppp" else 0.5)
@@ -280,7 +296,6 @@ def main():
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
-    fused_substep = (model.fuse_substep_active() if distributed else model.get_option("fuse_substep_active") == 1)
     bytes_per_cell = TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * fused_substep
     cells_per_gpu = cells / world
     achieved = bytes_per_cell * cells_per_gpu / t_launch / 1e9 if tend_n else None
@@ -288,7 +303,7 @@ def main():
         "metric": "cell_updates_per_s", "value": value, "unit": "cell-updates/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if args.global_size else "weak",
         "vs_baseline": value / V100_PUBLISHED_CELL_UPDATES if world == 1 and N == 256 and args.workload == "ppp" and not distributed else None,
-        "dtype": "f64", "data": "synthetic; SELF-LOOP: one rank running the N > 1 code path with device copies instead of RCCL transfers" if (distributed and os.environ.get("OCN_SELF_LOOP") == "1" and world == 1)
+        "dtype": "f64", "data": "synthetic; SELF-LOOP: one rank running the N > 1 code path, its RCCL transfers going to itself" if (distributed and os.environ.get("OCN_SELF_LOOP") == "1" and world == 1)
         else "synthetic" if not (distributed and os.environ.get("OCN_REHEARSE_ON_ONE_GPU") == "1")
         else "synthetic; REHEARSAL on one card over gloo + host staging: not a measurement",
         "config": {"workload": (("BASELINE.json configs[3] grid: " if args.global_size == 512 else

@@ -914,40 +914,61 @@ class Distributed:
         return cls(h, rank, world, arch, self_loop, keepalive=(t, cbs, collectives))
 
 
+_BOOT_MAGIC = b"OCN-RCCL-ID-1"
+
+
 def _broadcast_bytes(payload, rank, world, timeout=120.0):
-    """rank 0 -> everyone, over TCP on MASTER_ADDR : MASTER_PORT + 1 (the launcher's own store sits on MASTER_PORT)"""
+    """rank 0 -> everyone, one shot over TCP on MASTER_ADDR, first free port of MASTER_PORT + 1 .. + 16 (the launcher's own store sits
+    on MASTER_PORT); a magic prefix tells our listener from a stranger's"""
     import socket
     import time
-    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1
+    addr, base = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
+    ports = [base + 1 + k for k in range(16)]
     if rank == 0:
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind((addr, port))
+        srv = None
+        for port in ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind((addr, port))
+                break
+            except OSError:
+                srv.close()
+                srv = None
+        if srv is None:
+            raise _lib.OcnError(f"no free port in {ports[0]}..{ports[-1]} on {addr} for the unique-id exchange")
         srv.listen(world)
         srv.settimeout(timeout)
         for _ in range(world - 1):
             conn, _peer = srv.accept()
-            conn.sendall(payload)
+            conn.sendall(_BOOT_MAGIC + payload)
             conn.close()
         srv.close()
         return payload
     deadline = time.time() + timeout
-    while True:
-        try:
-            c = socket.create_connection((addr, port), timeout=5.0)
-            break
-        except OSError:
-            if time.time() > deadline:
-                raise _lib.OcnError(f"rank {rank}: no unique id from rank 0 at {addr}:{port}")
-            time.sleep(0.05)
-    data = b""
-    while len(data) < 128:
-        chunk = c.recv(128 - len(data))
-        if not chunk:
-            raise _lib.OcnError("unique-id exchange: connection closed early")
-        data += chunk
-    c.close()
-    return data
+    want = len(_BOOT_MAGIC) + 128
+    while time.time() < deadline:
+        for port in ports:
+            try:
+                c = socket.create_connection((addr, port), timeout=2.0)
+            except OSError:
+                continue
+            try:
+                c.settimeout(5.0)
+                data = b""
+                while len(data) < want:
+                    chunk = c.recv(want - len(data))
+                    if not chunk:
+                        break
+                    data += chunk
+            except OSError:
+                data = b""
+            finally:
+                c.close()
+            if len(data) == want and data.startswith(_BOOT_MAGIC):
+                return data[len(_BOOT_MAGIC):]
+        time.sleep(0.05)
+    raise _lib.OcnError(f"rank {rank}: no unique id from rank 0 at {addr}:{ports[0]}..{ports[-1]}")
 
 
 from .models import NonhydrostaticModel as _NonhydrostaticModel   # noqa: E402

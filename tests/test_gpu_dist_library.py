@@ -213,3 +213,46 @@ def test_library_transposing_solver_matches(ocn, arch):
     for r, (out, div, t) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, 9, (36, 12, 10))
+
+
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("R,zkind,options", [(2, "periodic", ""), (2, "periodic", "early_exchange=0 async_halos=1"), (2, "periodic", "thin_halos=0"),
+                                             (4, "periodic", ""), (2, "stretched", ""), (4, "stretched", "")])
+def test_library_rccl_separate_processes(ocn, arch, tmp_path, R, zkind, options):
+    """REAL ranks on REAL GPUs over RCCL: needs R cards, skipped on the one-GPU box (first executed on a multi-GPU lease). R = 2 is
+    the same-peer case (both neighbours are one rank: two sends and two receives per pair in one group)"""
+    if _gpu_count() < R:
+        pytest.skip(f"needs {R} GPUs; this box has {_gpu_count()}")
+    import os
+    import socket
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    size = (64 * R, 16, 12)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={R}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "gpu_lib_dist_worker.py"), str(tmp_path), "3", zkind] + [str(n) for n in size] + options.split()
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    z, topo = _z_and_topology(ocn, zkind, size[2])
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+    ocn.set_model(model, **{n: analytic(n, *grid.nodes(f.loc)) for n, f in model.fields().items()})
+    dt = 0.1 * (2.0 / size[0]) / 0.6
+    for _ in range(3):
+        ocn.time_step(model, dt)
+    ref = {n: f.parent() for n, f in model.fields().items()}
+    ref["p"] = model.pressures.pNHS.parent()
+    nxl = size[0] // R
+    for r in range(R):
+        d = np.load(os.path.join(tmp_path, f"rank{r}.npz"))
+        assert float(d["div"]) < 5e-8 and float(d["time"]) == model.clock.time
+        _compare({n: d[n] for n in ref}, ref, r, nxl, size)
