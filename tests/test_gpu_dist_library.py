@@ -227,17 +227,30 @@ def test_library_rccl_separate_processes(ocn, arch, tmp_path, R, zkind, options)
     the same-peer case (both neighbours are one rank: two sends and two receives per pair in one group)"""
     if _gpu_count() < R:
         pytest.skip(f"needs {R} GPUs; this box has {_gpu_count()}")
+    _separate_processes(ocn, arch, tmp_path, R, zkind, options, staged=False)
+
+
+@pytest.mark.parametrize("R,zkind,options", [(2, "periodic", ""), (4, "periodic", ""), (2, "periodic", "dist_substructured=0"), (2, "stretched", ""),
+                                             (2, "periodic", "early_exchange=0 async_halos=1")])
+def test_library_separate_processes_on_one_card(ocn, arch, tmp_path, R, zkind, options):
+    """the in-library partitioned step as REAL separate processes under torch.distributed.run -- rank-local coordinates and the
+    communicator's rank / size from the environment -- sharing this box's one card, their collectives staged through the host over
+    gloo (tests/host_staged.py through ocn_dist_create_transport). Fields after 3 RK3 steps against the single-GPU model."""
+    _separate_processes(ocn, arch, tmp_path, R, zkind, options, staged=True)
+
+
+def _separate_processes(ocn, arch, tmp_path, R, zkind, options, staged):
     import os
     import socket
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    size = (64 * R, 16, 12)
+    size = (64 * R, 16, 12) if not staged else (16 * R, 16, 12)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OCN_TEST_HOST_STAGED="1" if staged else "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={R}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(here, "gpu_lib_dist_worker.py"), str(tmp_path), "3", zkind] + [str(n) for n in size] + options.split()
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
