@@ -258,7 +258,7 @@ struct DistModel {
     ocn_dist_poisson_t solver = nullptr;
     double *ws = nullptr, *es = nullptr, *wr = nullptr, *er = nullptr;     // halo buffers: Hx columns of every prognostic field per side
     size_t slab_total = 0;
-    double *p2 = nullptr;                                                   // receives p / dt from the correction passes, swapped in
+    double *p2 = nullptr;                                                   // the solver's raw solution (p dt); the correction passes write p / dt into the model's pressure
     double *buf_a = nullptr, *buf_b = nullptr;                              // the solver's payload / gathered or send / recv buffers
     size_t payload = 0, nbuf = 0;
     bool halos_in_flight = false;
@@ -314,14 +314,14 @@ static int dist_solve_for_pressure(ocn_model_s *m) {
             if ((rc = ocn_dist_all_gather(dm->dist, dm->buf_a, dm->buf_b, 2 * dm->payload))) return rc;
         } else
             HIP_TRY(hipMemcpyAsync(dm->buf_b, dm->buf_a, 2 * dm->payload * sizeof(double), hipMemcpyDeviceToDevice, g_stream));
-        return ocn_dist_poisson_backward_local(s, m->p);
+        return ocn_dist_poisson_backward_local(s, dm->p2);
     }
     const size_t per_rank = 2 * dm->nbuf / (size_t)dm->dist->world;
     if ((rc = ocn_dist_poisson_forward_yz(s))) return rc;
     if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_y_to_x!
     if ((rc = ocn_dist_poisson_solve_x(s))) return rc;
     if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_x_to_y!
-    return ocn_dist_poisson_backward_yz(s, m->p);
+    return ocn_dist_poisson_backward_yz(s, dm->p2);
 }
 
 // compute_pressure_correction! (pressure_correction.jl:8-20). Of the x halos only ONE column is read before update_state! fills
@@ -333,12 +333,13 @@ static int dist_compute_pressure_correction(ocn_model_s *m) {
     int rc = dist_fill_halo_regions(m, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr, thin ? 1 : 3, thin ? 1 : 0);
     if (rc) return rc;
     if ((rc = dist_solve_for_pressure(m))) return rc;
-    double *pp[1] = {m->p};
+    double *pp[1] = {dm->p2};
     const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
     return dist_fill_halo_regions(m, pp, pl, 1, true, nullptr, 1, thin ? 1 : 0);
 }
 
-// make_pressure_correction! (pressure_correction.jl:40-53); the correction passes write p / dt into the second pressure array.
+// make_pressure_correction! (pressure_correction.jl:40-53); the correction passes read the solver's raw solution (p dt, second array) and
+// write p / dt into the model's pressure field -- no divide pass, no pointer swap (ocn_model_field pointers stay valid).
 // start_halo_exchange (tendencies are evaluated next): correct the two Hx-wide boundary strips first, fill their y / z halos, pack
 // them and START the x exchange of the coming update_state!; the interior correction runs while the halos are in flight.
 static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_halo_exchange) {
@@ -346,11 +347,9 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     const DGrid &g = m->grid->d;
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     int rc;
-    auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], m->p, range, dm->p2, dtp); };
+    auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], dm->p2, range, m->p, dtp); };
     if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx)) {
-        if ((rc = pc(nullptr))) return rc;
-        std::swap(m->p, dm->p2);
-        return OCN_OK;
+        return pc(nullptr);
     }
     const int west[6] = {1, g.Hx, 1, g.Ny, 1, g.Nz}, east[6] = {g.Nx - g.Hx + 1, g.Nx, 1, g.Ny, 1, g.Nz};
     const int mid[6] = {g.Hx + 1, g.Nx - g.Hx, 1, g.Ny, 1, g.Nz};
@@ -359,9 +358,7 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->ws, dm->es, true))) return rc;
     if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, dm->slab_total))) return rc;
     dm->halos_in_flight = true;
-    if ((rc = pc(mid))) return rc;
-    std::swap(m->p, dm->p2);
-    return OCN_OK;
+    return pc(mid);
 }
 
 static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubstep *sub, const int *amd_range);

@@ -168,10 +168,10 @@ def _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind):
             scale = np.abs(glob[name]).max()
             err = np.abs(a[3:-3, 3:-3, 3:-3] - ref).max() / scale
             assert err <= 1e-12, (r, name, err, int(np.isnan(a).sum()), float(np.abs(a).max()), float(scale))
-            if name != "p":   # x halos hold exact copies of the neighbours' interiors (bit-exact exchange)
-                lo = 3 + r * nxl - 3
-                west = glob[name][lo:lo + 3, 3:-3, 3:-3] if r > 0 else glob[name][size[0]:size[0] + 3, 3:-3, 3:-3]
-                assert rel_err(a[:3, 3:-3, 3:-3], west) <= 1e-12
+            if name != "p":   # x halos are COPIES of the neighbours' interior columns: bit-exact (==), like the reference's rank-id test
+                west_rank, east_rank = results[(r - 1) % R][0][name], results[(r + 1) % R][0][name]
+                assert np.array_equal(a[:3, 3:-3, 3:-3], west_rank[-6:-3, 3:-3, 3:-3]), (r, name, "west halo")
+                assert np.array_equal(a[-3:, 3:-3, 3:-3], east_rank[3:6, 3:-3, 3:-3]), (r, name, "east halo")
 
 
 def _in_virtual_ranks(arch, R, fn):

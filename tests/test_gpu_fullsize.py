@@ -91,3 +91,153 @@ def test_fused_substep_equals_separate_kernels_at_256(ocn, arch, big):
     model.set_option("fuse_substep", 1)
     for n in results[0]:
         assert np.array_equal(results[0][n], results[1][n]), n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: 256 x 256 x 128 (Periodic, Periodic, Bounded), tanh-stretched z, Fourier-tridiagonal solver
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_ppb(ocn, arch):
+    from helpers import tanh_faces
+    grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
+                               topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+    ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=1234))
+    yield grid, model
+    model.close()
+
+
+def test_tendency_kernels_agree_bitwise_at_config2(ocn, big_ppb):
+    """per-field kernels (the reference's launch structure, bit-identical to the oracle at small sizes), the all-fields kernel and
+    the role kernel on the stretched Bounded-z grid: the wall fallbacks (WENO{2}, UpwindBiased{1}, Centered{1} within 3 cells of
+    the bottom and the top) and the exclude_periphery mask of Gw ride in every plane of the z-march"""
+    grid, model = big_ppb
+    out = []
+    for impl in (0, 1, 2):
+        model.set_option("tendency_impl", impl)
+        for n in model.fields():
+            model.tendency(n).set_parent(np.zeros(model.tendency(n).shape))
+        ocn.update_state(model, True)
+        out.append([model.tendency(n).parent() for n in model.fields()])
+    for a, b, c, n in zip(out[0], out[1], out[2], model.fields()):
+        assert np.array_equal(a, b) and np.array_equal(a, c), n        # whole parent arrays: nothing outside the interior is written
+        assert np.isfinite(a).all() and np.abs(a).max() > 0
+    gw = out[2][2]
+    assert not gw[3:-3, 3:-3, 3].any() and not gw[3:-3, 3:-3, -4].any()     # w tendencies on the two walls stay zero
+    model.set_option("tendency_impl", 2)
+
+
+def test_projection_and_conservation_at_config2(ocn, big_ppb):
+    """test/test_time_stepping.jl:124-160,432-460 (max|div u| < 5e-8 on a stretched grid) and :165-199 (tracer conservation) at the
+    configuration's full size; w stays exactly zero on the walls"""
+    grid, model = big_ppb
+    dt = 0.1 / N / 0.6
+    from helpers import tanh_faces
+    dz = np.diff(tanh_faces(N // 2))
+    interior = (slice(3, -3),) * 3
+
+    def volume_mean(a):
+        return float((a[interior] * dz[None, None, :]).sum() / (dz.sum() * N * N))
+    mean0 = {n: volume_mean(model.fields()[n].parent()) for n in ("T", "S")}
+    for _ in range(3):
+        ocn.time_step(model, dt)
+    assert ocn.max_abs_divergence(model) < 5e-8
+    for n in ("T", "S"):
+        assert abs(volume_mean(model.fields()[n].parent()) - mean0[n]) < 1e-13 * max(1.0, abs(mean0[n])), n
+    w = model.fields()["w"].parent()
+    assert not w[3:-3, 3:-3, 3].any() and not w[3:-3, 3:-3, 3 + N // 2].any()
+
+
+def test_fused_substep_equals_separate_kernels_at_config2(ocn, big_ppb):
+    grid, model = big_ppb
+    dt = 0.1 / N / 0.6
+    start = {n: f.parent() for n, f in model.fields().items()}
+    results = []
+    for fuse in (1, 0):
+        for n, f in model.fields().items():
+            f.set_parent(start[n])
+        ocn.update_state(model, True)
+        model.set_option("fuse_substep", fuse)
+        for _ in range(2):
+            ocn.time_step(model, dt)
+        results.append({n: f.parent().copy() for n, f in model.fields().items()})
+    model.set_option("fuse_substep", 1)
+    for n in results[0]:
+        assert np.array_equal(results[0][n], results[1][n]), n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[3] / configs[4]: the LOCAL shape of one of 8 x-slabs, run through the partitioned code path by a one-rank
+# RCCL communicator that is its own neighbour (ocn_dist_set_self_loop) -- against the single-GPU model on the same periodic slab
+# ---------------------------------------------------------------------------------------------------------------------
+def _slab_pair(ocn, arch, size, zfaces, physics):
+    """x spans (0, 1) on the slab, so that the analytic state is periodic over it (cells are anisotropic; a state that jumps at the
+    slab's ends would make the comparison a test of the WENO weights' conditioning, not of the code path). For the same reason S is
+    used WITHOUT its offset of 35: the reference's smoothness indicators (weno_interpolants.jl:204-216) are sums of products of the
+    values themselves, not of differences, so for S = 35 + O(1) on a 512-point direction beta ~ 1e-4 is the difference of terms
+    ~ 1e3 and the weights amplify a 1e-14 perturbation of the advecting velocity (two correct pressure solvers differ by that) to
+    5e-11 in S after one step and 7e-10 after three (measured, tools/diag_slab.py: 64 x 512 x 512; 7e-13 / 1e-11 at 64 x 128 x 128;
+    2e-15 with the offset removed). A property of the reference's formulation, the same in the oracle."""
+    import ctypes as C
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    topo = (ocn.Periodic, ocn.Periodic, ocn.Periodic if zfaces is None else ocn.Bounded)
+    z = (0.0, 1.0) if zfaces is None else zfaces
+    uid = C.create_string_buffer(128)
+    _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+    ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
+    outs = []
+    dt = 0.1 * (1.0 / size[1]) / 0.6
+    for partitioned in (True, False):
+        if partitioned:
+            grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo)
+            model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), **physics(ocn))
+            nodes = {n: grid.local.nodes(f.loc) for n, f in model.fields().items()}
+        else:
+            grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo)
+            model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), **physics(ocn))
+            nodes = {n: grid.nodes(f.loc) for n, f in model.fields().items()}
+        vals = smooth_state(nodes, seed=99)
+        vals["S"] = vals["S"] - 35.0          # see the docstring: conditioning of the WENO weights of a tracer with a large offset
+        ocn.set_model(model, **vals)
+        for _ in range(2):
+            ocn.time_step(model, dt)
+        assert ocn.max_abs_divergence(model) < 5e-8
+        out = {n: f.parent() for n, f in model.fields().items()}
+        out["p"] = model.pressures.pNHS.parent()
+        outs.append(out)
+        model.close()
+    ctx.close()
+    # error model of the pressure: two exact-arithmetic-equivalent solvers (substructured / transposed x solve vs the single-GPU FFT
+    # or Fourier-tridiagonal solve) return solutions that differ by round-off times the condition number of the discrete Laplacian,
+    # lambda_max / lambda_min = (4/dx^2 + 4/dy^2 + 4/dz_min^2) / (2 pi / L)^2 -- 5e4 on the anisotropic 64 x 512 x 512 slab. The
+    # velocities, which only see grad p, and the tracers keep the 1e-12 bar.
+    dzmin = 1.0 / size[2] if zfaces is None else float(np.diff(np.asarray(zfaces)).min())
+    cond = (4.0 * size[0] ** 2 + 4.0 * size[1] ** 2 + 4.0 / dzmin ** 2) / (2 * np.pi) ** 2
+    for n in outs[0]:
+        a, b = outs[0][n][3:-3, 3:-3, 3:-3], outs[1][n][3:-3, 3:-3, 3:-3]
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err <= (1e-12 if n != "p" else max(1e-12, 4 * np.finfo(float).eps * cond)), (n, err, cond)
+        if n != "p":
+            assert np.array_equal(outs[0][n][:3, 3:-3, 3:-3], outs[0][n][-6:-3, 3:-3, 3:-3]), n     # exchanged x halos: exact copies
+
+
+def test_config3_local_slab_through_the_partitioned_path(ocn, arch):
+    """512^3 over Partition(8): the local 64 x 512 x 512 slab (thin slab: no interior / buffer split, substructured x solve)"""
+    _slab_pair(ocn, arch, (64, 512, 512), None, lambda ocn: {})
+
+
+def test_config4_local_slab_through_the_partitioned_path(ocn, arch):
+    """1024 x 1024 x 256 over Partition(8) with the ocean_wind_mixing_and_convection physics: the local 128 x 1024 x 256 slab
+    (stretched Bounded z, transposing Fourier-tridiagonal solver, AMD closure evaluated in the x-halo columns, linear seawater
+    buoyancy, wind-stress / heat-flux / bottom-gradient / evaporation conditions)"""
+    from helpers import tanh_faces
+
+    def physics(ocn):
+        F = ocn.FieldBoundaryConditions
+        return dict(closure=ocn.AnisotropicMinimumDissipation(),
+                    buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
+                    coriolis=ocn.FPlane(f=1e-4),
+                    boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-4)),
+                                         "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
+                                         "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-1e-3 / 3600.0), field_dependencies="S"))})
+    _slab_pair(ocn, arch, (128, 1024, 256), tanh_faces(256), physics)

@@ -162,7 +162,7 @@ def test_poisson_solvers_all_topologies(ocn, oracle, arch, topology, kind):
         p_cpu = g_cpu.zeros(oracle.LOC["c"])
         s_cpu.solve(p_cpu)
         got = phi.parent()[3:-3, 3:-3, 3:-3]
-        assert rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-11, (size, rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]))
+        assert rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-12, (size, rel_err(got, p_cpu[3:-3, 3:-3, 3:-3]))
         solver.close()
 
 
