@@ -350,6 +350,9 @@ int ocn_debug_rcp_check(int variant, int exponent, unsigned long long *mismatche
  * nsamples pseudo-random significands with exponents exp_lo..exp_hi; returns the number of differing results */
 int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, int exp_hi, unsigned long long seed,
                           unsigned long long *mismatches);
+/* where the cosine-transform path's permute_indices! (backward = 0) / unpermute_indices! (backward = 1) send element i of a line of
+ * length N: destination[i - 1], 1-based -- the tables of Solvers/index_permutations.jl:5-35 (host array, synchronous) */
+int ocn_debug_permute_indices(int N, int backward, int *destination);
 
 /* ---------------------------------------------------------------- distributed: communicator + partitioned model -- */
 /* `Distributed(GPU(); partition = Partition(R))` (DistributedComputations/distributed_architectures.jl:166-302): one process per

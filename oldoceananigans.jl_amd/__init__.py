@@ -4,14 +4,15 @@ Host-side mirror of the reference's Architecture / Grid / Field / launch! surfac
 libocn_mi355x.so (include/ocn_mi355x.h). Import as `import oldoceananigans_jl_amd as ocn`."""
 from . import _lib
 from ._lib import OcnError, build
-from .advection import WENO
+from .advection import (Centered, FluxFormAdvection, UpwindBiased, WENO, adapt_advection_order, inflate_halo_size,
+                        required_halo_size_x, required_halo_size_y, required_halo_size_z)
 from .architectures import GPU, architecture, own_stream, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, LinearFieldFlux, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
 from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
-from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid
+from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid, with_halo
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
 from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
                       solve_for_pressure)

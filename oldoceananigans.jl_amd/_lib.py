@@ -152,6 +152,7 @@ SYMBOLS = {
     "ocn_model_profile_read": (C.c_int, [_vp, _dp, _ip]),
     "ocn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "ocn_debug_rcp_check": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
+    "ocn_debug_permute_indices": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
 }
 
 

@@ -186,9 +186,15 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
         if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(topo[d] == OCN_CONNECTED && d == 0))
             return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) FullyConnected "
                                      "are accelerated", topo[d], d);
-        // WENO(order=5) needs a halo of 3 (nonhydrostatic_model.jl:184, inflate_grid_halo_size) and N >= 3 so that
-        // adapt_advection_order (Advection/adapt_advection_order.jl:90-96) keeps the scheme
-        if (H[d] < 3) return fail(OCN_EINVAL, "halo %d < 3 in dimension %d: WENO(order=5) requires halo >= 3", H[d], d);
+        // adapt_advection_order (Advection/adapt_advection_order.jl:90-96): WENO(order=5) stays where N >= 3 and becomes
+        // WENO(order = 2N-1) = WENO{2} where N = 2; the halo must hold the adapted scheme's buffer (nonhydrostatic_model.jl:184,
+        // inflate_grid_halo_size). N = 1 in a non-Flat direction is refused: the reference keeps Centered(order=4) for the
+        // advecting velocities of the OTHER directions' fluxes, which reads two cells into a one-cell halo there.
+        if (N[d] < 2) return fail(OCN_ENOTSUP, "size 1 in non-Flat dimension %d: make the direction Flat (the reference's adapted "
+                                               "UpwindBiased(order=1) scheme reads beyond its one-cell halo)", d);
+        const int B = N[d] >= 3 ? 3 : N[d];
+        if (H[d] < B) return fail(OCN_EINVAL, "halo %d < %d in dimension %d: %s requires halo >= %d", H[d], B, d,
+                                  B == 3 ? "WENO(order=5)" : "WENO(order=3)", B);
         if (N[d] < H[d]) return fail(OCN_EINVAL, "size %d < halo %d in dimension %d", N[d], H[d], d);
         if (!(L[d] > 0)) return fail(OCN_EINVAL, "extent must be positive");
     }
@@ -205,6 +211,9 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
     D.tx = topo[0]; D.ty = topo[1]; D.tz = topo[2];
     D.dx = dx; D.dy = dy; D.az = dx * dy;
     D.rdx = 1.0 / dx; D.rdy = 1.0 / dy;
+    D.Bx = (topo[0] == OCN_FLAT || N[0] >= 3) ? 3 : N[0];
+    D.By = (topo[1] == OCN_FLAT || N[1] >= 3) ? 3 : N[1];
+    D.Bz = (topo[2] == OCN_FLAT || N[2] >= 3) ? 3 : N[2];
     for (int d = 0; d < 3; ++d) g->L[d] = L[d];
     const int n = N[2] + 2 * H[2] + 1;
     g->h_dzc.resize(n); g->h_dzf.resize(n);
@@ -293,6 +302,25 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
     parent_size(g, loc, P);
     const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
     FView view = make_view(g, nullptr, loc);
+    // (Periodic | FullyConnected, Periodic, Bounded): bounded z fill + periodic y and x fills as one launch
+    if (g_fused_halo && (T[0] == OCN_PERIODIC || T[0] == OCN_CONNECTED) && T[1] == OCN_PERIODIC && T[2] == OCN_BOUNDED &&
+        (T[0] == OCN_CONNECTED || N[0] >= H[0]) && N[1] >= H[1]) {
+        const bool face = loc[2] == OCN_FACE, zfill = !face || fill_open;
+        BcSides bc;
+        for (int f = 0; f < n; ++f)
+            for (int sd = 0; sd < 2; ++sd) {
+                bc.kind[f][sd] = bcs ? bcs[f][4 + sd].kind : OCN_BC_DEFAULT;
+                bc.value[f][sd] = bcs ? bcs[f][4 + sd].value : 0.0;
+            }
+        bc.dlo = grid->h_dzf[g.Hz];
+        bc.dhi = grid->h_dzf[g.Nz + g.Hz];
+        const int H0 = T[0] == OCN_CONNECTED ? 0 : H[0], N0 = T[0] == OCN_CONNECTED ? P[0] : N[0];
+        const long total = (zfill ? (long)P[0] * P[1] * 2 : 0) + ((long)P[0] * (2 * H[1]) + (long)(2 * H0) * N[1]) * (P[2] - (zfill ? 2 : 0));
+        hipLaunchKernelGGL(fill_periodic_xy_bounded_z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, fl, bc, P[0], P[1],
+                           P[2], N0, N[1], N[2], H0, H[1], H[2], face, zfill, T[0] == OCN_CONNECTED ? H[0] : 0);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     // order: boundary_condition_ordering.jl:17-46 -- non-periodic first, then periodic; insertion sort with an
     // always-true `lt` reverses same-class entries => z, y, x inside each class.
     for (int d = 2; d >= 0; --d) {
@@ -2251,6 +2279,15 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
     a.any_flux = m->any_flux_bc;
+    a.nlin = 0;
+    for (int f = 0; f < m->nf; ++f)
+        for (int sd = 0; sd < 6; ++sd)
+            if (m->lin[f][sd].on) {
+                if (a.nlin == OCN_EPILOGUE_MAX_LIN) return fail(OCN_ESTATE, "more than %d field-dependent Flux conditions in the fused epilogue", OCN_EPILOGUE_MAX_LIN);
+                a.lin[a.nlin].f = f; a.lin[a.nlin].side = sd; a.lin[a.nlin].dep = m->lin[f][sd].dep;
+                a.lin[a.nlin].a = m->lin[f][sd].a; a.lin[a.nlin].b = m->lin[f][sd].b;
+                ++a.nlin;
+            }
     const int T[3] = {g.tx, g.ty, g.tz};
     for (int f = 0; f < OCN_MAX_FIELDS; ++f)
         for (int sd = 0; sd < 6; ++sd) {
@@ -2264,12 +2301,22 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     return OCN_OK;
 }
 
+// the one-pass epilogue runs whenever something follows the advective part: physics terms, valued or field-dependent Flux conditions
+static int count_linear_flux(const ocn_model_s *m) {
+    int n = 0;
+    for (int f = 0; f < m->nf; ++f)
+        for (int sd = 0; sd < 6; ++sd) n += m->lin[f][sd].on ? 1 : 0;
+    return n;
+}
+static bool epilogue_runs(const ocn_model_s *m) {
+    return m->fused_epilogue && (has_physics(m) || m->any_flux_bc || m->any_linear_flux) && count_linear_flux(m) <= OCN_EPILOGUE_MAX_LIN;
+}
 static bool can_fuse_substep(const ocn_model_s *m) {
     // without extra physics the substep rides in the fused advection kernel; with Coriolis / buoyancy / closure terms it rides in
     // the epilogue pass that completes the tendencies (any advection path); a valued Flux condition is added after both
-    if (!m->fuse_substep || !m->swap_tendencies || m->any_linear_flux) return false;   // linear Flux terms are added after the pass
-    if ((has_physics(m) || m->any_flux_bc) && m->fused_epilogue) return true;       // the epilogue pass also applies the Flux conditions
-    return !has_physics(m) && !m->any_flux_bc && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
+    if (!m->fuse_substep || !m->swap_tendencies) return false;
+    if (epilogue_runs(m)) return true;                               // the epilogue pass also applies the Flux conditions
+    return !has_physics(m) && !m->any_flux_bc && !m->any_linear_flux && fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl);
 }
 
 extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) {
@@ -2326,12 +2373,12 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
             ev = &m->events[m->events_used++];
             HIP_TRY(hipEventRecord(ev->first, g_stream));
         }
-        const bool physics = has_physics(m) || (m->any_flux_bc && m->fused_epilogue);
+        const bool physics = has_physics(m) || epilogue_runs(m);
         rc = compute_tendencies(g, m->U[0], m->U[1], m->U[2], m->U + 3, m->ntr, m->Gn[0], m->Gn[1], m->Gn[2], m->Gn + 3, nullptr,
                                 m->tendency_impl, physics ? nullptr : sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
         if (!rc && physics) {
-            if (m->fused_epilogue) rc = tendency_epilogue(m, sub);
+            if (epilogue_runs(m)) rc = tendency_epilogue(m, sub);
             else {
                 if (sub) return fail(OCN_ESTATE, "fused substep needs the fused epilogue");
                 if (!rc && m->has_coriolis) rc = add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1], nullptr);
@@ -2345,9 +2392,9 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
             }
         }
         // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) -- inside the epilogue pass when that runs
-        if (m->any_flux_bc && !(physics && m->fused_epilogue))
+        if (m->any_flux_bc && !epilogue_runs(m))
             for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
-        if (m->any_linear_flux)
+        if (m->any_linear_flux && !epilogue_runs(m))
             for (int f = 0; f < m->nf && !rc; ++f)
                 for (int sd = 0; sd < 6 && !rc; ++sd)
                     if (m->lin[f][sd].on)
@@ -2757,6 +2804,28 @@ extern "C" int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, in
     HIP_TRY(hipMemcpyAsync(mismatches, d, 8, hipMemcpyDeviceToHost, g_stream));
     HIP_TRY(hipStreamSynchronize(g_stream));
     HIP_TRY(hipFree(d));
+    return OCN_OK;
+}
+
+// where permute_indices! (line_gather_kernel, mode 1) / unpermute_indices! (line_scatter_kernel, mode 2) of the cosine-transform path
+// send element i of a line of length N: destination[i - 1], 1-based like Solvers/index_permutations.jl:5-35
+extern "C" int ocn_debug_permute_indices(int N, int backward, int *destination) {
+    NEED_INIT();
+    if (N < 1 || N > (1 << 20) || !destination) return fail(OCN_EINVAL, "invalid argument");
+    std::vector<double2> h((size_t)N);
+    for (int i = 0; i < N; ++i) h[i] = make_double2((double)(i + 1), 0.0);
+    double2 *a, *b;
+    HIP_TRY(dev_alloc((void **)&a, sizeof(double2) * (size_t)N));
+    HIP_TRY(dev_alloc((void **)&b, sizeof(double2) * (size_t)N));
+    HIP_TRY(hipMemcpyAsync(a, h.data(), sizeof(double2) * (size_t)N, hipMemcpyHostToDevice, g_stream));
+    const dim3 blk(64, 4, 1), grd((N + 63) / 64, 1, 1);
+    if (!backward) hipLaunchKernelGGL(line_gather_kernel, grd, blk, 0, g_stream, (const double2 *)a, b, N, 1, 1, 0, 1);
+    else hipLaunchKernelGGL(line_scatter_kernel, grd, blk, 0, g_stream, (const double2 *)a, b, N, 1, 1, 0, 2);
+    HIP_TRY(hipMemcpyAsync(h.data(), b, sizeof(double2) * (size_t)N, hipMemcpyDeviceToHost, g_stream));
+    HIP_TRY(hipStreamSynchronize(g_stream));
+    HIP_TRY(hipFree(a));
+    HIP_TRY(hipFree(b));
+    for (int m = 0; m < N; ++m) destination[(int)h[m].x - 1] = m + 1;      // position m holds source h[m].x
     return OCN_OK;
 }
 

@@ -25,6 +25,9 @@ struct DGrid {
     const double *vinv_c;      // 1 / ((Δx Δy) Δzᶜ)   = V⁻¹ᶜᶜᶜ = V⁻¹ᶠᶜᶜ = V⁻¹ᶜᶠᶜ
     const double *vinv_f;      // 1 / ((Δx Δy) Δzᶠ)   = V⁻¹ᶜᶜᶠ
     const double *rdzf;        // 1 / Δzᶠ
+    // adapt_advection_order (Advection/adapt_advection_order.jl:18-96): buffer of the scheme a direction ends up with --
+    // 3: WENO{3} (order 5), 2: WENO{2} = WENO(order = 2N-1) when N = 2, 1: UpwindBiased{1} (unused: N = 1 is refused)
+    int Bx, By, Bz;
 };
 
 // A haloed field addressed with the reference's 1-based (i, j, k): p[off + i + s1*j + s2*k]
@@ -169,5 +172,17 @@ __device__ __forceinline__ double biased_interp(double s0, double s1, double s2,
                                                 bool left, bool bounded, int i, bool center, int N) {
     if (!bounded || outside_biased_halo(i, center, N, 3)) return weno5_biased(s0, s1, s2, s3, s4, s5, left);
     if (outside_biased_halo(i, center, N, 2)) return weno3_biased(s1, s2, s3, s4, left);
+    return left ? 1.0 * s2 : 1.0 * s3;
+}
+
+// The same two functions for a direction whose scheme adapt_advection_order reduced to buffer B < 3 (a FluxFormAdvection,
+// flux_form_advection.jl:45-59: every flux along direction d is evaluated with scheme.d -- the biased reconstruction along d AND the
+// symmetric interpolation of the advecting transport along the other direction, upwind_biased_advective_fluxes.jl:23-93).
+// WENO{2}: advecting_velocity_scheme Centered(order = 2), buffer_scheme UpwindBiased{1} (weno_reconstruction.jl:81-93);
+// UpwindBiased{1}: Centered(order = 2), no buffer scheme (upwind_biased_reconstruction.jl:26-29).
+__device__ __forceinline__ double symmetric_interp_low(double q1, double q2) { return __builtin_fma(OCN_C2_1, q2, OCN_C2_2 * q1); }
+__device__ __forceinline__ double biased_interp_low(double s1, double s2, double s3, double s4, bool left, bool bounded, int i,
+                                                    bool center, int N, int B) {
+    if (B == 2 && (!bounded || outside_biased_halo(i, center, N, 2))) return weno3_biased(s1, s2, s3, s4, left);
     return left ? 1.0 * s2 : 1.0 * s3;
 }

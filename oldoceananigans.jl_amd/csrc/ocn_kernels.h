@@ -15,9 +15,10 @@ template <int AQ> __device__ __forceinline__ double area_q(const DGrid &g, const
     return a * f.at(i, j, k);
 }
 
-// symmetric interpolation of a transport along D; CEN: ᶜ variant (stencil of face idx+1)
+// symmetric interpolation of a transport along D; CEN: ᶜ variant (stencil of face idx+1). B: buffer of the scheme of the
+// direction the FLUX points along (adapt_advection_order; 3 unless that direction has fewer than 3 cells)
 template <int AQ, int D, bool CEN>
-__device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, int i, int j, int k) {
+__device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, int i, int j, int k, int B) {
     // interpolation along a Flat direction is the identity (flat_advective_fluxes.jl:35-50)
     if ((D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == OCN_FLAT) return area_q<AQ>(g, f, i, j, k);
     const int idx = D == 0 ? i : (D == 1 ? j : k);
@@ -26,8 +27,10 @@ __device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, 
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         int m = o - 2 + n;
+        if (B < 3 && (n == 0 || n == 3)) { q[n] = 0.0; continue; }      // Centered(order = 2): two points, one halo cell
         q[n] = D == 0 ? area_q<AQ>(g, f, i + m, j, k) : (D == 1 ? area_q<AQ>(g, f, i, j + m, k) : area_q<AQ>(g, f, i, j, k + m));
     }
+    if (B < 3) return symmetric_interp_low(q[1], q[2]);
     const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
     return symmetric_interp(q[0], q[1], q[2], q[3], bounded, idx, CEN, N);
@@ -39,9 +42,15 @@ __device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, b
     const int o = CEN ? 1 : 0;
     const long st = c.stride<D>();
     const double *p = c.p + c.lin(i, j, k) + (o - 3) * st;
-    double s0 = p[0], s1 = p[st], s2 = p[2 * st], s3 = p[3 * st], s4 = p[4 * st], s5 = p[5 * st];
     const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
+    const int B = D == 0 ? g.Bx : (D == 1 ? g.By : g.Bz);
+    if (B < 3) {                                                         // reduced scheme: the halo may be only B cells deep
+        const double s2 = p[2 * st], s3 = p[3 * st];
+        const double s1 = B == 2 ? p[st] : 0.0, s4 = B == 2 ? p[4 * st] : 0.0;
+        return biased_interp_low(s1, s2, s3, s4, left, bounded, idx, CEN, N, B);
+    }
+    double s0 = p[0], s1 = p[st], s2 = p[2 * st], s3 = p[3 * st], s4 = p[4 * st], s5 = p[5 * st];
     return biased_interp(s0, s1, s2, s3, s4, s5, left, bounded, idx, CEN, N);
 }
 
@@ -50,7 +59,7 @@ __device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, b
 template <int AQ, int DS, bool CS, int DB, bool CB>
 __device__ __forceinline__ double mom_flux(const DGrid &g, const FView &adv, const FView &psi, int i, int j, int k) {
     if ((DB == 0 ? g.tx : (DB == 1 ? g.ty : g.tz)) == OCN_FLAT) return 0.0;     // fluxes along a Flat direction vanish (:13-27)
-    double ut = sym_transport<AQ, DS, CS>(g, adv, i, j, k);
+    double ut = sym_transport<AQ, DS, CS>(g, adv, i, j, k, DB == 0 ? g.Bx : (DB == 1 ? g.By : g.Bz));
     double pr = biased_field<DB, CB>(g, psi, ut > 0, i, j, k);
     return ut * pr;
 }
@@ -444,6 +453,7 @@ __global__ void __launch_bounds__(256) fplane_coriolis_kernel(DGrid g, double f,
 // of the NEXT stage into the second set of prognostic arrays (the viscous stencils of neighbouring cells still read U). The
 // terms are the device functions of the stand-alone kernels above, evaluated in the reference's order => identical bits.
 // ---------------------------------------------------------------------------------------------------------------------
+#define OCN_EPILOGUE_MAX_LIN 12
 struct EpilogueArgs {
     int n, ntr;
     FView u, v, w, c[OCN_MAX_FIELDS], pHY;      // .p of the views = the live fields
@@ -460,6 +470,10 @@ struct EpilogueArgs {
     bool has_flux[OCN_MAX_FIELDS][6];
     double flux[OCN_MAX_FIELDS][6];
     int loc[OCN_MAX_FIELDS][3];
+    // linear field-dependent Flux conditions flux = a + b φ (linear_flux_bc_kernel), applied after the valued ones in (field, side)
+    // order like the stand-alone launches
+    int nlin;
+    struct Lin { int f, side, dep; double a, b; } lin[OCN_EPILOGUE_MAX_LIN];
 };
 
 __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
@@ -498,6 +512,21 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
             if (a.has_flux[f][2 * d] && idx[d] == 1) G += a.flux[f][2 * d] * area / vol;
             if (a.has_flux[f][2 * d + 1] && idx[d] == N[d]) G -= a.flux[f][2 * d + 1] * area / vol;
         }
+    }
+    for (int n = 0; n < a.nlin; ++n) {
+        if (a.lin[n].f != f) continue;
+        const int sd = a.lin[n].side, d = sd >> 1, dep = a.lin[n].dep;
+        const int idxd = d == 0 ? i : (d == 1 ? j : k), Nd = d == 0 ? g.Nx : (d == 1 ? g.Ny : g.Nz);
+        if (idxd != ((sd & 1) ? Nd : 1)) continue;
+        const double *dp = dep == 0 ? a.u.p : (dep == 1 ? a.v.p : (dep == 2 ? a.w.p : a.c[dep - 3].p));
+        const double dz = a.loc[f][2] == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
+        const double vol = (g.dx * g.dy) * dz;
+        const double area = d == 0 ? g.dy * dz : (d == 1 ? g.dx * dz : g.dx * g.dy);
+        const double phi = dp[q];                      // the dependency sits at the location of the field: same parent index
+        const double a_ = a.lin[n].a, b_ = a.lin[n].b;
+        const double flux = a_ == 0.0 ? b_ * phi : a_ + b_ * phi;
+        if (sd & 1) G -= flux * area / vol;
+        else        G += flux * area / vol;
     }
     a.Gn[f][q] = G;
     if (a.substep) {
@@ -608,6 +637,70 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides
             p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.value[f][1] : 0.0;
         }
     }
+}
+
+// (Periodic | FullyConnected, Periodic, Bounded) grids: the bounded z fill and the periodic y and x fills in ONE launch. The reference
+// fills z first (one halo cell below and above, over the interior (i, j) only), then y, then x over the whole extent of the other
+// dimensions (boundary_condition_ordering.jl:17-46), which leaves
+//   * the two z-boundary planes (Center fields: k = 0 and N+1; Face fields: the wall planes k = 1 and N+1) holding, at EVERY (i, j) of
+//     the parent, the boundary formula evaluated in the column at the wrapped interior (i, j);
+//   * every other plane -- the deeper z halos included, whose interior (i, j) nobody writes -- holding in its x / y halo cells the
+//     value of the wrapped interior (i, j) of the same plane.
+// Each such cell is written here directly from those sources: same bits, a third of the launches. `zfill`: the z fill runs (Center
+// fields always; Face fields when fill_open_bcs). An x-slab rank (x halos owned by the neighbours) passes H0 = 0, N0 = P0 and XC = Hx:
+// its XC outermost columns are left to the exchange -- in the z-boundary planes they only take part in the periodic y copy.
+__global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldList fl, BcSides bc, int P0, int P1, int P2, int N0, int N1,
+                                                                         int N2, int H0, int H1, int H2, bool face, bool zfill, int XC) {
+    const int klo = face ? H2 : H2 - 1, khi = N2 + H2;                       // 0-based parent planes of the z fill
+    const long nA = zfill ? (long)P0 * P1 * 2 : 0;
+    const int nplanes = P2 - (zfill ? 2 : 0);
+    const long rowsB = (long)P0 * (2 * H1), colsB = (long)(2 * H0) * N1, perplane = rowsB + colsB;
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nA) {
+        const int i = t % P0; const long r = t / P0; const int j = r % P1; const int side = r / P1;
+        const int si = i < H0 ? i + N0 : (i >= H0 + N0 ? i - N0 : i);
+        const int sj = j < H1 ? j + N1 : (j >= H1 + N1 ? j - N1 : j);
+        const long col = si + (long)P0 * sj, plane = (long)P0 * P1;
+        const long od = i + (long)P0 * j + plane * (side ? khi : klo);
+        if (i < XC || i >= P0 - XC) {                                       // a neighbour's column: periodic y copy only
+            if (sj == j) return;
+            const long os = col + plane * (side ? khi : klo);
+            for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
+            return;
+        }
+        for (int f = 0; f < fl.n; ++f) {
+            double *p = fl.p[f];
+            double val;
+            if (face) val = bc.kind[f][side] == OCN_BC_OPEN ? bc.value[f][side] : 0.0;
+            else {
+                const double c = p[col + plane * (side ? N2 + H2 - 1 : H2)];         // first / last interior cell of the column
+                const int kd = bc.kind[f][side];
+                val = c;
+                if (side == 0) {
+                    if (kd == OCN_BC_VALUE) val = c + ((c - bc.value[f][0]) / (bc.dlo / 2)) * (-bc.dlo);
+                    else if (kd == OCN_BC_GRADIENT) val = c + bc.value[f][0] * (-bc.dlo);
+                } else {
+                    if (kd == OCN_BC_VALUE) val = c + ((bc.value[f][1] - c) / (bc.dhi / 2)) * bc.dhi;
+                    else if (kd == OCN_BC_GRADIENT) val = c + bc.value[f][1] * bc.dhi;
+                }
+            }
+            p[od] = val;
+        }
+        return;
+    }
+    t -= nA;
+    if (t >= perplane * nplanes) return;
+    int kp = (int)(t / perplane);
+    if (zfill) { if (kp >= klo) ++kp; if (kp >= khi) ++kp; }
+    long q = t % perplane;
+    int i, j;
+    if (q < rowsB) { i = q % P0; const int hy = q / P0; j = hy < H1 ? hy : N1 + hy; }
+    else { q -= rowsB; const int hx = q % (2 * H0); i = hx < H0 ? hx : N0 + hx; j = H1 + (int)(q / (2 * H0)); }
+    const int si = i < H0 ? i + N0 : (i >= H0 + N0 ? i - N0 : i);
+    const int sj = j < H1 ? j + N1 : (j >= H1 + N1 ? j - N1 : j);
+    const long plane = (long)P0 * P1 * kp;
+    const long od = i + (long)P0 * j + plane, os = si + (long)P0 * sj + plane;
+    for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
 }
 
 // compute_x/y/z_bcs! (compute_flux_bcs.jl:57-163): G[1] += flux * A / V, G[N] -= flux * A / V over the interior extent of

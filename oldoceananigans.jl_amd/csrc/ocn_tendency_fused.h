@@ -329,6 +329,7 @@ static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
     const double bytes = 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy) * (g.Nz + 2.0 * g.Hz + 1.0);
     return g.tx != 1 && g.ty != 1 &&     // x, y Periodic or FullyConnected: identical x / y parent extents for all fields
            g.tx != 3 && g.ty != 3 && g.tz != 3 &&   // Flat directions take the per-field kernels
+           g.Bx == 3 && g.By == 3 && g.Bz == 3 &&   // so do directions with an adapted (reduced-order) scheme
            bytes < 4294967296.0;         // 32-bit byte offsets inside a parent array
 }
 

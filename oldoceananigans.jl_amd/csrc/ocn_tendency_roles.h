@@ -21,6 +21,9 @@
 #ifndef OCN_ROLE_WAVES
 #define OCN_ROLE_WAVES 6      // waves per SIMD the register allocation must allow (8-wave workgroups: 4 = two per CU, 6 = three)
 #endif
+#ifndef OCN_ROLE_TY
+#define OCN_ROLE_TY 7         // rows of a tile = row waves of a workgroup (+ 1 edge wave)
+#endif
 #ifndef OCN_ROLE_ABLATE
 #define OCN_ROLE_ABLATE 0     // timing experiments only (WRONG RESULTS when non-zero): 1 hot z-window load, 2 no previous-tendency load,
 #endif                        // 4 no stores, 8 x / y windows from registers, 16 no barrier, 32 idle edge wave
@@ -420,7 +423,7 @@ static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgro
 static inline int pick_role_kchunk(long tiles_roles, int nz) {
     int best = nz;
     double best_cost = -1;
-    const long slots = (long)(OCN_ROLE_WAVES / 2) * g_num_cus;
+    const long slots = (long)((4 * OCN_ROLE_WAVES) / (OCN_ROLE_TY + 1)) * g_num_cus;      // resident workgroups of the chip
     for (int kc = 8; kc <= 64; ++kc) {
         if (kc > nz && kc != 8) break;
         const int nchunk = (nz + kc - 1) / kc;
@@ -474,7 +477,7 @@ static int launch_roles_n(const DGrid &g, hipStream_t stream, const double *u, c
         a.r = Range6{1, g.Nx, 1, g.Ny, 1, g.Nz};
         a.wk0 = (g.tz != 0 && g.Nz > 1) ? 2 : 1;          // exclude_periphery: w tendencies start at k = 2 on Bounded z
     }
-    return launch_roles_t<NTR, 7>(g, stream, a, sub != nullptr);
+    return launch_roles_t<NTR, OCN_ROLE_TY>(g, stream, a, sub != nullptr);
 }
 
 static inline int launch_role_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,

@@ -96,8 +96,10 @@ class RectilinearGrid:
     2-tuple or an array/function of Nz+1 faces (Bounded only)."""
 
     def __init__(self, architecture, size, x=None, y=None, z=None, extent=None,
-                 topology=(Periodic, Periodic, Periodic), halo=(3, 3, 3)):
+                 topology=(Periodic, Periodic, Periodic), halo=None):
         self.architecture = architecture
+        # constructor_arguments(grid) (rectilinear_grid.jl:404-440): what with_halo / on_architecture rebuild the grid from
+        self._constructor_arguments = dict(size=size, x=x, y=y, z=z, extent=extent, topology=topology)
         self.topology = tuple(t if isinstance(t, type) else type(t) for t in topology)
         flat = [t is Flat for t in self.topology]
         # Flat directions (Grids/input_validation.jl): `size`, `halo` and `extent` list the non-Flat directions only (full
@@ -111,7 +113,12 @@ class RectilinearGrid:
             it = iter(values)
             return tuple(fill if f else next(it) for f in flat)
         self.Nx, self.Ny, self.Nz = (int(n) for n in expand(size, 1, "size"))
+        if halo is None:          # validate_halo(TX, TY, TZ, size, ::Nothing) (input_validation.jl:71-77): min(3, size)
+            halo = tuple(0 if f else min(3, n) for n, f in zip(self.size, flat))
         self.Hx, self.Hy, self.Hz = (int(h) for h in expand(halo, 0, "halo"))
+        for name, H, N in (("x", self.Hx, self.Nx), ("y", self.Hy, self.Ny)):      # input_validation.jl:86-92 (x and y only)
+            if not H <= N:
+                raise ValueError(f"halo={H} must be ≤ size={N} for coordinate {name}")
         if extent is not None:
             if any(c is not None for c in (x, y, z)):
                 raise ValueError("Cannot specify both extent and x, y, z keyword arguments!")
@@ -141,14 +148,22 @@ class RectilinearGrid:
                 z, self.Nz, self.Hz, True, "z")
             self.z_regular = False
             self._dz = 0.0
-        h = C.c_void_p()
-        dp = C.POINTER(C.c_double)
-        zc = None if self.z_regular else self.Δzᵃᵃᶜ.ctypes.data_as(dp)
-        zf = None if self.z_regular else self.Δzᵃᵃᶠ.ctypes.data_as(dp)
-        _lib.check(_lib.lib().ocn_grid_create(
-            C.byref(h), _lib.i3(self.size), _lib.i3(self.halo_size), _lib.i3([_topo_code(t) for t in self.topology]),
-            (C.c_double * 3)(self.Lx, self.Ly, self.Lz), self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ, self._dz, zc, zf))
-        self.handle = h
+        self._handle = None
+
+    @property
+    def handle(self):
+        """the library's device view of the grid, created on first use: a grid whose halo is smaller than the advection scheme
+        needs may exist as host metadata (the model constructor replaces it, `inflate_grid_halo_size`), but the library refuses it"""
+        if self._handle is None:
+            h = C.c_void_p()
+            dp = C.POINTER(C.c_double)
+            zc = None if self.z_regular else self.Δzᵃᵃᶜ.ctypes.data_as(dp)
+            zf = None if self.z_regular else self.Δzᵃᵃᶠ.ctypes.data_as(dp)
+            _lib.check(_lib.lib().ocn_grid_create(
+                C.byref(h), _lib.i3(self.size), _lib.i3(self.halo_size), _lib.i3([_topo_code(t) for t in self.topology]),
+                (C.c_double * 3)(self.Lx, self.Ly, self.Lz), self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ, self._dz, zc, zf))
+            self._handle = h
+        return self._handle
 
     @property
     def size(self):
@@ -184,10 +199,16 @@ class RectilinearGrid:
 
     def __del__(self):
         try:
-            _lib.lib().ocn_grid_destroy(self.handle)
+            if self._handle is not None:
+                _lib.lib().ocn_grid_destroy(self._handle)
         except Exception:
             pass
 
     def __repr__(self):
         names = "×".join(str(n) for n in self.size)
         return f"{names} RectilinearGrid{{Float64, {', '.join(t.__name__ for t in self.topology)}}} on {self.architecture} with {self.halo_size} halo"
+
+
+def with_halo(halo, grid):
+    """with_halo(halo, grid::RectilinearGrid) (rectilinear_grid.jl:442-449): the same grid with another halo"""
+    return type(grid)(grid.architecture, halo=tuple(halo), **grid._constructor_arguments)

@@ -42,8 +42,8 @@ class NonhydrostaticModel:
                  closure=None, forcing=None, boundary_conditions=None):
         if advection is None:
             advection = WENO()
-        if not isinstance(advection, WENO):
-            raise NotImplementedError("only advection = WENO(order=5) is on the accelerated hot path")
+        if not (isinstance(advection, WENO) and advection.order == 5 and advection.bounds is None):
+            raise NotImplementedError("only advection = WENO(order=5) without bounds is on the accelerated hot path")
         timestepper = str(timestepper).lstrip(":")
         if timestepper not in ("RungeKutta3", "QuasiAdamsBashforth2"):
             raise NotImplementedError("timestepper must be :RungeKutta3 (hot path) or :QuasiAdamsBashforth2 (SURVEY.md 8f.1)")
@@ -62,6 +62,18 @@ class NonhydrostaticModel:
             raise NotImplementedError("only closure = nothing | ScalarDiffusivity(ν, κ) | AnisotropicMinimumDissipation(C, Cν, Cκ) is on "
                                       "the accelerated path (SURVEY.md 8f)")
         self.closure = closure
+        # "Adjust advection scheme to be valid on a particular grid size" and "Adjust halos when the advection scheme or turbulence
+        # closure requires it" (nonhydrostatic_model.jl:176-184). The library derives the same per-direction schemes from the grid
+        # size (ocn_grid_create), so only the descriptor and the halo are settled here.
+        from .advection import adapt_advection_order, inflate_halo_size
+        from .grids import with_halo
+        advection = adapt_advection_order(advection, grid)
+        required = inflate_halo_size(*grid.halo_size, grid, advection, closure)
+        if any(u < r for u, r in zip(grid.halo_size, required)):
+            import warnings
+            warnings.warn(f"Inflating model grid halo size to {required} and recreating grid. The model grid will be different from the "
+                          f"input grid. To avoid this warning, pass halo={required} when constructing the grid.")
+            grid = with_halo(required, grid)
         self.grid, self.advection = grid, advection
         self.tracer_names = tuple(str(t) for t in (tracers if isinstance(tracers, (tuple, list)) else (tracers,)))
         self.handle = self._create_handle(grid, len(self.tracer_names))

@@ -34,8 +34,20 @@ oro_grid *oro_grid_create(const int N[3], const int H[3], const int topo[3], con
         int len = N[d] + 2 * H[d] + 1;
         g->dc[d] = dupvec(dc[d], len);
         g->df[d] = dupvec(df[d], len);
+        /* NonhydrostaticModel(advection = WENO()) adapts the scheme to the grid (nonhydrostatic_model.jl:176-179) */
+        g->B[d] = oro_adapt_advection_order(ORO_ADV_WENO, 3, N[d], topo[d]);
     }
     return g;
+}
+
+/* Advection/adapt_advection_order.jl:62-96, one direction. Flat: `adapt_advection_order(::Flat, advection, N, grid) = advection`
+ * (:63); Centered{B}: N >= B ? same : Centered(order = 2N) (:76-82) whose buffer is 2N / 2 = N (centered_reconstruction.jl:14);
+ * UpwindBiased{B}: N >= B ? same : UpwindBiased(order = 2N-1) (:84-90), buffer (2N-1+1) / 2 = N (upwind_biased_reconstruction.jl:16);
+ * WENO{B}: N >= B ? same : WENO(order = 2N-1) (:91-97), buffer N (weno_reconstruction.jl:90; order 1 is UpwindBiased(order=1), :81-83). */
+int oro_adapt_advection_order(int family, int B, int N, int topo) {
+    (void)family;                      /* the three families reduce to the same buffer; the family itself is kept */
+    if (topo == ORO_FLAT) return B;
+    return N >= B ? B : N;
 }
 
 void oro_grid_destroy(oro_grid *g) {
@@ -314,6 +326,16 @@ static inline double biased_interp(const double S[6], int left, int bounded, int
     return left ? 1.0 * S[2] : 1.0 * S[3];
 }
 
+/* The same pair for a direction whose scheme adapt_advection_order reduced (FluxFormAdvection, flux_form_advection.jl:45-59):
+ * WENO{2} carries advecting_velocity_scheme Centered(order=2) and buffer_scheme UpwindBiased{1} (weno_reconstruction.jl:81-93);
+ * UpwindBiased{1} carries Centered(order=2) and no buffer scheme (upwind_biased_reconstruction.jl:26-29; LOADV in
+ * topologically_conditional_interpolation.jl:79,98-99: never conditional). Q = q[f-1], q[f]; S = psi[f-2 .. f+1]. */
+static inline double symmetric_interp_low(const double Q[2]) { return fma(OCN_C2_1, Q[1], OCN_C2_2 * Q[0]); }
+static inline double biased_interp_low(const double S[4], int left, int bounded, int i, int center, int N, int B) {
+    if (B == 2 && (!bounded || outside_biased_halo(i, center, N, 2))) return oro_weno3_biased(S, left);
+    return left ? 1.0 * S[1] : 1.0 * S[2];
+}
+
 /* ------------------------------------------------------------------------------------------------------------------
  * advective fluxes (Advection/upwind_biased_advective_fluxes.jl:23-121)
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -330,11 +352,19 @@ static inline double Az_q_ccf(const vel *V, int i, int j, int k) { return (DC(V-
 typedef double (*aq_fn)(const vel *, int, int, int);
 
 /* symmetric interpolation of an area-weighted transport along direction d. `center`: ᶜ variant (face index idx+1). */
-static inline double sym_transport(const vel *V, aq_fn q, int d, int center, int i, int j, int k) {
+static inline double sym_transport(const vel *V, aq_fn q, int d, int center, int i, int j, int k, int B) {
     const oro_grid *g = V->g;
     if (g->topo[d] == ORO_FLAT) return q(V, i, j, k);     /* flat_advective_fluxes.jl:35-50: interpolation along a Flat direction = ψ[i, j, k] */
     int idx = (d == 0) ? i : (d == 1) ? j : k;
     int f = idx + (center ? 1 : 0);
+    if (B < 3) {   /* the scheme of the direction the flux points along was reduced: Centered(order=2) */
+        double Q2[2];
+        for (int n = 0; n < 2; ++n) {
+            int m = f - 1 + n;
+            Q2[n] = (d == 0) ? q(V, m, j, k) : (d == 1) ? q(V, i, m, k) : q(V, i, j, m);
+        }
+        return symmetric_interp_low(Q2);
+    }
     double Q[4];
     for (int n = 0; n < 4; ++n) {
         int m = f - 2 + n;
@@ -346,6 +376,14 @@ static inline double sym_transport(const vel *V, aq_fn q, int d, int center, int
 static inline double biased_field(const oro_grid *g, const fld *c, int left, int d, int center, int i, int j, int k) {
     int idx = (d == 0) ? i : (d == 1) ? j : k;
     int f = idx + (center ? 1 : 0);
+    if (g->B[d] < 3) {
+        double S4[4] = {0, 0, 0, 0};
+        for (int n = (g->B[d] == 2 ? 0 : 1); n < (g->B[d] == 2 ? 4 : 3); ++n) {
+            int m = f - 2 + n;
+            S4[n] = (d == 0) ? AT(*c, m, j, k) : (d == 1) ? AT(*c, i, m, k) : AT(*c, i, j, m);
+        }
+        return biased_interp_low(S4, left, g->topo[d] == ORO_BOUNDED, idx, center, g->N[d], g->B[d]);
+    }
     double S[6];
     for (int n = 0; n < 6; ++n) {
         int m = f - 3 + n;
@@ -357,7 +395,7 @@ static inline double biased_field(const oro_grid *g, const fld *c, int left, int
 #define FLUX(name, aq, dsym, csym, dbias, cbias, fieldmember)                                                  \
     static inline double name(const vel *V, const fld *psi, int i, int j, int k) {                             \
         if (V->g->topo[dbias] == ORO_FLAT) return 0.0;   /* flat_advective_fluxes.jl:13-27 */                   \
-        double ut = sym_transport(V, aq, dsym, csym, i, j, k);                                                 \
+        double ut = sym_transport(V, aq, dsym, csym, i, j, k, V->g->B[dbias]);                                 \
         double pr = biased_field(V->g, psi, ut > 0, dbias, cbias, i, j, k);                                    \
         return ut * pr;                                                                                        \
     }
@@ -1002,6 +1040,45 @@ static void dct_line(cplx *x, int n, int stride, int backward) {
     }
     for (int k = 0; k < n; ++k) x[(size_t)k * stride] = tmp[k];
     free(tmp);
+}
+
+/* Solvers/index_permutations.jl:18-35 (Makhoul 1980 eq. 20), 1-based */
+int oro_permute_index(int i, int N) { return (i % 2 == 1) ? (int)(i / 2.0) + 1 : N - (int)((i - 1) / 2.0); }
+int oro_unpermute_index(int i, int N) { return (i <= ceil(N / 2.0)) ? 2 * i - 1 : 2 * (N - i + 1); }
+
+/* The transforms as the CPU DiscreteTransform applies them (FFTW REDFT10 forward; REDFT01 x 1/2N backward,
+ * discrete_transforms.jl:20-34) on n real numbers */
+void oro_dct_direct(double *x, int n, int backward) {
+    cplx *t = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    for (int k = 0; k < n; ++k) t[k] = x[k];
+    dct_line(t, n, 1, backward);
+    for (int k = 0; k < n; ++k) x[k] = creal(t[k]) * (backward ? 1.0 / (2.0 * n) : 1.0);
+    free(t);
+}
+
+/* ... and as the GPU DiscreteTransform applies them (discrete_transforms.jl:108-175): forward = permute_indices!, complex FFT,
+ * A = 2 real(omega_4N^k A) (:166-169, twiddles :48-75: omega(M, k) = exp(-2 pi i k / M), Solvers.jl); backward = A *= omega_4N^-k with
+ * the zeroth factor halved, normalised inverse FFT, unpermute_indices!, real part */
+void oro_dct_makhoul(double *x, int n, int backward) {
+    cplx *A = (cplx *)malloc(sizeof(cplx) * (size_t)n), *Bf = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    fft_prepare(n);
+    if (!backward) {
+        for (int i = 1; i <= n; ++i) Bf[oro_permute_index(i, n) - 1] = x[i - 1];
+        fft_any(Bf, n, -1);
+        for (int k = 0; k < n; ++k) {
+            double ang = -2.0 * M_PI * (double)k / (4.0 * n);
+            x[k] = 2.0 * creal((cos(ang) + I * sin(ang)) * Bf[k]);
+        }
+    } else {
+        for (int k = 0; k < n; ++k) {
+            double ang = -2.0 * M_PI * (double)(-k) / (4.0 * n);
+            A[k] = x[k] * (cos(ang) + I * sin(ang)) * (k == 0 ? 0.5 : 1.0);
+        }
+        fft_any(A, n, +1);
+        for (int i = 1; i <= n; ++i) Bf[oro_unpermute_index(i, n) - 1] = A[i - 1] / (double)n;
+        for (int k = 0; k < n; ++k) x[k] = creal(Bf[k]);
+    }
+    free(A); free(Bf);
 }
 
 /* transform all lines along dimension d of a dense (n0, n1, n2) column-major complex array */

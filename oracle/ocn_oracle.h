@@ -32,7 +32,24 @@ typedef struct {
      * Lengths: dc N+2H+1 (last entry padding), df N+2H+1. (src/Grids/grid_generation.jl:34-135) */
     double *dc[3];
     double *df[3];
+    /* buffer of the advection scheme each direction ends up with after adapt_advection_order (set by oro_grid_create
+     * from WENO(order=5): 3 = WENO{3}, 2 = WENO{2}, 1 = UpwindBiased{1}) */
+    int B[3];
 } oro_grid;
+
+/* Advection/adapt_advection_order.jl:62-96 for one direction: scheme family (ORO_ADV_CENTERED / _UPWIND / _WENO) with buffer B
+ * on N cells of the given topology -> buffer of the adapted scheme (Flat: unchanged; N >= B: unchanged; else Centered(order=2N)
+ * -> buffer N, UpwindBiased / WENO(order=2N-1) -> buffer N). required_halo_size of a scheme is its buffer (Advection.jl:63-65). */
+enum { ORO_ADV_CENTERED = 0, ORO_ADV_UPWIND = 1, ORO_ADV_WENO = 2 };
+int oro_adapt_advection_order(int family, int B, int N, int topo);
+/* Solvers/index_permutations.jl:18-35 (1-based, as the reference writes them) */
+int oro_permute_index(int i, int N);
+int oro_unpermute_index(int i, int N);
+/* the reference's GPU cosine transforms (discrete_transforms.jl:48-75,126-139,166-169): permute_index + FFT + twiddle (forward),
+ * twiddle + IFFT + unpermute_index (backward, scaled like FFTW's REDFT01 / 2N... see the .c file); checks that route against
+ * the direct REDFT10 / REDFT01 sums the rest of the oracle uses. x: n real numbers, in place. */
+void oro_dct_makhoul(double *x, int n, int backward);
+void oro_dct_direct(double *x, int n, int backward);
 
 typedef struct oro_model oro_model;
 

@@ -120,6 +120,11 @@ def lib():
         L.oro_model_max_abs_divergence.restype = C.c_double
         L.oro_model_max_abs_divergence.argtypes = [vp]
         L.oro_set_num_threads.argtypes = [C.c_int]
+        L.oro_adapt_advection_order.argtypes = [C.c_int] * 4
+        L.oro_permute_index.argtypes = [C.c_int, C.c_int]
+        L.oro_unpermute_index.argtypes = [C.c_int, C.c_int]
+        L.oro_dct_makhoul.argtypes = [dp, C.c_int, C.c_int]
+        L.oro_dct_direct.argtypes = [dp, C.c_int, C.c_int]
     return _LIB
 
 
@@ -210,10 +215,14 @@ def stretched_spacings(faces, N, H, bounded):
 class Grid:
     """RectilinearGrid (x, y regular; z regular or stretched-Bounded). reference: Grids/rectilinear_grid.jl:264-291"""
 
-    def __init__(self, size, halo=(3, 3, 3), topology=(PERIODIC, PERIODIC, PERIODIC),
+    def __init__(self, size, halo=None, topology=(PERIODIC, PERIODIC, PERIODIC),
                  x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0)):
         self.N = tuple(int(n) for n in size)
         self.topo = tuple(int(t) for t in topology)
+        if halo is None:      # validate_halo(..., ::Nothing) (Grids/input_validation.jl:71-77): min(3, size)
+            halo = tuple(min(3, n) for n in self.N)
+        # buffers of the per-direction schemes NonhydrostaticModel(advection = WENO()) ends up with
+        self.B = tuple(lib().oro_adapt_advection_order(2, 3, self.N[d], self.topo[d]) for d in range(3))
         # Flat directions: one cell, no halo, unit spacing and extent (Grids/grid_utils.jl, spacings_and_areas_and_volumes.jl:123)
         assert all(self.N[d] == 1 for d in range(3) if self.topo[d] == FLAT), "a Flat direction has size 1"
         self.H = tuple(0 if self.topo[d] == FLAT else int(h) for d, h in enumerate(halo))

@@ -94,8 +94,13 @@ def test_weno_descriptor_validation():
     assert "WENO{3, Float64, Float32}(order=5)" in repr(ocn.WENO())          # weno_reconstruction.jl:53-57
     with pytest.raises(ValueError):
         ocn.WENO(order=4)                                                    # "defined only for odd orders"
-    with pytest.raises(NotImplementedError):
-        ocn.WENO(order=7)
+    # descriptors of every order exist (host metadata); the accelerated model takes WENO(order=5) -- refused before anything touches
+    # the device, so this runs without a GPU
+    assert ocn.WENO(order=7).buffer == 4
+    grid = ocn.RectilinearGrid(None, size=(8, 8, 8), extent=(1, 1, 1))
+    for scheme in (ocn.WENO(order=7), ocn.WENO(bounds=(0, 1)), ocn.Centered(order=4), ocn.UpwindBiased(order=3)):
+        with pytest.raises(NotImplementedError):
+            ocn.NonhydrostaticModel(grid=grid, advection=scheme)
 
 
 def test_partition_coordinate_is_contiguous():

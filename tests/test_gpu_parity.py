@@ -770,3 +770,134 @@ def test_split_pressure_step_equals_library_plans(ocn, arch, size, zb):
     for name in outs[0]:
         a, b = outs[0][name][3:-3, 3:-3, 3:-3], outs[1][name][3:-3, 3:-3, 3:-3]
         assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-30), name
+
+
+@pytest.mark.parametrize("N", [8, 9, 2, 3, 16, 27, 128])
+def test_permutation_tables_on_device(ocn, oracle, arch, N):
+    """the cosine-transform path's gather / scatter kernels move element i where the reference's permute_index / unpermute_index
+    say (Solvers/index_permutations.jl:5-35; docstring tables for N = 8, 9), bit for bit like the oracle's restatement"""
+    import ctypes as C
+    from oldoceananigans_jl_amd import _lib
+    tables = {(8, 0): [1, 8, 2, 7, 3, 6, 4, 5], (9, 0): [1, 9, 2, 8, 3, 7, 4, 6, 5],
+              (8, 1): [1, 3, 5, 7, 8, 6, 4, 2], (9, 1): [1, 3, 5, 7, 9, 8, 6, 4, 2]}
+    L = oracle.lib()
+    for backward in (0, 1):
+        out = (C.c_int * N)()
+        _lib.check(_lib.lib().ocn_debug_permute_indices(N, backward, out))
+        got = list(out)
+        fn = L.oro_unpermute_index if backward else L.oro_permute_index
+        assert got == [fn(i, N) for i in range(1, N + 1)]
+        if (N, backward) in tables:
+            assert got == tables[(N, backward)]
+
+
+ADAPTED = [((4, 2, 4), ("Periodic", "Periodic", "Periodic")), ((8, 2, 6), ("Periodic", "Periodic", "Bounded")),
+           ((2, 8, 6), ("Periodic", "Periodic", "Periodic")), ((6, 8, 2), ("Periodic", "Periodic", "Periodic")),
+           ((8, 2, 6), ("Periodic", "Bounded", "Bounded")), ((2, 6, 2), ("Bounded", "Periodic", "Periodic"))]
+
+
+@pytest.mark.parametrize("size,topology", ADAPTED)
+def test_adapted_advection_order_matches_oracle(ocn, oracle, arch, size, topology):
+    """NonhydrostaticModel(advection = WENO()) on a grid with two cells in a direction (adapt_advection_order.jl:18-96, expectations of
+    test/test_nonhydrostatic_models.jl:72-91): that direction carries WENO(order=3) + Centered(order=2) and a halo of 2. Tendencies
+    bit-identical to the oracle, 10 RK3 steps within 1e-12."""
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology)
+    assert isinstance(m_gpu.advection, ocn.FluxFormAdvection)
+    expected = tuple(min(3, n) for n in size)
+    assert (ocn.required_halo_size_x(m_gpu.advection), ocn.required_halo_size_y(m_gpu.advection),
+            ocn.required_halo_size_z(m_gpu.advection)) == expected
+    assert m_gpu.grid.halo_size == expected == g_cpu.H and g_cpu.B == expected
+    assert m_gpu.get_option("fused_tendency_active") == 0          # reduced-order directions take the per-field kernels
+    set_both(ocn, m_gpu, m_cpu, seed=5, enforce_incompressibility=False)
+    ocn.update_state(m_gpu, True)
+    m_cpu.update_state(True)
+    for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+        G_gpu, G_cpu = m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)
+        assert np.array_equal(G_gpu, G_cpu), (n, np.abs(G_gpu - G_cpu).max())
+    set_both(ocn, m_gpu, m_cpu, seed=6, smooth=True)
+    dt = 0.02 * min(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ)
+    for _ in range(10):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    Hx, Hy, Hz = expected
+    umax = max(np.abs(m_cpu.field(n)).max() for n in ("u", "v", "w"))
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        ia, ib = a[Hx:-Hx, Hy:-Hy, Hz:-Hz], b[Hx:-Hx, Hy:-Hy, Hz:-Hz]
+        assert np.all(np.isfinite(ia))
+        if name == "pNHS":
+            # on these few-cell grids the smooth state is almost divergence-free: |p| ~ 1e-5 |u|^2, while the round-off that reaches p
+            # is that of the velocities (p solves lap p = div u* / dt) -- measured against the kinetic scale |u|^2 of the pressure
+            assert np.max(np.abs(ia - ib)) < 1e-12 * max(np.abs(ib).max(), umax ** 2), name
+            continue
+        assert rel_err(ia, ib) < 1e-12, (name, rel_err(ia, ib))
+    assert ocn.max_abs_divergence(m_gpu) < 5e-8
+
+
+def test_one_cell_in_a_non_flat_direction_is_refused(ocn, arch):
+    """N = 1 in a Periodic / Bounded direction: adapt_advection_order would give UpwindBiased(order=1) with a one-cell halo, into which
+    the reference's Centered(order=4) advecting-velocity interpolation of the other directions' fluxes reads two cells. Refused with
+    a message that names the remedy (a Flat direction)."""
+    grid = ocn.RectilinearGrid(arch, size=(4, 1, 4), extent=(1, 1, 1))
+    with pytest.raises(ocn.OcnError, match="Flat"):
+        ocn.NonhydrostaticModel(grid=grid)
+
+
+@pytest.mark.parametrize("size", [(8, 8, 8), (16, 9, 5), (3, 3, 3), (5, 4, 2)])
+def test_one_launch_fill_on_bounded_z_with_boundary_conditions(ocn, oracle, arch, size):
+    """(Periodic, Periodic, Bounded): bounded z fill + periodic y + periodic x as ONE launch (fill_periodic_xy_bounded_z_kernel) -- every
+    cell of the parent array, the stale deep z halos included, equals the oracle's three ordered fills
+    (boundary_condition_ordering.jl:17-46) and the three-launch path, with Value / Gradient / Flux / Open conditions on the z sides"""
+    topology = ("Periodic", "Periodic", "Bounded")
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology)
+    spec = {"T": dict(bottom=("Value", 0.25), top=("Gradient", -0.7)), "S": dict(top=("Flux", 4.0)),
+            "u": dict(bottom=("Value", 0.0), top=("Flux", -1e-3)), "v": dict(bottom=("Gradient", 0.3)),
+            "w": dict(top=("Open", 0.125), bottom=("Open", -0.25))}
+    rng = np.random.default_rng(17)
+    for name, f in m_gpu.fields().items():
+        loc = tuple(1 if l is ocn.Face else 0 for l in f.loc)
+        for fill_open in (False, True):
+            a = rng.standard_normal(f.shape)            # random data EVERYWHERE, halos included
+            out = []
+            for fused in (1, 0):
+                ocn.set_option("fused_halo", fused)
+                f.set_parent(a)
+                ocn.fill_halo_regions(f, fill_open_bcs=fill_open, boundary_conditions=_fbcs(ocn, spec[name]))
+                out.append(f.parent())
+            ocn.set_option("fused_halo", 1)
+            b = np.asfortranarray(a.copy())
+            g_cpu.fill_halo_regions(b, loc, fill_open, bcs=_oracle_bcs(spec[name]))
+            assert np.array_equal(out[0], b), (name, fill_open)
+            assert np.array_equal(out[0], out[1]), (name, fill_open)
+
+
+def test_fused_substep_with_field_dependent_flux_conditions(ocn, arch):
+    """the configs[4] physics keeps the RK3 substeps of stages 2 and 3 inside the one-pass epilogue also when a linear
+    field-dependent Flux condition is set (it used to fall back to rk3_substep_kernel): bit-identical to the separate launches"""
+    size = (64, 12, 10)
+    z = tanh_faces(size[2])
+    F, rate = ocn.FieldBoundaryConditions, 2.5e-3
+    bcs = {"u": F(top=ocn.FluxBoundaryCondition(-1e-3)),
+           "T": F(top=ocn.FluxBoundaryCondition(4e-3), bottom=ocn.GradientBoundaryCondition(0.01)),
+           "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(a=1e-4, b=-rate), field_dependencies="S"),
+                  bottom=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=rate), field_dependencies="T"))}
+    out = []
+    for fuse, epilogue in ((1, 1), (0, 1), (0, 0)):
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), closure=ocn.AnisotropicMinimumDissipation(),
+                                        buoyancy=ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4)),
+                                        boundary_conditions=bcs)
+        model.set_option("fuse_substep", fuse)
+        model.set_option("fused_epilogue", epilogue)
+        assert model.get_option("fuse_substep_active") == fuse
+        ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=5))
+        for _ in range(3):
+            ocn.time_step(model, 0.05 * grid.Δxᶜᵃᵃ)
+        out.append({n: f.parent() for n, f in model.fields().items()} | {"Gu": model.tendency("u").parent(), "GS": model.tendency("S").parent()})
+        model.close()
+    for other in out[1:]:
+        for n in out[0]:
+            assert np.array_equal(out[0][n], other[n]), n
+    # and without any other physics: the Flux conditions alone route the substep through the epilogue
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=bcs)
+    assert model.get_option("fuse_substep_active") == 1

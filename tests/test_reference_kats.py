@@ -1,0 +1,276 @@
+"""Known answers the reference itself holds in docstrings and tests that are not field data: the
+`permute_index` / `unpermute_index` tables (src/Solvers/index_permutations.jl:5-35), `load_weno_stencil` (src/Advection/
+weno_interpolants.jl:366-374), the `WENO()` composition (weno_reconstruction.jl:53-75), and the halo / advection-order expectations of
+test/test_nonhydrostatic_models.jl:40-97 (adapt_advection_order + inflate_grid_halo_size). CPU side: the oracle's restatements and the
+host mirror. The HIP side of the same answers is in tests/test_gpu_parity.py (test_permutation_tables_on_device,
+test_adapted_advection_order_*).
+
+Parity stays UNPINNED against Julia output: these pin index work and scheme selection, not WENO-5 / RK3 field values."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+# the tables of the docstrings, index_permutations.jl:8-13 and :26-31
+PERMUTE = {8: [1, 8, 2, 7, 3, 6, 4, 5], 9: [1, 9, 2, 8, 3, 7, 4, 6, 5]}
+UNPERMUTE = {8: [1, 3, 5, 7, 8, 6, 4, 2], 9: [1, 3, 5, 7, 9, 8, 6, 4, 2]}
+
+
+@pytest.mark.parametrize("N", [8, 9])
+def test_permute_and_unpermute_index_tables(oracle, N):
+    L = oracle.lib()
+    assert [L.oro_permute_index(i, N) for i in range(1, N + 1)] == PERMUTE[N]
+    assert [L.oro_unpermute_index(i, N) for i in range(1, N + 1)] == UNPERMUTE[N]
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 7, 8, 9, 16, 27, 128])
+def test_permutations_are_mutually_inverse(oracle, N):
+    """unpermute_indices!(permute_indices!(a)) == a: dst[permute_index(i)] = src[i] followed by dst[unpermute_index(i)] = src[i]"""
+    L = oracle.lib()
+    a = np.arange(1, N + 1)
+    b = np.empty_like(a)
+    for i in range(1, N + 1):
+        b[L.oro_permute_index(i, N) - 1] = a[i - 1]
+    c = np.empty_like(a)
+    for i in range(1, N + 1):
+        c[L.oro_unpermute_index(i, N) - 1] = b[i - 1]
+    assert np.array_equal(c, a)
+    assert sorted(L.oro_permute_index(i, N) for i in range(1, N + 1)) == list(a)
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 9, 16, 27, 64])
+def test_gpu_route_cosine_transform_equals_the_cpu_route(oracle, N):
+    """the reference has two routes to the same cosine transforms: FFTW REDFT10 / REDFT01 x 1/2N on the CPU (discrete_transforms.jl:
+    20-34) and permute + FFT + twiddle on the GPU (:108-175, Makhoul 1980). The oracle's Poisson solver uses the first, the HIP
+    library the second: they must agree, and backward(forward(x)) = x."""
+    L = oracle.lib()
+    dp = C.POINTER(C.c_double)
+    rng = np.random.default_rng(N)
+    x = rng.standard_normal(N)
+    for backward in (0, 1):
+        a, b = x.copy(), x.copy()
+        L.oro_dct_direct(a.ctypes.data_as(dp), N, backward)
+        L.oro_dct_makhoul(b.ctypes.data_as(dp), N, backward)
+        assert np.max(np.abs(a - b)) < 1e-13 * max(1.0, np.max(np.abs(a))), (N, backward)
+    y = x.copy()
+    L.oro_dct_makhoul(y.ctypes.data_as(dp), N, 0)
+    L.oro_dct_makhoul(y.ctypes.data_as(dp), N, 1)
+    assert np.max(np.abs(y - x)) < 1e-13
+
+
+@pytest.mark.parametrize("sign", [+1.0, -1.0])
+def test_load_weno_stencil_footprint(oracle, sign):
+    """load_weno_stencil(3, :x) = (ψ[i-3], ..., ψ[i+2]) (weno_interpolants.jl:366-374): the face value at i reads exactly these six
+    cells -- the left-biased reconstruction (ũ > 0) the first five, the right-biased one the last five. A unit impulse in c on the
+    reference's (Nx, 1, 1) Flat grids therefore reaches the tracer tendency of cells i0-2 .. i0+3 (ũ > 0) or i0-3 .. i0+2 (ũ < 0)
+    and no other."""
+    O = oracle
+    N, i0 = 24, 12                                             # 1-based cell of the impulse
+    g = O.Grid((N, 1, 1), topology=(O.PERIODIC, O.FLAT, O.FLAT))
+    H = g.H[0]
+    u = g.zeros(O.LOC["u"]); v = g.zeros(O.LOC["v"]); w = g.zeros(O.LOC["w"]); c = g.zeros(O.LOC["c"])
+    u[...] = sign
+    c[i0 - 1 + H, 0, 0] = 1.0
+    g.fill_halo_regions(c, O.LOC["c"])
+    G = g.zeros(O.LOC["c"])
+    g.compute_G("c", u, v, w, G, c=c)
+    Gi = g.interior_cells(G)[:, 0, 0]
+    touched = set(np.nonzero(Gi)[0] + 1)
+    expect = set(range(i0 - 2, i0 + 4)) if sign > 0 else set(range(i0 - 3, i0 + 3))
+    assert touched <= expect
+    assert min(expect) in touched and max(expect) in touched
+
+
+def test_weno_composition_docstring(ocn_host):
+    """weno_reconstruction.jl:53-75 (jldoctest)"""
+    ocn = ocn_host
+    assert repr(ocn.WENO()) == ("WENO{3, Float64, Float32}(order=5)\n├── buffer_scheme: WENO{2, Float64, Float32}(order=3)\n"
+                                "└── advection_velocity_scheme: Centered(order=4)")
+    assert repr(ocn.WENO(order=9)) == ("WENO{5, Float64, Float32}(order=9)\n├── buffer_scheme: WENO{4, Float64, Float32}(order=7)\n"
+                                       "└── advection_velocity_scheme: Centered(order=8)")
+    assert repr(ocn.WENO(order=9, bounds=(0, 1))) == ("WENO{5, Float64, Float32}(order=9)\n├── bounds: (0, 1)\n"
+                                                      "├── buffer_scheme: WENO{4, Float64, Float32}(order=7)\n"
+                                                      "└── advection_velocity_scheme: Centered(order=8)")
+    # WENO(order=1) is UpwindBiased(order=1) (:81-83); the cascade ends there
+    w = ocn.WENO()
+    assert isinstance(w.buffer_scheme.buffer_scheme, ocn.UpwindBiased) and w.buffer_scheme.buffer_scheme.buffer == 1
+    assert w.buffer_scheme.advecting_velocity_scheme == ocn.Centered(order=2)
+    assert w.buffer_scheme.buffer_scheme.advecting_velocity_scheme == ocn.Centered(order=2)
+    with pytest.raises(ValueError):
+        ocn.WENO(order=4)
+    with pytest.raises(ValueError):
+        ocn.Centered(order=3)
+    with pytest.raises(ValueError):
+        ocn.UpwindBiased(order=2)
+    # required_halo_size_x(Centered(order=4)) == 2 (Grids/automatic_halo_sizing.jl:10-18, jldoctest)
+    assert ocn.required_halo_size_x(ocn.Centered(order=4)) == 2
+    assert ocn.required_halo_size_y(ocn.Centered(order=4)) == 2
+    assert ocn.required_halo_size_z(ocn.Centered(order=4)) == 2
+
+
+@pytest.fixture()
+def ocn_host():
+    """the host mirror without a device: grids are metadata until a kernel needs their handle"""
+    import oldoceananigans_jl_amd as ocn
+    return ocn
+
+
+def _model_grid_and_advection(ocn, grid, advection, closure=None):
+    """what the NonhydrostaticModel constructor settles before it allocates anything (nonhydrostatic_model.jl:176-184)"""
+    advection = ocn.adapt_advection_order(advection, grid)
+    required = ocn.inflate_halo_size(*grid.halo_size, grid, advection, closure)
+    if any(u < r for u, r in zip(grid.halo_size, required)):
+        grid = ocn.with_halo(required, grid)
+    return grid, advection
+
+
+def test_adjustment_of_halos_in_the_model_constructor(ocn_host):
+    """test/test_nonhydrostatic_models.jl:40-70"""
+    ocn = ocn_host
+    minimal_grid = ocn.RectilinearGrid(None, size=(4, 4, 4), extent=(1, 2, 3), halo=(1, 1, 1))
+    funny_grid = ocn.RectilinearGrid(None, size=(4, 4, 4), extent=(1, 2, 3), halo=(1, 3, 4))
+    g, _ = _model_grid_and_advection(ocn, minimal_grid, None)             # the reference's default advection is Centered(order=2)
+    assert g.halo_size == (1, 1, 1)
+    g, _ = _model_grid_and_advection(ocn, funny_grid, ocn.Centered())
+    assert g.halo_size == (1, 3, 4)
+    for scheme in (ocn.Centered(order=4), ocn.UpwindBiased(order=3)):
+        assert _model_grid_and_advection(ocn, minimal_grid, scheme)[0].halo_size == (2, 2, 2)
+        assert _model_grid_and_advection(ocn, funny_grid, scheme)[0].halo_size == (2, 3, 4)
+    for scheme in (ocn.WENO(), ocn.UpwindBiased(order=5)):
+        assert _model_grid_and_advection(ocn, minimal_grid, scheme)[0].halo_size == (3, 3, 3)
+        assert _model_grid_and_advection(ocn, funny_grid, scheme)[0].halo_size == (3, 3, 4)
+    # the inflated grid is the same grid otherwise
+    g = _model_grid_and_advection(ocn, funny_grid, ocn.WENO())[0]
+    assert (g.size, g.Lx, g.Ly, g.Lz, g.topology) == (funny_grid.size, 1.0, 2.0, 3.0, funny_grid.topology)
+    # default halo: min(3, size) per direction (Grids/input_validation.jl:71-77); halo <= size in x and y (:86-92)
+    assert ocn.RectilinearGrid(None, size=(4, 2, 4), extent=(1, 2, 3)).halo_size == (3, 2, 3)
+    with pytest.raises(ValueError):
+        ocn.RectilinearGrid(None, size=(4, 2, 4), extent=(1, 2, 3), halo=(3, 3, 3))
+
+
+def test_adjustment_of_advection_schemes_in_the_model_constructor(ocn_host):
+    """test/test_nonhydrostatic_models.jl:72-91: small_grid = (4, 2, 4), halo (1, 1, 1)"""
+    ocn = ocn_host
+    small_grid = ocn.RectilinearGrid(None, size=(4, 2, 4), extent=(1, 2, 3), halo=(1, 1, 1))
+    for scheme, expected in ((ocn.WENO(), (3, 2, 3)), (ocn.UpwindBiased(order=9), (4, 2, 4)), (ocn.Centered(order=10), (4, 2, 4))):
+        grid, advection = _model_grid_and_advection(ocn, small_grid, scheme)
+        assert isinstance(advection, ocn.FluxFormAdvection)
+        assert (ocn.required_halo_size_x(advection), ocn.required_halo_size_y(advection),
+                ocn.required_halo_size_z(advection)) == expected
+        assert grid.halo_size == expected
+        assert type(advection.y) is type(scheme)                       # the family is kept, the order is 2N - 1 (2N for Centered)
+    # nothing changes on a grid that is large enough: the scheme itself comes back (adapt_advection_order.jl:49)
+    big = ocn.RectilinearGrid(None, size=(8, 8, 8), extent=(1, 1, 1))
+    w = ocn.WENO()
+    assert ocn.adapt_advection_order(w, big) is w
+    # Flat directions are not adapted (:62-63)
+    flat = ocn.RectilinearGrid(None, size=(8, 8), extent=(1, 1), topology=(ocn.Periodic, ocn.Flat, ocn.Bounded))
+    assert ocn.adapt_advection_order(w, flat) is w
+    # the oracle's restatement of the same rule, and what the oracle's grid derives from WENO(order=5)
+    from oracle import oracle as O
+    L = O.lib()
+    for family, B in ((0, 5), (1, 5), (2, 3)):
+        for N in range(1, 8):
+            assert L.oro_adapt_advection_order(family, B, N, O.PERIODIC) == min(B, N)
+            assert L.oro_adapt_advection_order(family, B, N, O.FLAT) == B
+    assert O.Grid((4, 2, 4)).B == (3, 2, 3) and O.Grid((4, 2, 4)).H == (3, 2, 3)
+
+
+def test_reduced_order_direction_uses_weno3_and_centered2(oracle):
+    """a direction with N = 2 carries WENO(order=3): tracer flux Ay v cᴿ with cᴿ from the four-point stencil ψ[j-2 .. j+1]
+    (weno_interpolants.jl:366-374, buffer 2), and the fluxes that point along it interpolate their advecting transport with
+    Centered(order=2) (weno_reconstruction.jl:87). Hand evaluation with the oracle's WENO{2} function."""
+    O = oracle
+    L = O.lib()
+    dp = C.POINTER(C.c_double)
+    g = O.Grid((6, 2, 5))
+    assert g.B == (3, 2, 3)
+    rng = np.random.default_rng(5)
+    u = g.zeros(O.LOC["u"]); v = g.zeros(O.LOC["v"]); w = g.zeros(O.LOC["w"]); c = g.zeros(O.LOC["c"])
+    Hx, Hy, Hz = g.H
+    vi = rng.standard_normal((6, 2, 5))
+    ci = rng.standard_normal((6, 2, 5))
+    v[Hx:-Hx, Hy:-Hy, Hz:-Hz] = vi
+    c[Hx:-Hx, Hy:-Hy, Hz:-Hz] = ci
+    for a, loc in ((v, "v"), (c, "c")):
+        g.fill_halo_regions(a, O.LOC[loc])
+    G = g.zeros(O.LOC["c"])
+    g.compute_G("c", u, v, w, G, c=c)
+    dx, dy, dz = g.dc[0][0], g.dc[1][0], g.dc[2][0]
+
+    def flux(i, j, k):                                                    # 0-based parent indices of the face
+        vt = v[i, j, k]
+        S = np.ascontiguousarray(c[i, j - 2:j + 2, k])
+        cr = L.oro_weno3_biased(S.ctypes.data_as(dp), int(vt > 0))
+        return (dx * dz) * vt * cr
+
+    for i in range(6):
+        for j in range(2):
+            for k in range(5):
+                I, J, K = i + Hx, j + Hy, k + Hz
+                div = (1.0 / ((dx * dy) * dz)) * ((0.0 + (flux(I, J + 1, K) - flux(I, J, K))) + 0.0)
+                assert G[I, J, K] == -div + 0.0, (i, j, k)
+    # momentum: u = u(y) only, w = 0, v random -> the x- and z-flux differences of Gu vanish exactly and the only flux left is
+    # Vu = ṽ uᴿ with ṽ the TWO-point average of Ay v along x (Centered(order=2): the flux points along y, whose scheme is WENO{2})
+    from fractions import Fraction
+
+    def fma(a, b, cc):                                                    # one rounding, like the hardware instruction
+        return float(Fraction(a) * Fraction(b) + Fraction(cc))
+
+    u[...] = 0.0
+    u[Hx:-Hx, Hy:-Hy, Hz:-Hz] = rng.standard_normal((1, 2, 1))
+    g.fill_halo_regions(u, O.LOC["u"])
+    Gu = g.zeros(O.LOC["u"])
+    g.compute_G("u", u, v, w, Gu)
+
+    def Vu(i, j, k):
+        q1, q2 = (dx * dz) * v[i - 1, j, k], (dx * dz) * v[i, j, k]
+        vt = fma(0.5, q2, 0.5 * q1)
+        S = np.ascontiguousarray(u[i, j - 2:j + 2, k])
+        return vt * L.oro_weno3_biased(S.ctypes.data_as(dp), int(vt > 0))
+
+    for i in range(6):
+        for j in range(2):
+            for k in range(5):
+                I, J, K = i + Hx, j + Hy, k + Hz
+                div = (1.0 / ((dx * dy) * dz)) * ((0.0 + (Vu(I, J + 1, K) - Vu(I, J, K))) + 0.0)
+                assert Gu[I, J, K] == -div + 0.0, (i, j, k)
+
+
+@pytest.mark.parametrize("perm", [(0, 1, 2), (1, 0, 2), (2, 1, 0)])
+def test_adapted_model_time_steps_and_is_direction_symmetric(oracle, perm):
+    """NonhydrostaticModel(grid = (8, 2, 6)-like, advection = WENO()) as the reference builds it (adapted y scheme, halo (3, 2, 3)):
+    stays finite, divergence-free (test/test_time_stepping.jl:124-160) and conserves the tracer mean; the same physical problem
+    with the short direction along x, y or z gives the same answer (the convergence tests' cx ≈ cy ≈ cz symmetry check,
+    validation/convergence_tests/one_dimensional_advection_schemes.jl:108-118, here for the adapted scheme)."""
+    O = oracle
+    base = (8, 2, 6)
+    size = tuple(base[perm.index(d)] for d in range(3))                  # direction d of this run is base direction perm.index(d)
+
+    def run(size, axes):
+        g = O.Grid(size)
+        m = O.Model(g, 1)
+        rng = np.random.default_rng(3)
+        fields = {n: rng.standard_normal(base) for n in ("u", "v", "w", "c0")}
+        vel = [fields["u"], fields["v"], fields["w"]]
+        # base velocity component b becomes component axes[b] of this run, arrays transposed accordingly
+        args = {}
+        for b in range(3):
+            args["uvw"[axes[b]]] = np.ascontiguousarray(np.moveaxis(vel[b], (0, 1, 2), axes))
+        args["c0"] = np.ascontiguousarray(np.moveaxis(fields["c0"], (0, 1, 2), axes))
+        m.set(**args)
+        mean0 = g.interior_cells(m.field("c0")).mean()
+        for _ in range(3):
+            m.time_step(1e-3)
+        assert m.max_abs_divergence() < 5e-8
+        c = g.interior_cells(m.field("c0"))
+        assert np.all(np.isfinite(c)) and abs(c.mean() - mean0) < 1e-13
+        # copies: the oracle's arrays die with the model
+        return (np.moveaxis(c, axes, (0, 1, 2)).copy(),
+                [np.moveaxis(g.interior_cells(m.field("uvw"[axes[b]])), axes, (0, 1, 2)).copy() for b in range(3)])
+
+    c_ref, vel_ref = run(base, (0, 1, 2))
+    c, vel = run(size, perm)
+    assert np.max(np.abs(c - c_ref)) < 1e-12 * np.max(np.abs(c_ref))
+    for a, b in zip(vel, vel_ref):
+        assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(b))
