@@ -95,7 +95,11 @@ int ocn_fill_halo_regions(ocn_grid_t grid, double *const *fields, const int (*lo
 #define OCN_BC_VALUE 2
 #define OCN_BC_GRADIENT 3
 #define OCN_BC_OPEN 4
-typedef struct { int kind; double value; } ocn_bc_t;
+/* `array` != NULL: an array-valued condition, getbc(condition::AbstractArray, i, j, grid) = condition[i, j] (boundary_condition.jl:164):
+ * a BORROWED device pointer to a dense column-major array over the interior extents of the two tangential directions in the order
+ * x before y before z -- west / east: (Ny, Nz), south / north: (Nx, Nz), bottom / top: (Nx, Ny) -- that replaces the number `value`
+ * point by point (Flux, Value, Gradient and Open conditions alike). It must stay valid while the condition is in use. */
+typedef struct { int kind; double value; const double *array; } ocn_bc_t;
 int ocn_fill_halo_regions_bcs(ocn_grid_t grid, double *const *fields, const int (*locs)[3], int nfields,
                               const ocn_bc_t (*bcs)[6], int fill_open_bcs);
 /* compute_x_bcs! / compute_y_bcs! / compute_z_bcs! (BoundaryConditions/compute_flux_bcs.jl:12-163), called by
@@ -325,6 +329,8 @@ int ocn_model_set_closure(ocn_model_t model, double nu, const double *kappa);
  * computes the model fields "nu_e", "kappa_e0", ... and fills their halos before the tendencies. */
 int ocn_model_set_amd(ocn_model_t model, double Cnu, const double *Ckappa);
 int ocn_model_set_boundary_condition(ocn_model_t model, const char *name, int side, int kind, double value);
+/* the same with an array-valued condition (see ocn_bc_t; borrowed device pointer, valid for the model's lifetime) */
+int ocn_model_set_boundary_condition_array(ocn_model_t model, const char *name, int side, int kind, const double *device_array);
 /* name.side = FluxBoundaryCondition((ξ, η, t, φ, p) -> a + b φ, field_dependencies = dep); dep at the location of `name` */
 int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, double a, double b, const char *dep);
 /* library-wide knobs (no reference equivalent; the defaults are the tuned values, 0 / 1 unless noted):

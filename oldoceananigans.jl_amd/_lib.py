@@ -31,7 +31,7 @@ _pp = C.POINTER(C.c_void_p)
 
 class BC(C.Structure):
     """ocn_bc_t"""
-    _fields_ = [("kind", C.c_int), ("value", C.c_double)]
+    _fields_ = [("kind", C.c_int), ("value", C.c_double), ("array", C.c_void_p)]
 
 class Transport(C.Structure):
     """ocn_transport_t: caller-supplied collectives (device addresses as integers)"""
@@ -106,6 +106,7 @@ SYMBOLS = {
     "ocn_model_cell_advection_timescale": (C.c_int, [_vp, _dp]),
     "ocn_model_get_option": (C.c_int, [_vp, C.c_char_p, _ip]),
     "ocn_model_set_boundary_condition": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, C.c_double]),
+    "ocn_model_set_boundary_condition_array": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, _vp]),
     "ocn_dist_poisson_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_double]),
     "ocn_dist_poisson_destroy": (C.c_int, [_vp]),
     "ocn_dist_poisson_set_buffers": (C.c_int, [_vp, _vp, _vp]),

@@ -311,13 +311,14 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
             for (int sd = 0; sd < 2; ++sd) {
                 bc.kind[f][sd] = bcs ? bcs[f][4 + sd].kind : OCN_BC_DEFAULT;
                 bc.value[f][sd] = bcs ? bcs[f][4 + sd].value : 0.0;
+                bc.arr[f][sd] = bcs ? bcs[f][4 + sd].array : nullptr;
             }
         bc.dlo = grid->h_dzf[g.Hz];
         bc.dhi = grid->h_dzf[g.Nz + g.Hz];
         const int H0 = T[0] == OCN_CONNECTED ? 0 : H[0], N0 = T[0] == OCN_CONNECTED ? P[0] : N[0];
         const long total = (zfill ? (long)P[0] * P[1] * 2 : 0) + ((long)P[0] * (2 * H[1]) + (long)(2 * H0) * N[1]) * (P[2] - (zfill ? 2 : 0));
         hipLaunchKernelGGL(fill_periodic_xy_bounded_z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, fl, bc, P[0], P[1],
-                           P[2], N0, N[1], N[2], H0, H[1], H[2], face, zfill, T[0] == OCN_CONNECTED ? H[0] : 0);
+                           P[2], N0, N[1], N[2], H0, H[1], H[2], face, zfill, T[0] == OCN_CONNECTED ? H[0] : 0, N[0]);
         KERNEL_CHECK();
         return OCN_OK;
     }
@@ -332,6 +333,7 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
             for (int sd = 0; sd < 2; ++sd) {
                 bc.kind[f][sd] = bcs ? bcs[f][2 * d + sd].kind : OCN_BC_DEFAULT;
                 bc.value[f][sd] = bcs ? bcs[f][2 * d + sd].value : 0.0;
+                bc.arr[f][sd] = bcs ? bcs[f][2 * d + sd].array : nullptr;
             }
         // Δ at the boundary faces (flip(Center) = Face): Δxᶠ = Δx, Δyᶠ = Δy, Δzᶠ[1], Δzᶠ[N+1]
         bc.dlo = d == 0 ? g.dx : (d == 1 ? g.dy : grid->h_dzf[g.Hz]);
@@ -449,9 +451,10 @@ static int compute_flux_bcs(const DGrid &g, double *G, const int loc[3], const o
         const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
         const int nb = (int)(((long)Na * Nb + 255) / 256);
         const double flo = bcs[2 * d].value, fhi = bcs[2 * d + 1].value;
-        if (d == 0) hipLaunchKernelGGL(flux_bc_kernel<0>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[0], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
-        if (d == 1) hipLaunchKernelGGL(flux_bc_kernel<1>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[1], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
-        if (d == 2) hipLaunchKernelGGL(flux_bc_kernel<2>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[2], loc[0], loc[1], loc[2], lo, flo, hi, fhi);
+        const double *alo = lo ? bcs[2 * d].array : nullptr, *ahi = hi ? bcs[2 * d + 1].array : nullptr;
+        if (d == 0) hipLaunchKernelGGL(flux_bc_kernel<0>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[0], loc[0], loc[1], loc[2], lo, flo, hi, fhi, alo, ahi);
+        if (d == 1) hipLaunchKernelGGL(flux_bc_kernel<1>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[1], loc[0], loc[1], loc[2], lo, flo, hi, fhi, alo, ahi);
+        if (d == 2) hipLaunchKernelGGL(flux_bc_kernel<2>, dim3(nb), dim3(256), 0, g_stream, g, view, Na, Nb, N[2], loc[0], loc[1], loc[2], lo, flo, hi, fhi, alo, ahi);
     }
     KERNEL_CHECK();
     return OCN_OK;
@@ -2291,8 +2294,10 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     const int T[3] = {g.tx, g.ty, g.tz};
     for (int f = 0; f < OCN_MAX_FIELDS; ++f)
         for (int sd = 0; sd < 6; ++sd) {
-            a.has_flux[f][sd] = f < m->nf && T[sd / 2] == OCN_BOUNDED && m->bcs[f][sd].kind == OCN_BC_FLUX && m->bcs[f][sd].value != 0.0;
+            a.has_flux[f][sd] = f < m->nf && T[sd / 2] == OCN_BOUNDED && m->bcs[f][sd].kind == OCN_BC_FLUX &&
+                                (m->bcs[f][sd].value != 0.0 || m->bcs[f][sd].array);
             a.flux[f][sd] = f < m->nf ? m->bcs[f][sd].value : 0.0;
+            a.flux_arr[f][sd] = f < m->nf ? m->bcs[f][sd].array : nullptr;
             if (sd < 3) a.loc[f][sd] = f < m->nf ? m->loc[f][sd] : 0;
         }
     if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
@@ -2515,7 +2520,7 @@ extern "C" int ocn_model_set_linear_flux_bc(ocn_model_t m, const char *name, int
         if (m->loc[fd][q] != m->loc[f][q])
             return fail(OCN_ENOTSUP, "the field dependency %s must sit at the location of %s (identity interpolation to the boundary)", dep, name);
     (void)d;
-    m->bcs[f][side].kind = OCN_BC_FLUX; m->bcs[f][side].value = 0.0;      // halos of a Flux side: zero gradient
+    m->bcs[f][side].kind = OCN_BC_FLUX; m->bcs[f][side].value = 0.0; m->bcs[f][side].array = nullptr;   // halos of a Flux side: zero gradient
     m->any_bc = true;
     m->lin[f][side].on = true; m->lin[f][side].dep = fd; m->lin[f][side].a = a; m->lin[f][side].b = b;
     m->any_linear_flux = true;
@@ -2548,7 +2553,7 @@ extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa
     return OCN_OK;
 }
 
-extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name, int side, int kind, double value) {
+static int model_set_bc(ocn_model_t m, const char *name, int side, int kind, double value, const double *array) {
     if (m) m->epoch += 1;
     if (!m || !name) return fail(OCN_EINVAL, "NULL argument");
     int f = -1;
@@ -2559,8 +2564,10 @@ extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name,
     if (f < 0) return fail(OCN_EINVAL, "boundary conditions can be set on u, v, w and the tracers c0..c%d; got '%s'", m->ntr - 1, name);
     int rc = validate_bc(m->grid->d, m->loc[f], side, kind);
     if (rc) return rc;
+    if (array && kind == OCN_BC_DEFAULT) return fail(OCN_EINVAL, "an array-valued condition needs a classification (Flux, Value, Gradient, Open)");
     m->bcs[f][side].kind = kind;
     m->bcs[f][side].value = value;
+    m->bcs[f][side].array = array;
     m->lin[f][side].on = false;                 // a plain condition replaces a field-dependent one on this side
     m->any_linear_flux = false;
     for (int q = 0; q < m->nf; ++q)
@@ -2569,9 +2576,19 @@ extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name,
     for (int q = 0; q < m->nf; ++q)
         for (int sd = 0; sd < 6; ++sd) {
             if (m->bcs[q][sd].kind != OCN_BC_DEFAULT) m->any_bc = true;
-            if (m->bcs[q][sd].kind == OCN_BC_FLUX && m->bcs[q][sd].value != 0.0) m->any_flux_bc = true;
+            if (m->bcs[q][sd].kind == OCN_BC_FLUX && (m->bcs[q][sd].value != 0.0 || m->bcs[q][sd].array)) m->any_flux_bc = true;
         }
     return OCN_OK;
+}
+
+extern "C" int ocn_model_set_boundary_condition(ocn_model_t m, const char *name, int side, int kind, double value) {
+    return model_set_bc(m, name, side, kind, value, nullptr);
+}
+
+// the same with an array-valued condition (getbc(condition::AbstractArray, i, j, grid, args...) = condition[i, j], boundary_condition.jl:164)
+extern "C" int ocn_model_set_boundary_condition_array(ocn_model_t m, const char *name, int side, int kind, const double *device_array) {
+    if (!device_array) return fail(OCN_EINVAL, "NULL array");
+    return model_set_bc(m, name, side, kind, 0.0, device_array);
 }
 
 extern "C" int ocn_model_update_state(ocn_model_t m, int compute_tendencies_flag) {

@@ -253,9 +253,20 @@ extern "C" int ocn_dist_barrier(ocn_dist_t d) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the partitioned model: NonhydrostaticModel on Distributed(GPU(); partition = Partition(R)) (x-slabs)
 // ---------------------------------------------------------------------------------------------------------------------
+// Irregular partition: the gathered solve (see gather_assemble_kernel). Memory and traffic grow with the GLOBAL grid on every rank --
+// the fallback for slab sizes the transposing / substructured solvers do not take, not the scaling path.
+struct GatheredSolve {
+    ocn_grid_s *ggrid = nullptr;        // the global grid, x Periodic
+    ocn_poisson_s *solver = nullptr;    // the single-GPU solver on it
+    double *loc = nullptr, *all = nullptr, *gp = nullptr;   // own source term (nmax, Ny, Nz); all ranks' (.., R); global haloed solution
+    SlabTable table = {};
+    int nmax = 0, Nxg = 0;
+};
+
 struct DistModel {
     ocn_dist_t dist = nullptr;
     ocn_dist_poisson_t solver = nullptr;
+    GatheredSolve *gs = nullptr;
     double *ws = nullptr, *es = nullptr, *wr = nullptr, *er = nullptr;     // halo buffers: Hx columns of every prognostic field per side
     size_t slab_total = 0;
     double *p2 = nullptr;                                                   // the solver's raw solution (p dt); the correction passes write p / dt into the model's pressure
@@ -272,6 +283,12 @@ struct DistModel {
 static void dist_model_free(DistModel *dm) {
     if (!dm) return;
     ocn_dist_poisson_destroy(dm->solver);
+    if (dm->gs) {
+        ocn_poisson_destroy(dm->gs->solver);
+        ocn_grid_destroy(dm->gs->ggrid);
+        hipFree(dm->gs->loc); hipFree(dm->gs->all); hipFree(dm->gs->gp);
+        delete dm->gs;
+    }
     hipFree(dm->ws); hipFree(dm->es); hipFree(dm->wr); hipFree(dm->er); hipFree(dm->p2); hipFree(dm->buf_a);
     if (dm->buf_b != dm->buf_a) hipFree(dm->buf_b);
     delete dm;
@@ -304,8 +321,31 @@ static int dist_fill_halo_regions(ocn_model_s *m, double *const *fields, const i
 // solve_for_pressure! + solve!(::DistributedFFTBasedPoissonSolver | ::DistributedFourierTridiagonalPoissonSolver)
 static int dist_solve_for_pressure(ocn_model_s *m) {
     DistModel *dm = m->dm;
-    ocn_dist_poisson_s *s = dm->solver;
     int rc;
+    if (dm->gs) {
+        // irregular partition: every rank gathers the whole source term and runs the single-GPU solver on the global grid
+        GatheredSolve *q = dm->gs;
+        const DGrid &g = m->grid->d, &G = q->ggrid->d;
+        ocn_poisson_s *ps = q->solver;
+        const size_t piece = (size_t)q->nmax * g.Ny * g.Nz;
+        if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], q->loc, ps->kind == 1, true, q->nmax, (long)q->nmax * g.Ny))) return rc;
+        if ((rc = ocn_dist_all_gather(dm->dist, q->loc, q->all, piece))) return rc;
+        const bool real_path = g_real_fft && !ps->general;
+        if (!real_path && (rc = ensure_complex(ps))) return rc;
+        if (real_path)
+            hipLaunchKernelGGL(gather_assemble_kernel<false>, grid3(G.Nx, G.Ny, G.Nz, BLK), BLK, 0, g_stream, (const double *)q->all, (void *)ps->rrhs,
+                               q->table, q->nmax, G.Nx, G.Ny, G.Nz);
+        else
+            hipLaunchKernelGGL(gather_assemble_kernel<true>, grid3(G.Nx, G.Ny, G.Nz, BLK), BLK, 0, g_stream, (const double *)q->all,
+                               (void *)(ps->kind == 0 ? ps->storage : ps->source), q->table, q->nmax, G.Nx, G.Ny, G.Nz);
+        KERNEL_CHECK();
+        if ((rc = real_path ? poisson_solve_real(ps, q->gp) : poisson_solve(ps, q->gp))) return rc;
+        hipLaunchKernelGGL(slab_extract_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, dm->p2, LOC_C),
+                           make_view(G, q->gp, LOC_C), q->table.first[dm->dist->rank]);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
+    ocn_dist_poisson_s *s = dm->solver;
     if ((rc = ocn_dist_poisson_source_term(s, m->U[0], m->U[1], m->U[2]))) return rc;
     if (s->sub) {
         // z Periodic: substructured solve along the partitioned direction -- local transforms and sweeps, one small all-gather
@@ -416,7 +456,55 @@ static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow)
 
 // NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected
 // (OCN_CONNECTED) when the direction is partitioned; `Lx_global`: extent of the global domain along x (the solver's eigenvalues)
+static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes);
 extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global) {
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, nullptr);
+}
+// the same for an irregular partition: local_sizes[r] = Nx of rank r (local_size, distributed_grids.jl:44-58: N ÷ R cells per rank and
+// the remainder on the last one; or any `Sizes`). Equal sizes take the solvers above; otherwise the pressure solve gathers the source
+// term on every rank and runs the single-GPU solver on the global grid (correct for every slab layout, but its memory and traffic
+// grow with the global grid: a fallback, not the scaling path).
+extern "C" int ocn_dist_model_create_sizes(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                           const int *local_sizes) {
+    if (!local_sizes) return fail(OCN_EINVAL, "NULL argument");
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, local_sizes);
+}
+
+static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes) {
+    const DGrid &g = local_grid->d;
+    const int R = dm->dist->world;
+    if (R > OCN_MAX_RANKS) return fail(OCN_ENOTSUP, "irregular partitions take at most %d ranks", OCN_MAX_RANKS);
+    GatheredSolve *q = new GatheredSolve();
+    dm->gs = q;
+    q->table.R = R;
+    for (int r = 0; r < R; ++r) {
+        if (sizes[r] < g.Hx) return fail(OCN_EINVAL, "rank %d holds %d columns, fewer than the halo %d", r, sizes[r], g.Hx);
+        q->table.first[r] = q->Nxg;
+        q->Nxg += sizes[r];
+        q->nmax = std::max(q->nmax, sizes[r]);
+    }
+    q->table.first[R] = q->Nxg;
+    if (sizes[dm->dist->rank] != g.Nx) return fail(OCN_EINVAL, "local_sizes[%d] = %d but the local grid has Nx = %d", dm->dist->rank, sizes[dm->dist->rank], g.Nx);
+    const int N[3] = {q->Nxg, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {OCN_PERIODIC, g.ty, g.tz};
+    const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
+    const bool zr = local_grid->z_regular;
+    int rc = ocn_grid_create(&q->ggrid, N, H, topo, L, Lx_global / (double)q->Nxg, g.dy, local_grid->h_dzc[g.Hz],
+                             zr ? nullptr : local_grid->h_dzc.data(), zr ? nullptr : local_grid->h_dzf.data());
+    if (rc) return rc;
+    if ((rc = ocn_poisson_create(&q->solver, q->ggrid, -1))) return rc;
+    int P[3];
+    parent_size(q->ggrid->d, LOC_C, P);
+    const size_t piece = (size_t)q->nmax * g.Ny * g.Nz;
+    HIP_TRY(dev_alloc((void **)&q->loc, piece * sizeof(double)));
+    HIP_TRY(dev_alloc((void **)&q->all, piece * (size_t)R * sizeof(double)));
+    HIP_TRY(dev_alloc((void **)&q->gp, (size_t)P[0] * P[1] * P[2] * sizeof(double)));
+    HIP_TRY(hipMemsetAsync(q->loc, 0, piece * sizeof(double), g_stream));
+    HIP_TRY(hipMemsetAsync(q->all, 0, piece * (size_t)R * sizeof(double), g_stream));
+    HIP_TRY(hipMemsetAsync(q->gp, 0, (size_t)P[0] * P[1] * P[2] * sizeof(double), g_stream));
+    return OCN_OK;
+}
+
+static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes) {
     NEED_INIT();
     if (!model || !local_grid || !dist) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
@@ -444,6 +532,14 @@ extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, 
         hipError_t e = dev_alloc((void **)&dm->p2, bytes);
         if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(p2): %s", hipGetErrorString(e)));
         hipMemsetAsync(dm->p2, 0, bytes, g_stream);
+    }
+    bool irregular = false;
+    if (local_sizes)
+        for (int r = 0; r < dist->world; ++r) irregular = irregular || local_sizes[r] != local_sizes[0];
+    if (irregular) {
+        if (dist->self_loop) return bail(fail(OCN_EINVAL, "self_loop has one slab"));
+        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes))) return bail(rc);
+        return OCN_OK;
     }
     if ((rc = ocn_dist_poisson_create(&dm->solver, local_grid, dist->world, dist->rank, Lx_global))) return bail(rc);
     size_t n = 0;

@@ -469,6 +469,7 @@ struct EpilogueArgs {
     bool any_flux;
     bool has_flux[OCN_MAX_FIELDS][6];
     double flux[OCN_MAX_FIELDS][6];
+    const double *flux_arr[OCN_MAX_FIELDS][6];  // array-valued Flux conditions (null: the number above)
     int loc[OCN_MAX_FIELDS][3];
     // linear field-dependent Flux conditions flux = a + b φ (linear_flux_bc_kernel), applied after the valued ones in (field, side)
     // order like the stand-alone launches
@@ -509,8 +510,16 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             const double area = d == 0 ? g.dy * dz : (d == 1 ? g.dx * dz : g.dx * g.dy);
-            if (a.has_flux[f][2 * d] && idx[d] == 1) G += a.flux[f][2 * d] * area / vol;
-            if (a.has_flux[f][2 * d + 1] && idx[d] == N[d]) G -= a.flux[f][2 * d + 1] * area / vol;
+            // tangential point of the condition: (j, k) on west / east, (i, k) on south / north, (i, j) on bottom / top
+            const long ab = d == 0 ? (long)(j - 1) + (long)g.Ny * (k - 1) : (d == 1 ? (long)(i - 1) + (long)g.Nx * (k - 1) : (long)(i - 1) + (long)g.Nx * (j - 1));
+            if (a.has_flux[f][2 * d] && idx[d] == 1) {
+                const double *fa = a.flux_arr[f][2 * d];
+                G += (fa ? fa[ab] : a.flux[f][2 * d]) * area / vol;
+            }
+            if (a.has_flux[f][2 * d + 1] && idx[d] == N[d]) {
+                const double *fa = a.flux_arr[f][2 * d + 1];
+                G -= (fa ? fa[ab] : a.flux[f][2 * d + 1]) * area / vol;
+            }
         }
     }
     for (int n = 0; n < a.nlin; ++n) {
@@ -607,7 +616,13 @@ __global__ void __launch_bounds__(256) fill_periodic_xyz_kernel(FieldList fl, in
 struct BcSides {
     int kind[OCN_MAX_FIELDS][2];      // [field][lo | hi], OCN_BC_*
     double value[OCN_MAX_FIELDS][2];
+    const double *arr[OCN_MAX_FIELDS][2];   // array-valued condition (getbc(::AbstractArray, i, j), boundary_condition.jl:164) or null
     double dlo, dhi;                  // spacing at the boundary faces (Δ between the first interior and the first halo point)
+    // the condition at tangential interior point (a, b) (1-based) of a dense (Na, .) array, or the number
+    __device__ __forceinline__ double get(int f, int side, long ab) const {
+        const double *p = arr[f][side];
+        return p ? p[ab] : value[f][side];
+    }
 };
 
 template <int D>
@@ -620,21 +635,22 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides
     if (D == 0) { lo = view.lin(face ? 1 : 0, a, b); ilo = view.lin(1, a, b); hi = view.lin(N + 1, a, b); ihi = view.lin(N, a, b); }
     else if (D == 1) { lo = view.lin(a, face ? 1 : 0, b); ilo = view.lin(a, 1, b); hi = view.lin(a, N + 1, b); ihi = view.lin(a, N, b); }
     else { lo = view.lin(a, b, face ? 1 : 0); ilo = view.lin(a, b, 1); hi = view.lin(a, b, N + 1); ihi = view.lin(a, b, N); }
+    const long ab = (long)(a - 1) + (long)Na * (b - 1);
     for (int f = 0; f < fl.n; ++f) {
         double *p = fl.p[f];
         if (!face) {
             const double c1 = p[ilo], cN = p[ihi];
             const int kl = bc.kind[f][0], kh = bc.kind[f][1];
             double h0 = c1, h1 = cN;
-            if (kl == OCN_BC_VALUE) h0 = c1 + ((c1 - bc.value[f][0]) / (bc.dlo / 2)) * (-bc.dlo);
-            else if (kl == OCN_BC_GRADIENT) h0 = c1 + bc.value[f][0] * (-bc.dlo);
-            if (kh == OCN_BC_VALUE) h1 = cN + ((bc.value[f][1] - cN) / (bc.dhi / 2)) * bc.dhi;
-            else if (kh == OCN_BC_GRADIENT) h1 = cN + bc.value[f][1] * bc.dhi;
+            if (kl == OCN_BC_VALUE) h0 = c1 + ((c1 - bc.get(f, 0, ab)) / (bc.dlo / 2)) * (-bc.dlo);
+            else if (kl == OCN_BC_GRADIENT) h0 = c1 + bc.get(f, 0, ab) * (-bc.dlo);
+            if (kh == OCN_BC_VALUE) h1 = cN + ((bc.get(f, 1, ab) - cN) / (bc.dhi / 2)) * bc.dhi;
+            else if (kh == OCN_BC_GRADIENT) h1 = cN + bc.get(f, 1, ab) * bc.dhi;
             p[lo] = h0;
             p[hi] = h1;
         } else if (fill_open) {
-            p[lo] = bc.kind[f][0] == OCN_BC_OPEN ? bc.value[f][0] : 0.0;
-            p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.value[f][1] : 0.0;
+            p[lo] = bc.kind[f][0] == OCN_BC_OPEN ? bc.get(f, 0, ab) : 0.0;
+            p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.get(f, 1, ab) : 0.0;
         }
     }
 }
@@ -650,7 +666,8 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides
 // fields always; Face fields when fill_open_bcs). An x-slab rank (x halos owned by the neighbours) passes H0 = 0, N0 = P0 and XC = Hx:
 // its XC outermost columns are left to the exchange -- in the z-boundary planes they only take part in the periodic y copy.
 __global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldList fl, BcSides bc, int P0, int P1, int P2, int N0, int N1,
-                                                                         int N2, int H0, int H1, int H2, bool face, bool zfill, int XC) {
+                                                                         int N2, int H0, int H1, int H2, bool face, bool zfill, int XC,
+                                                                         int NA) {
     const int klo = face ? H2 : H2 - 1, khi = N2 + H2;                       // 0-based parent planes of the z fill
     const long nA = zfill ? (long)P0 * P1 * 2 : 0;
     const int nplanes = P2 - (zfill ? 2 : 0);
@@ -668,20 +685,21 @@ __global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldLi
             for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
             return;
         }
+        const long ab = (long)(si - H0 - XC) + (long)NA * (sj - H1);        // tangential interior point (i, j) of the source column
         for (int f = 0; f < fl.n; ++f) {
             double *p = fl.p[f];
             double val;
-            if (face) val = bc.kind[f][side] == OCN_BC_OPEN ? bc.value[f][side] : 0.0;
+            if (face) val = bc.kind[f][side] == OCN_BC_OPEN ? bc.get(f, side, ab) : 0.0;
             else {
                 const double c = p[col + plane * (side ? N2 + H2 - 1 : H2)];         // first / last interior cell of the column
                 const int kd = bc.kind[f][side];
                 val = c;
                 if (side == 0) {
-                    if (kd == OCN_BC_VALUE) val = c + ((c - bc.value[f][0]) / (bc.dlo / 2)) * (-bc.dlo);
-                    else if (kd == OCN_BC_GRADIENT) val = c + bc.value[f][0] * (-bc.dlo);
+                    if (kd == OCN_BC_VALUE) val = c + ((c - bc.get(f, 0, ab)) / (bc.dlo / 2)) * (-bc.dlo);
+                    else if (kd == OCN_BC_GRADIENT) val = c + bc.get(f, 0, ab) * (-bc.dlo);
                 } else {
-                    if (kd == OCN_BC_VALUE) val = c + ((bc.value[f][1] - c) / (bc.dhi / 2)) * bc.dhi;
-                    else if (kd == OCN_BC_GRADIENT) val = c + bc.value[f][1] * bc.dhi;
+                    if (kd == OCN_BC_VALUE) val = c + ((bc.get(f, 1, ab) - c) / (bc.dhi / 2)) * bc.dhi;
+                    else if (kd == OCN_BC_GRADIENT) val = c + bc.get(f, 1, ab) * bc.dhi;
                 }
             }
             p[od] = val;
@@ -707,7 +725,7 @@ __global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldLi
 // the two other dims. area / volume evaluated per cell by the caller-provided metric look-ups.
 template <int D>
 __global__ void __launch_bounds__(256) flux_bc_kernel(DGrid g, FView G, int Na, int Nb, int N, int lx, int ly, int lz, bool has_lo,
-                                                      double flo, bool has_hi, double fhi) {
+                                                      double flo, bool has_hi, double fhi, const double *alo, const double *ahi) {
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)Na * Nb) return;
     const int a = 1 + t % Na, b = 1 + t / Na;
@@ -719,7 +737,8 @@ __global__ void __launch_bounds__(256) flux_bc_kernel(DGrid g, FView G, int Na, 
         const double dz = lz == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
         const double vol = (dx * dy) * dz;          // volume = Az * Δz
         const double area = D == 0 ? dy * dz : (D == 1 ? dx * dz : dx * dy);
-        const double flux = side ? fhi : flo;
+        const double *arr = side ? ahi : alo;
+        const double flux = arr ? arr[(long)(a - 1) + (long)Na * (b - 1)] : (side ? fhi : flo);
         double &Gq = G.at(i, j, k);
         if (side) Gq -= flux * area / vol;
         else      Gq += flux * area / vol;
@@ -1011,6 +1030,36 @@ __global__ void __launch_bounds__(256) copy_dense_real_kernel(DGrid g, FView phi
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
     phi.at(i, j, k) = src[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Irregular x partitions (remainder columns on the last rank, distributed_grids.jl:44-58): the gathered pressure solve. Every rank
+// contributes its source term with rows padded to the widest slab (nmax columns); assemble the global dense right-hand side from
+// the R gathered pieces, and -- after the single-GPU solver ran on it -- take the own slab back out of the global solution.
+// first[q] = global index (0-based) of rank q's first column, first[R] = Nx_global.
+// ---------------------------------------------------------------------------------------------------------------------
+#define OCN_MAX_RANKS 64
+struct SlabTable { int first[OCN_MAX_RANKS + 1]; int R; };
+template <bool COMPLEX>
+__global__ void __launch_bounds__(256) gather_assemble_kernel(const double *all, void *dst, SlabTable t, int nmax, int Nxg, int Ny, int Nz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = blockIdx.z;
+    if (i >= Nxg || j >= Ny || k >= Nz) return;
+    int q = 0;
+    while (q + 1 < t.R && i >= t.first[q + 1]) ++q;
+    const double v = all[(size_t)(i - t.first[q]) + (size_t)nmax * (j + (size_t)Ny * (k + (size_t)Nz * q))];
+    const size_t d = (size_t)i + (size_t)Nxg * (j + (size_t)Ny * k);
+    if (COMPLEX) ((double2 *)dst)[d] = make_double2(v, 0.0);
+    else ((double *)dst)[d] = v;
+}
+// local haloed phi(i, j, k) = global haloed gphi(off + i, j, k) over the local interior
+__global__ void __launch_bounds__(256) slab_extract_kernel(DGrid g, FView phi, FView gphi, int off) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    phi.at(i, j, k) = gphi.at(off + i, j, k);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -24,6 +24,9 @@
 #ifndef OCN_ROLE_TY
 #define OCN_ROLE_TY 7         // rows of a tile = row waves of a workgroup (+ 1 edge wave)
 #endif
+#ifndef OCN_ROLE_PF
+#define OCN_ROLE_PF 1         // planes the two cold streams (new z-window level, previous tendency) are fetched ahead of their use
+#endif
 #ifndef OCN_ROLE_ABLATE
 #define OCN_ROLE_ABLATE 0     // timing experiments only (WRONG RESULTS when non-zero): 1 hot z-window load, 2 no previous-tendency load,
 #endif                        // 4 no stores, 8 x / y windows from registers, 16 no barrier, 32 idle edge wave
@@ -259,6 +262,7 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     const unsigned cell_off = cell_r ? 0u : ROLE_OOB;
 
     double fz_prev = 0, qn = 0, gmn = 0;
+    double qnn = 0, gmnn = 0;                         // OCN_ROLE_PF == 2: the same streams one more plane ahead
     Win6 qz;                                          // own 6-deep z-window (role w reads the z-windows of u, v from memory:
                                                       // kept in registers they cost 20 VGPRs and spilled)
 #pragma unroll
@@ -267,6 +271,8 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
 #pragma unroll
         for (int n = 0; n < 5; ++n) qz.s[n + 1] = ldb<24>(p.q, o.c, p.so + (unsigned)(n - 3) * s2);   // levels kc0-3 .. kc0+1
         qn = ldb<24>(p.q, o.c, p.so + 2u * s2);                                                        // level kc0+2
+        if (OCN_ROLE_PF == 2) qnn = ldb<24>(p.q, o.c, p.so + 3u * s2);                                 // level kc0+3 (inside the halo)
+        if (SUB && OCN_ROLE_PF == 2 && !edge) gmnn = ldb_once<24>(rGm, o.c | cell_off, p.so);          // level kc0: closed in plane kc0+1
     }
 
     // The edge wave and the row waves run SEPARATE loops over the same planes (one barrier per plane in each): loop-carried values
@@ -316,7 +322,9 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
 #pragma unroll
         for (int n = 0; n < 5; ++n) vmov(qz.s[n], qz.s[n + 1]);
         vmov(qz.s[5], qn);
+        if (OCN_ROLE_PF == 2) vmov(qn, qnn);
         if (SUB) vmov(gm, gmn);
+        if (SUB && OCN_ROLE_PF == 2) vmov(gmn, gmnn);
         zin = load_zin<ROLE>(p, p.so, o);
     };
     auto z_compute = [&](const int k, const int buf, const long pk) {
@@ -363,6 +371,12 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
             yaux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
         };
         auto prefetches = [&]() {
+            if (OCN_ROLE_PF == 2) {
+                // level k + 4 exists only while k + 1 <= kc1 can still use it (k + 4 <= Nz + Hz); the last plane re-reads level k + 3
+                qnn = ldb<24>(p.q, o.c, (OCN_ROLE_ABLATE & 1) ? p.so : p.so + (k < kc1 ? 4u : 3u) * s2);
+                if (SUB && !(OCN_ROLE_ABLATE & 2)) gmnn = ldb_once<24>(rGm, o.c | cell_off, p.so + s2);   // level k + 1: closed in plane k + 2
+                return;
+            }
             qn = ldb<24>(p.q, o.c, (OCN_ROLE_ABLATE & 1) ? p.so : p.so + 3u * s2);
             if (SUB && !(OCN_ROLE_ABLATE & 2)) gmn = ldb_once<24>(rGm, o.c | cell_off, p.so);          // level k: closed in plane k + 1
         };

@@ -133,4 +133,4 @@ def fill_halo_regions(fields, fill_open_bcs=True, boundary_conditions=None):
     if len(boundary_conditions) != len(fields):
         raise ValueError("one FieldBoundaryConditions (or None) per field")
     _lib.check(_lib.lib().ocn_fill_halo_regions_bcs(grid.handle, _ptr_array(fields), _loc_array(fields), len(fields),
-                                                    bc_table(list(boundary_conditions)), int(fill_open_bcs)))
+                                                    bc_table(list(boundary_conditions), grid), int(fill_open_bcs)))

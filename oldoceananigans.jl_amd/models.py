@@ -127,6 +127,12 @@ class NonhydrostaticModel:
                     _lib.check(_lib.lib().ocn_model_set_linear_flux_bc(self.handle, self._cname(name).encode(), SIDES.index(side), a, b,
                                                                        self._cname(dep).encode()))
                     continue
+                if bc.array is not None:
+                    from .boundary_conditions import _tangential_shape
+                    dev = bc.device_array(_tangential_shape(self.grid, SIDES.index(side)))      # borrowed by the library: `bc` is kept
+                    _lib.check(_lib.lib().ocn_model_set_boundary_condition_array(self.handle, self._cname(name).encode(), SIDES.index(side),
+                                                                                 KINDS[bc.classification], dev))
+                    continue
                 _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, self._cname(name).encode(), SIDES.index(side),
                                                                        KINDS[bc.classification], bc.condition))
 

@@ -109,17 +109,29 @@ static void fill_periodic(const oro_grid *g, double *c, const int loc[3], int d)
 /* fill_halo_regions_flux.jl:9-27 (no-flux mirror, ONE halo cell) and fill_halo_regions_open.jl:2-7 (impenetrable wall
  * value on Face fields), launched over the interior extent of the other two dims (`:xy` etc., fill_halo_kernels.jl:69-70,
  * Utils/kernel_launching.jl:211-221). */
+/* getbc (boundary_condition.jl:156-164): a number, or condition[i, j] with (i, j) the interior indices along the two tangential
+ * directions of side direction d, in the order x before y before z; q = (i, j, k) of the boundary-adjacent cell */
+static inline double getbc(const oro_grid *g, const oro_bc *bc, int d, const int q[3]) {
+    if (!bc->array) return bc->value;
+    const int t1 = d == 0 ? 1 : 0, t2 = d == 2 ? 1 : 2;
+    return bc->array[(size_t)(q[t1] - 1) + (size_t)g->N[t1] * (size_t)(q[t2] - 1)];
+}
+
 static void fill_bounded(const oro_grid *g, double *c, const int loc[3], int d, int fill_open_bcs, const oro_bc *bcs) {
     fld f = mkfld(g, c, loc);
     const int N = g->N[d];
     int d1 = (d + 1) % 3, d2 = (d + 2) % 3;
-    const oro_bc lo_bc = bcs ? bcs[2 * d] : (oro_bc){ORO_BC_DEFAULT, 0.0};
-    const oro_bc hi_bc = bcs ? bcs[2 * d + 1] : (oro_bc){ORO_BC_DEFAULT, 0.0};
+    const oro_bc lo_src = bcs ? bcs[2 * d] : (oro_bc){ORO_BC_DEFAULT, 0.0, NULL};
+    const oro_bc hi_src = bcs ? bcs[2 * d + 1] : (oro_bc){ORO_BC_DEFAULT, 0.0, NULL};
     for (int b = 1; b <= g->N[d2]; ++b)
         for (int a = 1; a <= g->N[d1]; ++a) {
             int lo[3], hi[3], ilo[3], ihi[3];
             lo[d1] = hi[d1] = ilo[d1] = ihi[d1] = a;
             lo[d2] = hi[d2] = ilo[d2] = ihi[d2] = b;
+            ilo[d] = 1;
+            oro_bc lo_bc = lo_src, hi_bc = hi_src;          /* the condition at this boundary point */
+            lo_bc.value = getbc(g, &lo_src, d, ilo);
+            hi_bc.value = getbc(g, &hi_src, d, ilo);
             if (loc[d] == ORO_CENTER) {
                 lo[d] = 0; ilo[d] = 1; hi[d] = N + 1; ihi[d] = N;
                 double *h0 = &AT(f, lo[0], lo[1], lo[2]), *h1 = &AT(f, hi[0], hi[1], hi[2]);
@@ -183,8 +195,9 @@ void oro_compute_flux_bcs(const oro_grid *g, double *Gc, const int loc[3], const
                     else if (d == 1) area = spacing(g, 0, loc[0], q[0]) * spacing(g, 2, loc[2], q[2]);                 /* Ay = Δx Δz */
                     else             area = spacing(g, 0, loc[0], q[0]) * spacing(g, 1, loc[1], q[1]);                 /* Az = Δx Δy */
                     (void)fidx;      /* x / y spacings are uniform and Az does not depend on k: the flipped index only matters on curvilinear grids */
-                    if (side) AT(G, q[0], q[1], q[2]) -= bc.value * area / vol;
-                    else      AT(G, q[0], q[1], q[2]) += bc.value * area / vol;
+                    const double flux = getbc(g, &bc, d, q);
+                    if (side) AT(G, q[0], q[1], q[2]) -= flux * area / vol;
+                    else      AT(G, q[0], q[1], q[2]) += flux * area / vol;
                 }
             }
     }
@@ -1353,7 +1366,13 @@ void oro_model_field_loc(oro_model *m, const char *name, int loc[3]) {
 
 /* FieldBoundaryConditions validation (field_boundary_conditions.jl, boundary_condition.jl): Flux / Value / Gradient on
  * fields at Center along the boundary direction, Open on the wall-normal (Face) component, Bounded sides only */
-int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value) {
+static int model_set_bc(oro_model *m, const char *name, int side, int kind, double value, const double *array);
+int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value) { return model_set_bc(m, name, side, kind, value, NULL); }
+/* array-valued condition: `array` is borrowed and must outlive the model's use of it */
+int oro_model_set_bc_array(oro_model *m, const char *name, int side, int kind, const double *array) {
+    return array ? model_set_bc(m, name, side, kind, 0.0, array) : -1;
+}
+static int model_set_bc(oro_model *m, const char *name, int side, int kind, double value, const double *array) {
     char k;
     int f = field_index(m, name, &k);
     if (f < 0 || k != 'U' || side < 0 || side > 5) return -1;
@@ -1363,10 +1382,11 @@ int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double 
     if (kind < ORO_BC_DEFAULT || kind > ORO_BC_OPEN) return -1;
     m->bcs[f][side].kind = kind;
     m->bcs[f][side].value = value;
+    m->bcs[f][side].array = array;
     m->any_flux_bc = 0;
     for (int q = 0; q < 3 + m->ntr; ++q)
         for (int sd = 0; sd < 6; ++sd)
-            if (m->bcs[q][sd].kind == ORO_BC_FLUX && m->bcs[q][sd].value != 0.0) m->any_flux_bc = 1;
+            if (m->bcs[q][sd].kind == ORO_BC_FLUX && (m->bcs[q][sd].value != 0.0 || m->bcs[q][sd].array)) m->any_flux_bc = 1;
     return 0;
 }
 

@@ -70,7 +70,9 @@ void oro_fill_halo_regions(const oro_grid *g, double *c, const int loc[3], int f
  * fill_halo_regions_value_gradient.jl:7-119, fill_halo_regions_flux.jl:9-27, fill_halo_regions_open.jl:2-7,
  * compute_flux_bcs.jl:57-163). Sides are ordered west, east, south, north, bottom, top. */
 enum { ORO_BC_DEFAULT = 0, ORO_BC_FLUX = 1, ORO_BC_VALUE = 2, ORO_BC_GRADIENT = 3, ORO_BC_OPEN = 4 };
-typedef struct { int kind; double value; } oro_bc;
+/* array != NULL: getbc(condition::AbstractArray, i, j, grid, args...) = condition[i, j] (BoundaryConditions/boundary_condition.jl:164):
+ * a dense column-major array over the interior extents of the two tangential directions (x before y before z) replaces `value` */
+typedef struct { int kind; double value; const double *array; } oro_bc;
 void oro_fill_halo_regions_bcs(const oro_grid *g, double *c, const int loc[3], const oro_bc bcs[6], int fill_open_bcs);
 /* compute_x/y/z_bcs!: adds the flux divergence of Flux boundary conditions to the tendency G of a field at loc */
 void oro_compute_flux_bcs(const oro_grid *g, double *G, const int loc[3], const oro_bc bcs[6]);
@@ -131,6 +133,7 @@ double *oro_model_field(oro_model *m, const char *name); /* "u","v","w","c0".., 
 void oro_model_field_loc(oro_model *m, const char *name, int loc[3]);
 /* side 0..5 = west, east, south, north, bottom, top; returns 0, or -1 for an invalid combination */
 int oro_model_set_bc(oro_model *m, const char *name, int side, int kind, double value);
+int oro_model_set_bc_array(oro_model *m, const char *name, int side, int kind, const double *array);   /* borrowed */
 /* buoyancy: kind 0 nothing; 1 BuoyancyTracer (tracer index b); 2 SeawaterBuoyancy with LinearEquationOfState
  * (tracer indices T, S; b = g (α T - β S)). The model then carries the hydrostatic pressure anomaly "pHY". */
 int oro_model_set_buoyancy(oro_model *m, int kind, int b_or_T_index, int S_index, double grav, double alpha, double beta);

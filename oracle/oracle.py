@@ -68,6 +68,7 @@ def lib():
         L.oro_fill_halo_regions_bcs.argtypes = [vp, dp, ip, C.POINTER(BC), C.c_int]
         L.oro_compute_flux_bcs.argtypes = [vp, dp, ip, C.POINTER(BC)]
         L.oro_model_set_bc.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, C.c_double]
+        L.oro_model_set_bc_array.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp]
         L.oro_model_set_closure.argtypes = [vp, C.c_double, dp]
         L.oro_model_set_coriolis.argtypes = [vp, C.c_int, C.c_double]
         L.oro_add_fplane_coriolis.argtypes = [vp, C.c_double, dp, dp, dp, dp]
@@ -130,7 +131,7 @@ def lib():
 
 class BC(C.Structure):
     """oro_bc: constant-valued boundary condition on one side"""
-    _fields_ = [("kind", C.c_int), ("value", C.c_double)]
+    _fields_ = [("kind", C.c_int), ("value", C.c_double), ("array", C.c_void_p)]
 
 
 BC_KINDS = {"default": 0, "flux": 1, "value": 2, "gradient": 3, "open": 4}
@@ -140,9 +141,15 @@ SIDES = {"west": 0, "east": 1, "south": 2, "north": 3, "bottom": 4, "top": 5}
 def _bcs(bcs):
     """dict side -> (kind, value)  ->  oro_bc[6]"""
     arr = (BC * 6)()
+    arr._keep = []                 # array-valued conditions: (N_a, N_b) Fortran-ordered float64, kept alive with the struct
     for side, (kind, value) in (bcs or {}).items():
         arr[SIDES[side]].kind = BC_KINDS[kind]
-        arr[SIDES[side]].value = float(value)
+        if isinstance(value, np.ndarray):
+            a = np.asfortranarray(value, dtype=np.float64)
+            arr._keep.append(a)
+            arr[SIDES[side]].array = a.ctypes.data
+        else:
+            arr[SIDES[side]].value = float(value)
     return arr
 
 
@@ -372,8 +379,15 @@ class Model:
             raise ValueError(f"invalid field-dependent flux condition on the {side} side of {name} (dependency {dep})")
 
     def set_bc(self, name, side, kind, value=0.0):
-        """field boundary condition with a constant value: kind in flux | value | gradient | open | default"""
-        if lib().oro_model_set_bc(self.handle, name.encode(), SIDES[side], BC_KINDS[kind], float(value)) != 0:
+        """field boundary condition with a constant value or a 2-D array of per-point values: kind in flux | value | gradient | open |
+        default"""
+        if isinstance(value, np.ndarray):
+            a = np.asfortranarray(value, dtype=np.float64)
+            self._bc_arrays = getattr(self, "_bc_arrays", []) + [a]           # borrowed by the C model
+            rc = lib().oro_model_set_bc_array(self.handle, name.encode(), SIDES[side], BC_KINDS[kind], a.ctypes.data)
+        else:
+            rc = lib().oro_model_set_bc(self.handle, name.encode(), SIDES[side], BC_KINDS[kind], float(value))
+        if rc != 0:
             raise ValueError(f"invalid boundary condition {kind} on the {side} side of {name}")
 
     def set(self, enforce_incompressibility=True, **fields):

@@ -274,3 +274,68 @@ def test_adapted_model_time_steps_and_is_direction_symmetric(oracle, perm):
     assert np.max(np.abs(c - c_ref)) < 1e-12 * np.max(np.abs(c_ref))
     for a, b in zip(vel, vel_ref):
         assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(b))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# array-valued boundary conditions: getbc(condition::AbstractArray, i, j, grid, args...) = condition[i, j]
+# (src/BoundaryConditions/boundary_condition.jl:164; used by compute_flux_bcs.jl:114-163 and fill_halo_regions_value_gradient.jl:7-119)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_array_valued_conditions_reduce_to_numbers_and_index_the_tangential_point(oracle):
+    O = oracle
+    N = (6, 5, 4)
+    g = O.Grid(N, topology=(O.BOUNDED, O.BOUNDED, O.BOUNDED), z=(-1.0, 0.0))
+    rng = np.random.default_rng(8)
+    loc = O.LOC["c"]
+    shape = {"west": (N[1], N[2]), "east": (N[1], N[2]), "south": (N[0], N[2]), "north": (N[0], N[2]), "bottom": (N[0], N[1]), "top": (N[0], N[1])}
+    kinds = {"west": "value", "east": "gradient", "south": "gradient", "north": "value", "bottom": "value", "top": "gradient"}
+    # 1. an array filled with one number gives the bits of the number
+    c0 = np.asfortranarray(rng.standard_normal(g.parent_size(loc)))
+    a, b = c0.copy(order="F"), c0.copy(order="F")
+    g.fill_halo_regions(a, loc, True, bcs={s: (k, 0.37) for s, k in kinds.items()})
+    g.fill_halo_regions(b, loc, True, bcs={s: (k, np.full(shape[s], 0.37)) for s, k in kinds.items()})
+    assert np.array_equal(a, b)
+    # 2. a varying array: the halo cell behind boundary point (i, j) follows condition[i, j]
+    arrs = {s: rng.standard_normal(shape[s]) for s in kinds}
+    c = c0.copy(order="F")
+    g.fill_halo_regions(c, loc, True, bcs={s: (kinds[s], arrs[s]) for s in kinds})
+    H = 3
+    I = (slice(H, H + N[0]), slice(H, H + N[1]), slice(H, H + N[2]))
+    dx, dy, dz = 1.0 / N[0], 1.0 / N[1], 1.0 / N[2]
+    assert np.allclose((c[H - 1, I[1], I[2]] + c[H, I[1], I[2]]) / 2, arrs["west"], rtol=0, atol=1e-13)
+    assert np.allclose((c[H + N[0], I[1], I[2]] - c[H + N[0] - 1, I[1], I[2]]) / dx, arrs["east"], rtol=0, atol=1e-12)
+    assert np.allclose((c[I[0], H, I[2]] - c[I[0], H - 1, I[2]]) / dy, arrs["south"], rtol=0, atol=1e-12)
+    assert np.allclose((c[I[0], H + N[1], I[2]] + c[I[0], H + N[1] - 1, I[2]]) / 2, arrs["north"], rtol=0, atol=1e-13)
+    assert np.allclose((c[I[0], I[1], H - 1] + c[I[0], I[1], H]) / 2, arrs["bottom"], rtol=0, atol=1e-13)
+    assert np.allclose((c[I[0], I[1], H + N[2]] - c[I[0], I[1], H + N[2] - 1]) / dz, arrs["top"], rtol=0, atol=1e-12)
+    # 3. Flux arrays: G[1] += flux[i, j] A / V, G[N] -= flux[i, j] A / V (compute_flux_bcs.jl:57-163)
+    G = g.zeros(loc)
+    fl = {"west": rng.standard_normal(shape["west"]), "top": rng.standard_normal(shape["top"])}
+    g.compute_flux_bcs(G, loc, {s: ("flux", fl[s]) for s in fl})
+    Gi = g.interior_cells(G)
+    expect = np.zeros(N)
+    expect[0, :, :] += fl["west"] * (dy * dz) / ((dx * dy) * dz)
+    expect[:, :, -1] -= fl["top"] * (dx * dy) / ((dx * dy) * dz)
+    assert np.allclose(Gi, expect, rtol=1e-15, atol=0)
+    # Open arrays on the wall-normal component
+    w = g.zeros(O.LOC["w"])
+    top = rng.standard_normal(shape["top"])
+    g.fill_halo_regions(w, O.LOC["w"], True, bcs={"top": ("open", top)})
+    assert np.array_equal(w[H:H + N[0], H:H + N[1], H + N[2]], top)
+
+
+def test_array_flux_condition_budget(oracle):
+    """the flux budget of test/test_boundary_conditions_integration.jl:28-52 with a spatially varying flux array: after one RK3 step with
+    Δt = 1 from rest, mean(c) = -mean(flux_top) t / Lz (a tracer at rest is only moved by its boundary flux)"""
+    O = oracle
+    Lz = 0.5
+    g = O.Grid((4, 6, 4), topology=(O.PERIODIC, O.PERIODIC, O.BOUNDED), z=(0.0, Lz))
+    m = O.Model(g, 1)
+    rng = np.random.default_rng(1)
+    flux = rng.standard_normal((4, 6))
+    m.set_bc("c0", "top", "flux", flux)
+    m.set(**{n: 0.0 for n in m.names()})
+    m.time_step(1.0)
+    c = g.interior_cells(m.field("c0"))
+    assert abs(c.mean() - (-flux.mean() * m.time / Lz)) < 1e-13
+    # ... and column by column (nothing mixes the columns of a fluid at rest): the top cell of column (i, j) took -flux[i, j] t / Δz
+    assert np.allclose(c[:, :, -1], -flux * m.time / (Lz / 4), rtol=1e-13, atol=0)
