@@ -409,6 +409,12 @@ int ocn_dist_barrier(ocn_dist_t dist);                           /* synchronous 
  * exchange started from make_pressure_correction!, and solve! of the distributed solvers
  * (distributed_fft_based_poisson_solver.jl:141-178, distributed_fft_tridiagonal_solver.jl:153-257) -- entirely inside the library. */
 int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global);
+/* the same for an irregular partition (local_size, distributed_grids.jl:44-58: N / R columns per rank, the remainder on the last one;
+ * or any `Sizes`): local_sizes[r] = Nx of rank r. Equal sizes take the distributed solvers; otherwise solve! gathers the source term
+ * on every rank and runs the single-GPU solver on the global grid -- every slab layout works, memory and traffic grow with the
+ * GLOBAL grid (a fallback, not the scaling path). */
+int ocn_dist_model_create_sizes(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                const int *local_sizes);
 int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus

@@ -233,14 +233,24 @@ def init_process_group(local_rank=0, backend=None, rehearse_on_one_gpu=False, se
 # ----------------------------------------------------------------------------------------------------------------------
 # grid
 # ----------------------------------------------------------------------------------------------------------------------
+def local_sizes(N, R):
+    """local_size(N, R, local_index) for every rank (distributed_grids.jl:44-58): N ÷ R cells per rank, the remainder on the last"""
+    nl = [N // R] * R
+    nl[-1] += N - sum(nl)
+    return nl
+
+
 def partition_coordinate(c, n_local, R, r):
-    """partition_coordinate(c::Tuple, n, arch, dim) (partition_assemble.jl:57-70), equal local sizes"""
-    N = n_local * R
+    """partition_coordinate(c::Tuple, n, arch, dim) (partition_assemble.jl:63-76): Δl = (c₂ - c₁) / N, the intervals are chained
+    l[i] = (l[i-1][2], l[i-1][2] + Δl nl[i]). `n_local`: one size (equal slabs) or the list of all ranks' sizes."""
+    nl = [n_local] * R if isinstance(n_local, int) else list(n_local)
+    N = sum(nl)
     dl = (c[1] - c[0]) / N
-    lo = c[0]
-    for _ in range(r):
-        lo = lo + dl * n_local
-    return (lo, lo + dl * n_local)
+    lo, hi = c[0], c[0] + dl * nl[0]
+    for i in range(1, r + 1):
+        lo = hi
+        hi = lo + dl * nl[i]
+    return (lo, hi)
 
 
 class DistributedRectilinearGrid:
@@ -254,17 +264,18 @@ class DistributedRectilinearGrid:
         if extent is not None:
             x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
         self.global_size = tuple(int(n) for n in size)
-        if self.global_size[0] % R != 0:
-            raise ValueError(f"Nx = {size[0]} must be divisible by the number of ranks {R} (equal x-slabs)")
         if topology[0] is not Periodic:
-            raise NotImplementedError("only a Periodic partitioned direction is accelerated")
-        nxl = self.global_size[0] // R
+            raise NotImplementedError("only a Periodic partitioned direction is accelerated (Left / RightConnected ends: not yet)")
+        # local_size (distributed_grids.jl:44-58): the remainder of Nx / R goes to the last rank
+        self.local_sizes = local_sizes(self.global_size[0], R)
+        self.irregular = len(set(self.local_sizes)) > 1
+        nxl = self.local_sizes[r]
         self.x_global = (float(x[0]), float(x[1]))
         self.Lx_global = _regular_coordinate(x, self.global_size[0], "x")[1]
-        xl = x if R == 1 else partition_coordinate(x, nxl, R, r)
+        xl = x if R == 1 else partition_coordinate(x, self.local_sizes, R, r)
         topo = (FullyConnected if ctx.partitioned else topology[0], topology[1], topology[2])
         self.local_size = (nxl, self.global_size[1], self.global_size[2])
-        self.i_offset = r * nxl                      # global index of local i = 1 minus one
+        self.i_offset = sum(self.local_sizes[:r])    # global index of local i = 1 minus one
         if make_local_grid is None:
             self.local = RectilinearGrid(ctx.arch, self.local_size, x=xl, y=y, z=z, topology=topo, halo=halo)
         else:
@@ -279,6 +290,8 @@ class DistributedRectilinearGrid:
 # ----------------------------------------------------------------------------------------------------------------------
 class DeviceBackend:
     def __init__(self, ctx, grid, ntracers):
+        if getattr(grid, "irregular", False):
+            raise NotImplementedError("irregular partitions (Nx % R != 0) run through LibraryDistributedModel (gathered pressure solve)")
         self.ctx, self.grid, self.ntracers = ctx, grid, ntracers
         torch = ctx.torch
         g = grid.local
@@ -987,7 +1000,12 @@ class LibraryDistributedModel(_NonhydrostaticModel):
 
     def _create_handle(self, grid, ntracers):
         h = C.c_void_p()
-        _lib.check(_lib.lib().ocn_dist_model_create(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global)))
+        if getattr(grid, "irregular", False):
+            sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
+            _lib.check(_lib.lib().ocn_dist_model_create_sizes(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
+                                                              float(grid.Lx_global), sizes))
+        else:
+            _lib.check(_lib.lib().ocn_dist_model_create(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global)))
         return h
 
     def max_abs_divergence(self):

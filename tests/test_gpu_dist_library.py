@@ -50,9 +50,10 @@ def _library_model(ocn, dist, ctx, size, zkind):
     return grid, model
 
 
-def _compare(out, ref, r, nxl, size):
+def _compare(out, ref, r, nxl, size, offset=None):
+    i0 = r * nxl if offset is None else offset
     for name, a in out.items():
-        want = ref[name][3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]
+        want = ref[name][3 + i0:3 + i0 + nxl, 3:-3, 3:-3]
         scale = np.abs(ref[name]).max()
         err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / scale
         assert err <= 1e-12, (r, name, err, int(np.isnan(a).sum()))
@@ -199,6 +200,30 @@ def test_library_virtual_ranks_match_single_gpu(ocn, arch, R, size, zkind, optio
     for r, (out, div, t) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, nxl, size)
+
+
+@pytest.mark.parametrize("R,size,zkind", [
+    (3, (25, 8, 6), "periodic"),          # 8, 8, 9 columns; Ny not divisible by R either
+    (2, (13, 8, 6), "bounded"),           # 6, 7 columns: Fourier-tridiagonal solver + ScalarDiffusivity + buoyancy
+    (4, (30, 8, 8), "stretched"),         # 7, 7, 7, 9 columns, stretched z, Coriolis, boundary conditions
+    (4, (31, 8, 8), "amd"),               # the configs[4] physics on 7, 7, 7, 10 columns
+])
+def test_library_irregular_partition_matches_single_gpu(ocn, arch, R, size, zkind):
+    """Nx not divisible by the number of ranks: local_size puts the remainder on the last rank (distributed_grids.jl:44-58,
+    partition_coordinate partition_assemble.jl:63-76). The halo exchange is unchanged (Hx columns per side whatever the slab width); the
+    pressure solve takes the gathered form (every rank assembles the global source term and runs the single-GPU solver)."""
+    from oldoceananigans_jl_amd import distributed as dist
+    assert dist.local_sizes(25, 3) == [8, 8, 9] and dist.local_sizes(24, 3) == [8, 8, 8] and dist.local_sizes(7, 4) == [1, 1, 1, 4]
+    edges = [dist.partition_coordinate((0.0, 2.0), dist.local_sizes(25, 3), 3, r) for r in range(3)]
+    assert edges[0][0] == 0.0 and all(a[1] == b[0] for a, b in zip(edges[:-1], edges[1:])) and abs(edges[-1][1] - 2.0) < 1e-15
+    _own_stream()
+    nsteps = 3
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, {})
+    ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps)
+    sizes = dist.local_sizes(size[0], R)
+    for r, (out, div, t) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, sizes[r], size, offset=sum(sizes[:r]))
 
 
 def test_library_transposing_solver_matches(ocn, arch):
