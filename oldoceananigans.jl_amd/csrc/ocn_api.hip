@@ -677,6 +677,8 @@ extern "C" int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const doubl
     if (!grid || !u || !v || !w || !nu_e || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
         (ntracers > 0 && (!tracers || !Gc || !kappa_e)))
         return fail(OCN_EINVAL, "invalid argument");
+    if (grid->d.tx == OCN_FLAT || grid->d.ty == OCN_FLAT || grid->d.tz == OCN_FLAT)
+        return fail(OCN_ENOTSUP, "eddy-coefficient arrays (AnisotropicMinimumDissipation) need a grid without Flat directions");
     return closure_tendencies(grid->d, u, v, w, tracers, ntracers, 0.0, nullptr, Gu, Gv, Gw, Gc, range, nu_e, kappa_e);
 }
 
@@ -2301,7 +2303,14 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
             if (sd < 3) a.loc[f][sd] = f < m->nf ? m->loc[f][sd] : 0;
         }
     if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
-    hipLaunchKernelGGL(tendency_epilogue_kernel, grid3(nx, ny, nz * m->nf, BLK), BLK, 0, g_stream, g, a);
+    const dim3 grd = grid3(nx, ny, nz * m->nf, BLK);
+    const int clo = m->has_amd ? 2 : (m->has_closure ? 1 : 0);
+#define OCN_EPI(COR, BUOY, CLO) hipLaunchKernelGGL((tendency_epilogue_kernel<COR, BUOY, CLO>), grd, BLK, 0, g_stream, g, a)
+#define OCN_EPI_CLO(COR, BUOY) do { if (clo == 2) OCN_EPI(COR, BUOY, 2); else if (clo == 1) OCN_EPI(COR, BUOY, 1); else OCN_EPI(COR, BUOY, 0); } while (0)
+    if (a.has_coriolis) { if (a.has_buoyancy) OCN_EPI_CLO(true, true); else OCN_EPI_CLO(true, false); }
+    else                { if (a.has_buoyancy) OCN_EPI_CLO(false, true); else OCN_EPI_CLO(false, false); }
+#undef OCN_EPI_CLO
+#undef OCN_EPI
     KERNEL_CHECK();
     return OCN_OK;
 }

@@ -161,7 +161,9 @@ struct ClosureCtx {
 template <int F>
 __device__ __forceinline__ double closure_divergence(const DGrid &g, const FView &u, const FView &v, const FView &w, const FView &c,
                                                      double coef, int i, int j, int k, bool var, const FView &K) {
-    const ClosureCtx X{g, u, v, w, coef, g.tx == OCN_FLAT, g.ty == OCN_FLAT, g.tz == OCN_FLAT, var, K};
+    // eddy-coefficient arrays come with grids that have no Flat direction (ocn_model_set_amd): with `var` a compile-time constant the
+    // three Flat tests fold away and the loads of all six face fluxes are issued together
+    const ClosureCtx X{g, u, v, w, coef, var ? false : g.tx == OCN_FLAT, var ? false : g.ty == OCN_FLAT, var ? false : g.tz == OCN_FLAT, var, K};
     const double dx_ = g.dx, dy_ = g.dy;
     double dx, dy, dz, vinv;
     if (F == F_U) {            // ∂ⱼ_τ₁ⱼ at fcc: Ax_qᶜᶜᶜ, Ay_qᶠᶠᶜ, Az_qᶠᶜᶠ
@@ -208,31 +210,13 @@ __global__ void __launch_bounds__(256) closure_tendency_kernel(DGrid g, FView u,
 // ---------------------------------------------------------------------------------------------------------------------
 enum AmdOp { A_DXV, A_DYU, A_DXW, A_DZU, A_DYW, A_DZV, A_S12, A_S13, A_S23, A_DXV2, A_DYU2, A_DXW2, A_DZU2, A_DYW2, A_DZV2,
              A_DXV_S12, A_DYU_S12, A_DXW_S13, A_DZU_S13, A_DZV_S23, A_DYW_S23, A_DXC, A_DYC, A_DZC, A_DXC2, A_DYC2, A_DZC2 };
-struct AmdCtx {
-    const DGrid &g;
-    const FView &u, &v, &w, &c;
-    __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
-    __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
-    __device__ __forceinline__ double FX() const { return 2 * g.dx; }
-    __device__ __forceinline__ double FY() const { return 2 * g.dy; }
-    __device__ __forceinline__ double FZ(int k) const { return 2 * dzc(k); }
-    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return (f.at(i + 1, j, k) - f.at(i, j, k)) * (1.0 / g.dx); }
-    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return (f.at(i, j + 1, k) - f.at(i, j, k)) * (1.0 / g.dy); }
-    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return (f.at(i, j, k + 1) - f.at(i, j, k)) * (1.0 / dzc(k)); }
-    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i - 1, j, k)) * (1.0 / g.dx); }
-    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j - 1, k)) * (1.0 / g.dy); }
-    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j, k - 1)) * (1.0 / dzf(k)); }
+// The derived operands and the interpolations, shared by the two ways the base operands are obtained (CRTP): D::base<OP>(i, j, k)
+// returns one of the twelve base operands -- the normalised gradients norm_∂x_v ... and the strain components built from them.
+template <class D>
+struct AmdTerms {
+    __device__ __forceinline__ const D &self() const { return *static_cast<const D *>(this); }
     template <int OP> __device__ __forceinline__ double op(int i, int j, int k) const {
         switch (OP) {
-        case A_DXV: return FX() / FY() * ddx_f(v, i, j, k);
-        case A_DYU: return FY() / FX() * ddy_f(u, i, j, k);
-        case A_DXW: return FX() / FZ(k) * ddx_f(w, i, j, k);
-        case A_DZU: return FZ(k) / FX() * ddz_f(u, i, j, k);
-        case A_DYW: return FY() / FZ(k) * ddy_f(w, i, j, k);
-        case A_DZV: return FZ(k) / FY() * ddz_f(v, i, j, k);
-        case A_S12: return 0.5 * (op<A_DYU>(i, j, k) + op<A_DXV>(i, j, k));
-        case A_S13: return 0.5 * (op<A_DZU>(i, j, k) + op<A_DXW>(i, j, k));
-        case A_S23: return 0.5 * (op<A_DZV>(i, j, k) + op<A_DYW>(i, j, k));
         case A_DXV2: { const double x = op<A_DXV>(i, j, k); return x * x; }
         case A_DYU2: { const double x = op<A_DYU>(i, j, k); return x * x; }
         case A_DXW2: { const double x = op<A_DXW>(i, j, k); return x * x; }
@@ -245,12 +229,10 @@ struct AmdCtx {
         case A_DZU_S13: return op<A_DZU>(i, j, k) * op<A_S13>(i, j, k);
         case A_DZV_S23: return op<A_DZV>(i, j, k) * op<A_S23>(i, j, k);
         case A_DYW_S23: return op<A_DYW>(i, j, k) * op<A_S23>(i, j, k);
-        case A_DXC: return FX() * ddx_f(c, i, j, k);
-        case A_DYC: return FY() * ddy_f(c, i, j, k);
-        case A_DZC: return FZ(k) * ddz_f(c, i, j, k);
         case A_DXC2: { const double x = op<A_DXC>(i, j, k); return x * x; }
         case A_DYC2: { const double x = op<A_DYC>(i, j, k); return x * x; }
-        default: { const double x = op<A_DZC>(i, j, k); return x * x; }   // A_DZC2
+        case A_DZC2: { const double x = op<A_DZC>(i, j, k); return x * x; }
+        default: return self().template base<OP>(i, j, k);
         }
     }
     template <int OP> __device__ __forceinline__ double Ix(int i, int j, int k) const { return 0.5 * (op<OP>(i, j, k) + op<OP>(i + 1, j, k)); }
@@ -259,52 +241,95 @@ struct AmdCtx {
     template <int OP> __device__ __forceinline__ double Ixy(int i, int j, int k) const { return 0.5 * (Ix<OP>(i, j, k) + Ix<OP>(i, j + 1, k)); }
     template <int OP> __device__ __forceinline__ double Ixz(int i, int j, int k) const { return 0.5 * (Ix<OP>(i, j, k) + Ix<OP>(i, j, k + 1)); }
     template <int OP> __device__ __forceinline__ double Iyz(int i, int j, int k) const { return 0.5 * (Iy<OP>(i, j, k) + Iy<OP>(i, j, k + 1)); }
+};
+
+// metric factors and the direct evaluation of the base operands from the fields
+struct AmdFields {
+    const DGrid &g;
+    const FView &u, &v, &w, &c;
+    __device__ __forceinline__ AmdFields(const DGrid &g_, const FView &u_, const FView &v_, const FView &w_, const FView &c_) : g(g_), u(u_), v(v_), w(w_), c(c_) {}
+    __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double FX() const { return 2 * g.dx; }
+    __device__ __forceinline__ double FY() const { return 2 * g.dy; }
+    __device__ __forceinline__ double FZ(int k) const { return 2 * dzc(k); }
+    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return (f.at(i + 1, j, k) - f.at(i, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return (f.at(i, j + 1, k) - f.at(i, j, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return (f.at(i, j, k + 1) - f.at(i, j, k)) * (1.0 / dzc(k)); }
+    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i - 1, j, k)) * (1.0 / g.dx); }
+    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j - 1, k)) * (1.0 / g.dy); }
+    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return (f.at(i, j, k) - f.at(i, j, k - 1)) * (1.0 / dzf(k)); }
+    template <int OP> __device__ __forceinline__ double direct(int i, int j, int k) const {
+        switch (OP) {
+        case A_DXV: return FX() / FY() * ddx_f(v, i, j, k);
+        case A_DYU: return FY() / FX() * ddy_f(u, i, j, k);
+        case A_DXW: return FX() / FZ(k) * ddx_f(w, i, j, k);
+        case A_DZU: return FZ(k) / FX() * ddz_f(u, i, j, k);
+        case A_DYW: return FY() / FZ(k) * ddy_f(w, i, j, k);
+        case A_DZV: return FZ(k) / FY() * ddz_f(v, i, j, k);
+        case A_S12: return 0.5 * (direct<A_DYU>(i, j, k) + direct<A_DXV>(i, j, k));
+        case A_S13: return 0.5 * (direct<A_DZU>(i, j, k) + direct<A_DXW>(i, j, k));
+        case A_S23: return 0.5 * (direct<A_DZV>(i, j, k) + direct<A_DYW>(i, j, k));
+        case A_DXC: return FX() * ddx_f(c, i, j, k);
+        case A_DYC: return FY() * ddy_f(c, i, j, k);
+        default: return FZ(k) * ddz_f(c, i, j, k);     // A_DZC
+        }
+    }
     __device__ __forceinline__ double delta2(int k) const {
         const double fx = FX(), fy = FY(), fz = FZ(k);
         return 3 / ((1 / (fx * fx) + 1 / (fy * fy)) + 1 / (fz * fz));
     }
 };
 
-__device__ __forceinline__ double amd_viscosity(const AmdCtx &A, double Cnu, int i, int j, int k) {
+// every operand recomputed where it is needed (one thread per cell, no cooperation)
+struct AmdCtx : AmdFields, AmdTerms<AmdCtx> {
+    __device__ __forceinline__ AmdCtx(const DGrid &g_, const FView &u_, const FView &v_, const FView &w_, const FView &c_) : AmdFields(g_, u_, v_, w_, c_) {}
+    template <int OP> __device__ __forceinline__ double base(int i, int j, int k) const { return direct<OP>(i, j, k); }
+};
+
+
+template <class A_>
+__device__ __forceinline__ double amd_viscosity(const A_ &A, double Cnu, int i, int j, int k) {
     const double dxu = A.ddx_c(A.u, i, j, k), dyv = A.ddy_c(A.v, i, j, k), dzw = A.ddz_c(A.w, i, j, k);
-    const double xv2 = A.Ixy<A_DXV2>(i, j, k), yu2 = A.Ixy<A_DYU2>(i, j, k), xw2 = A.Ixz<A_DXW2>(i, j, k), zu2 = A.Ixz<A_DZU2>(i, j, k),
-                 yw2 = A.Iyz<A_DYW2>(i, j, k), zv2 = A.Iyz<A_DZV2>(i, j, k);
+    const double xv2 = A.template Ixy<A_DXV2>(i, j, k), yu2 = A.template Ixy<A_DYU2>(i, j, k), xw2 = A.template Ixz<A_DXW2>(i, j, k), zu2 = A.template Ixz<A_DZU2>(i, j, k),
+                 yw2 = A.template Iyz<A_DYW2>(i, j, k), zv2 = A.template Iyz<A_DZV2>(i, j, k);
     double q = dxu * dxu + dyv * dyv;
     q = q + dzw * dzw;
     q = q + xv2; q = q + yu2; q = q + xw2; q = q + zu2; q = q + yw2; q = q + zv2;
     if (q == 0) return fmax(0.0, 0.0);
     double b1 = dxu * (dxu * dxu) + dyv * xv2;
     b1 = b1 + dzw * xw2;
-    b1 = b1 + 2 * dxu * A.Ixy<A_DXV_S12>(i, j, k);
-    b1 = b1 + 2 * dxu * A.Ixz<A_DXW_S13>(i, j, k);
-    b1 = b1 + 2 * A.Ixy<A_DXV>(i, j, k) * A.Ixz<A_DXW>(i, j, k) * A.Iyz<A_S23>(i, j, k);
+    b1 = b1 + 2 * dxu * A.template Ixy<A_DXV_S12>(i, j, k);
+    b1 = b1 + 2 * dxu * A.template Ixz<A_DXW_S13>(i, j, k);
+    b1 = b1 + 2 * A.template Ixy<A_DXV>(i, j, k) * A.template Ixz<A_DXW>(i, j, k) * A.template Iyz<A_S23>(i, j, k);
     double b2 = dxu * yu2 + dyv * (dyv * dyv);
     b2 = b2 + dzw * yw2;
-    b2 = b2 + 2 * dyv * A.Ixy<A_DYU_S12>(i, j, k);
-    b2 = b2 + 2 * A.Ixy<A_DYU>(i, j, k) * A.Iyz<A_DYW>(i, j, k) * A.Ixz<A_S13>(i, j, k);
-    b2 = b2 + 2 * dyv * A.Iyz<A_DYW_S23>(i, j, k);
+    b2 = b2 + 2 * dyv * A.template Ixy<A_DYU_S12>(i, j, k);
+    b2 = b2 + 2 * A.template Ixy<A_DYU>(i, j, k) * A.template Iyz<A_DYW>(i, j, k) * A.template Ixz<A_S13>(i, j, k);
+    b2 = b2 + 2 * dyv * A.template Iyz<A_DYW_S23>(i, j, k);
     double b3 = dxu * zu2 + dyv * zv2;
     b3 = b3 + dzw * (dzw * dzw);
-    b3 = b3 + 2 * A.Ixz<A_DZU>(i, j, k) * A.Iyz<A_DZV>(i, j, k) * A.Ixy<A_S12>(i, j, k);
-    b3 = b3 + 2 * dzw * A.Ixz<A_DZU_S13>(i, j, k);
-    b3 = b3 + 2 * dzw * A.Iyz<A_DZV_S23>(i, j, k);
+    b3 = b3 + 2 * A.template Ixz<A_DZU>(i, j, k) * A.template Iyz<A_DZV>(i, j, k) * A.template Ixy<A_S12>(i, j, k);
+    b3 = b3 + 2 * dzw * A.template Ixz<A_DZU_S13>(i, j, k);
+    b3 = b3 + 2 * dzw * A.template Iyz<A_DZV_S23>(i, j, k);
     const double r = (b1 + b2) + b3;
     const double Cb_zeta = 0.0 / A.FZ(k);
     const double nu = -Cnu * A.delta2(k) * (r - Cb_zeta) / q;
     return fmax(0.0, nu);
 }
 
-__device__ __forceinline__ double amd_diffusivity(const AmdCtx &A, double Ck, int i, int j, int k) {
-    const double xc2 = A.Ix<A_DXC2>(i, j, k), yc2 = A.Iy<A_DYC2>(i, j, k), zc2 = A.Iz<A_DZC2>(i, j, k);
+template <class A_>
+__device__ __forceinline__ double amd_diffusivity(const A_ &A, double Ck, int i, int j, int k) {
+    const double xc2 = A.template Ix<A_DXC2>(i, j, k), yc2 = A.template Iy<A_DYC2>(i, j, k), zc2 = A.template Iz<A_DZC2>(i, j, k);
     const double sigma = (xc2 + yc2) + zc2;
     if (sigma == 0) return fmax(0.0, 0.0);
     const double dxu = A.ddx_c(A.u, i, j, k), dyv = A.ddy_c(A.v, i, j, k), dzw = A.ddz_c(A.w, i, j, k);
-    const double cx = A.Ix<A_DXC>(i, j, k), cy = A.Iy<A_DYC>(i, j, k), cz = A.Iz<A_DZC>(i, j, k);
-    double t1 = dxu * xc2 + A.Ixy<A_DXV>(i, j, k) * cx * cy;
-    t1 = t1 + A.Ixz<A_DXW>(i, j, k) * cx * cz;
-    double t2 = A.Ixy<A_DYU>(i, j, k) * cy * cx + dyv * yc2;
-    t2 = t2 + A.Ixz<A_DYW>(i, j, k) * cy * cz;
-    double t3 = A.Ixz<A_DZU>(i, j, k) * cz * cx + A.Iyz<A_DZV>(i, j, k) * cz * cy;
+    const double cx = A.template Ix<A_DXC>(i, j, k), cy = A.template Iy<A_DYC>(i, j, k), cz = A.template Iz<A_DZC>(i, j, k);
+    double t1 = dxu * xc2 + A.template Ixy<A_DXV>(i, j, k) * cx * cy;
+    t1 = t1 + A.template Ixz<A_DXW>(i, j, k) * cx * cz;
+    double t2 = A.template Ixy<A_DYU>(i, j, k) * cy * cx + dyv * yc2;
+    t2 = t2 + A.template Ixz<A_DYW>(i, j, k) * cy * cz;
+    double t3 = A.template Ixz<A_DZU>(i, j, k) * cz * cx + A.template Iyz<A_DZV>(i, j, k) * cz * cy;
     t3 = t3 + dzw * zc2;
     const double theta = (t1 + t2) + t3;
     const double kap = -Ck * A.delta2(k) * theta / sigma;
@@ -318,19 +343,27 @@ struct AmdArgs {
     double Cnu, Ck[OCN_MAX_FIELDS];
 };
 
-__global__ void __launch_bounds__(256) amd_diffusivities_kernel(DGrid g, AmdArgs a) {
+// Measured at 256 x 256 x 128 (tools/time_amd.py): 0.56 ms at 1 or 2 waves per SIMD (174 VGPRs), 0.51 ms at 3 (<= 168), 0.84 ms at 4
+// (spills). Two LDS variants were built, verified bit-identical and dropped: (i) three rotating planes of u, v, w, T, S as LDS tiles
+// (~10 global loads per cell instead of ~150): 0.60 ms -- the kernel is not load bound; (ii) the twelve base operands evaluated once
+// per patch point and shared through LDS (~550 instead of ~1100 FP64 instructions per cell): 0.65 ms -- the ~350 LDS reads per cell
+// then saturate the CU's one LDS pipe (4 clocks per wave-wide 8-byte read) and two barriers per level remain.
+#ifndef OCN_AMD_WAVES
+#define OCN_AMD_WAVES 3       // waves per SIMD the register allocation must allow
+#endif
+__global__ void __launch_bounds__(256, OCN_AMD_WAVES) amd_diffusivities_kernel(DGrid g, AmdArgs a) {
     const int i = a.r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = a.r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = a.r.k0 + blockIdx.z;
     if (i > a.r.i1 || j > a.r.j1 || k > a.r.k1) return;
     {
-        const AmdCtx A{g, a.u, a.v, a.w, a.u};
+        const AmdCtx A(g, a.u, a.v, a.w, a.u);
         a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);
     }
 #pragma unroll 1
     for (int t = 0; t < a.ntr; ++t) {
         const FView c = a.c[t], out = a.kappa_e[t];       // local copies (scalar loads): no address of a kernel argument is taken
-        const AmdCtx A{g, a.u, a.v, a.w, c};
+        const AmdCtx A(g, a.u, a.v, a.w, c);
         out.at(i, j, k) = amd_diffusivity(A, a.Ck[t], i, j, k);
     }
 }
@@ -477,6 +510,10 @@ struct EpilogueArgs {
     struct Lin { int f, side, dep; double a, b; } lin[OCN_EPILOGUE_MAX_LIN];
 };
 
+// COR / BUOY / CLO (0 none, 1 constant ν, κ, 2 eddy-coefficient arrays) are compile-time: the terms of one cell then form ONE basic
+// block whose ~40 loads the compiler issues together -- with run-time flags every term was its own block behind a branch and its
+// loads waited one after the other (0.94 -> see DESIGN.md for the measured time at 256 x 256 x 128).
+template <bool COR, bool BUOY, int CLO>
 __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
     const int f = blockIdx.z % a.n;
     const Range6 r = a.r[f];
@@ -487,20 +524,21 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
     const FView &fv = f == 0 ? a.u : (f == 1 ? a.v : (f == 2 ? a.w : a.c[f - 3]));
     const long q = fv.lin(i, j, k);
     double G = a.Gn[f][q];
+    constexpr bool VAR = CLO == 2;
     if (f == 0) {
-        if (a.has_coriolis) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
-        if (a.has_buoyancy) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
+        if (COR) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
+        if (BUOY) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
     } else if (f == 1) {
-        if (a.has_coriolis) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
-        if (a.has_buoyancy) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
+        if (COR) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
+        if (BUOY) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
     } else if (f == 2) {
-        if (a.nu != 0.0 || a.amd) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, a.amd, a.nu_e)) + 0.0;
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
     } else {
         const double kap = a.kappa[f - 3];
-        if (kap != 0.0 || a.amd)
-            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, a.amd, a.kappa_e[f - 3])) + 0.0;
+        if (CLO && (VAR || kap != 0.0))
+            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, VAR, a.kappa_e[f - 3])) + 0.0;
     }
     if (a.any_flux) {
         // compute_x/y/z_bcs!: G[1] += flux A / V, G[N] -= flux A / V (x, then y, then z as the reference launches them)
