@@ -359,6 +359,10 @@ int ocn_debug_rcp64_check(unsigned long long nsamples, int exp_lo, int exp_hi, u
 /* where the cosine-transform path's permute_indices! (backward = 0) / unpermute_indices! (backward = 1) send element i of a line of
  * length N: destination[i - 1], 1-based -- the tables of Solvers/index_permutations.jl:5-35 (host array, synchronous) */
 int ocn_debug_permute_indices(int N, int backward, int *destination);
+/* number of Poisson solvers of this process that switched to the per-direction transform path because their multi-dimensional rocFFT
+ * plans failed the creation-time self-check (rocFFT returns wrong transforms from such plans while plans of other sizes are alive;
+ * the unit-stride 1-D plans of the per-direction path are not affected) */
+int ocn_debug_fft_fallbacks(void);
 
 /* ---------------------------------------------------------------- distributed: communicator + partitioned model -- */
 /* `Distributed(GPU(); partition = Partition(R))` (DistributedComputations/distributed_architectures.jl:166-302): one process per

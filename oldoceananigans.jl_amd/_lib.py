@@ -155,6 +155,7 @@ SYMBOLS = {
     "ocn_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "ocn_debug_rcp_check": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]),
     "ocn_debug_permute_indices": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "ocn_debug_fft_fallbacks": (C.c_int, []),
 }
 
 

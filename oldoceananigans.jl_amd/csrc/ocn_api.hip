@@ -1026,12 +1026,29 @@ static int plan_set_stream(hipfftHandle plan) {
 
 // complex-to-complex resources of the reference's API (solve!(ϕ, solver, b) with a complex b): created on first use so
 // that the model fast path keeps only its two real plans alive
+// rocFFT hazard (tools/fft_real_test2.hip): a multi-dimensional plan created while plans of OTHER sizes are alive in
+// the process can return wrong transforms (e.g. the 64x16x8 real 3-D pair after 32x16x8, 8x16x32 and 32^3; exact again once the older
+// plans are destroyed -- an internal cache of rocFFT keyed too coarsely). Triage on MI355X: the embedded (strided) Z2D plans and the
+// unit-stride batched 1-D complex plans stay exact in exactly that situation. A solver whose multi-dimensional plans fail their
+// creation-time self-check therefore switches to the per-direction path (gather -> unit-stride batched 1-D Z2Z -> scatter, the path
+// of the cosine-transform topologies), which is verified in turn; only if that fails too is the solver refused (OCN_EFFT).
+static int g_fft_fallbacks = 0;
+static int ensure_complex(ocn_poisson_s *s);
+static int poisson_fall_back(ocn_poisson_s *s) {
+    (void)hipGetLastError();
+    s->general = true;
+    s->split = false;
+    ++g_fft_fallbacks;
+    return ensure_complex(s);
+}
+extern "C" int ocn_debug_fft_fallbacks(void) { return g_fft_fallbacks; }
+
 static int ensure_complex(ocn_poisson_s *s) {
     if (s->has_plan || s->buffer) return OCN_OK;
     const DGrid &g = s->grid->d;
-    HIP_TRY(dev_alloc((void **)&s->storage, s->n * sizeof(double2)));
+    if (!s->storage) HIP_TRY(dev_alloc((void **)&s->storage, s->n * sizeof(double2)));
     HIP_TRY(hipMemsetAsync(s->storage, 0, s->n * sizeof(double2), g_stream));
-    if (s->kind == 1) {
+    if (s->kind == 1 && !s->source) {
         HIP_TRY(dev_alloc((void **)&s->source, s->n * sizeof(double2)));
         HIP_TRY(hipMemsetAsync(s->source, 0, s->n * sizeof(double2), g_stream));
         HIP_TRY(dev_alloc((void **)&s->partial, 1024 * sizeof(double2)));
@@ -1069,7 +1086,12 @@ static int ensure_complex(ocn_poisson_s *s) {
     s->has_plan = true;
     FFT_TRY(hipfftSetStream(s->plan, g_stream));
     const double scale = s->kind == 0 ? 1.0 / ((double)g.Nx * g.Ny * g.Nz) : 1.0 / ((double)g.Nx * g.Ny);
-    return verify_complex_plan(s->plan, s->storage, (long)s->n, scale, "complex-to-complex");
+    int rc = verify_complex_plan(s->plan, s->storage, (long)s->n, scale, "complex-to-complex");
+    if (rc != OCN_EFFT) return rc;
+    // the multi-dimensional plan came out wrong (see poisson_fall_back): per-direction transforms on unit-stride 1-D plans instead
+    hipfftDestroy(s->plan);
+    s->has_plan = false;
+    return poisson_fall_back(s);
 }
 
 // one direction of the transform on a grid with Bounded directions (forward: physical -> spectral)
@@ -1218,7 +1240,14 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             rc = fail(1000 + (int)r, "hipfftSetStream failed (%d)", (int)r);
             goto bad;
         }
-        if ((rc = verify_real_plans(s))) goto bad;
+        if ((rc = verify_real_plans(s))) {
+            if (rc != OCN_EFFT) goto bad;
+            hipfftDestroy(s->plan_r2c); hipfftDestroy(s->plan_c2r);
+            s->has_r2c = s->has_c2r = false;
+            if ((rc = poisson_fall_back(s))) goto bad;
+            *solver = s;
+            return OCN_OK;
+        }
         if (g_split_solve && (kind == 1 || s->zfused) && g.Ny >= 8 && g.Ny <= 512 && (g.Ny & (g.Ny - 1)) == 0 && g.tx == OCN_PERIODIC &&
             g.ty == OCN_PERIODIC) {
             int nx1[1] = {g.Nx};

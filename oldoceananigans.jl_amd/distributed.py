@@ -559,6 +559,19 @@ class DistributedNonhydrostaticModel:
             names = ["u", "v", "w"] + list(self.tracer_names)
             self.backend.set_boundary_conditions({names.index(n): fb for n, fb in boundary_conditions.items()})
 
+    @property
+    def clock(self):
+        """model.clock (TimeSteppers/clock.jl:39-45): this model keeps time, iteration, stage, last_Δt, last_stage_Δt itself"""
+        return self
+
+    def reset(self):
+        """reset!(model.clock) + zeroed tendencies (what ocn_model_reset does for the library's models)"""
+        self.time, self.iteration, self.stage = 0.0, 0, 1
+        self.last_Δt = self.last_stage_Δt = float("inf")
+        import numpy as _np
+        for f in list(self.backend.Gn) + list(self.backend.Gm):
+            f.set_parent(_np.zeros(f.shape))
+
     # field access ---------------------------------------------------------------------------------------------
     def fields(self):
         names = ["u", "v", "w"] + list(self.tracer_names)

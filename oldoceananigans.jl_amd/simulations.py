@@ -33,6 +33,20 @@ def cell_diffusion_timescale(model):
     grid = model.grid.local if hasattr(model.grid, "local") else model.grid
     spacings = [grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, float(np.min(grid.Δzᵃᵃᶜ[grid.Hz:grid.Hz + grid.Nz]))]
     delta = min(d for d, t in zip(spacings, grid.topology) if t is not Flat)
+    from .closures import AnisotropicMinimumDissipation
+    if isinstance(closure, AnisotropicMinimumDissipation):
+        # the eddy coefficients are fields: Δ² / max(νₑ, κₑ) over the model's diffusivity fields (and over the ranks)
+        D = getattr(model, "diffusivity_fields", None)
+        if D is not None:
+            arrays = [D[0].parent()] + [k.parent() for k in D[1]]
+        else:
+            b = model.backend
+            arrays = [b.nu_e.parent()] + [k.parent() for k in b.kappa_e]
+        biggest = max(float(np.max(a)) for a in arrays)
+        if hasattr(model, "ctx") and hasattr(model.ctx, "allreduce_max"):
+            biggest = model.ctx.allreduce_max(biggest)
+        with np.errstate(divide="ignore"):
+            return float(np.float64(delta ** 2) / np.float64(biggest))
     kappas = list(closure.κ.values()) if isinstance(closure.κ, dict) else [closure.κ]
     max_k = max([float(k) for k in kappas] or [0.0])
     with np.errstate(divide="ignore"):
@@ -201,7 +215,10 @@ class Simulation:
     def initialize(self):
         """initialize!(sim) (run.jl:196-251): update_state!, schedules, callbacks at iteration 0"""
         from .models import update_state
-        if hasattr(self.model, "handle"):
+        if hasattr(self.model, "backend"):             # DistributedNonhydrostaticModel (host-orchestrated partitioned model)
+            from . import distributed
+            distributed.update_state(self.model, True)
+        elif hasattr(self.model, "handle"):
             update_state(self.model, True)
         for cb in self.callbacks.values():
             cb.schedule.initialize(self.model)
@@ -233,7 +250,10 @@ class Simulation:
 
     def reset(self):
         """reset!(sim) (simulation.jl:203-213)"""
-        _lib.check(_lib.lib().ocn_model_reset(self.model.handle))
+        if hasattr(self.model, "backend"):
+            self.model.reset()
+        else:
+            _lib.check(_lib.lib().ocn_model_reset(self.model.handle))
         self.stop_iteration = self.stop_time = self.wall_time_limit = math.inf
         self.run_wall_time, self.initialized, self.running = 0.0, False, True
 

@@ -365,3 +365,59 @@ def test_substructured_solver_layouts(ocn, arch):
         for name in a:
             err = np.abs(a[name][3:-3, 3:-3, 3:-3] - b[name][3:-3, 3:-3, 3:-3]).max() / np.abs(b[name]).max()
             assert err <= 1e-12, (name, err)
+
+
+def test_simulation_drives_a_partitioned_model(ocn, arch):
+    """Simulation(model) with the host-orchestrated partitioned model (its clock view, reset, initialize through the distributed
+    update_state!) and with the library's partitioned model: run! with a stop iteration and a TimeInterval callback, against the same
+    Simulation of the single-GPU model (the Simulation branches on `model.backend` were never driven)"""
+    import ctypes as C
+    import torch
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    size = (32, 16, 8)
+    z, topo = _z_and_topology(ocn, "periodic", size[2])
+
+    def drive(model, set_fn, nodes_grid):
+        set_fn(model, **{n: analytic(n, *nodes_grid.nodes(f.loc)) for n, f in model.fields().items()})
+        dt = 0.1 * nodes_grid.Δxᶜᵃᵃ / 0.6
+        sim = ocn.Simulation(model, Δt=dt, stop_iteration=5)
+        hits = []
+        sim.callbacks["probe"] = ocn.Callback(lambda s: hits.append((s.model.clock.iteration, s.model.clock.time)), ocn.TimeInterval(2.5 * dt))
+        ocn.run(sim)
+        assert model.clock.iteration == 5
+        first = ({n: f.parent() for n, f in model.fields().items()}, list(hits), model.clock.time)
+        ocn.reset(sim)
+        assert model.clock.iteration == 0 and model.clock.time == 0.0
+        return first
+
+    ctx = dist.SelfLoopContext(0, 1, torch.device("cuda", 0), torch, None, arch)
+    grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    host_model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
+    out_host, hits_host, t_host = drive(host_model, dist.set_model, grid.local)
+    host_model.backend.close()
+    sgrid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    smodel = ocn.NonhydrostaticModel(grid=sgrid, tracers=("T", "S"))
+    out_ref, hits_ref, t_ref = drive(smodel, ocn.set_model, sgrid)
+    assert t_host == t_ref and [h[0] for h in hits_host] == [h[0] for h in hits_ref] and len(hits_ref) >= 2
+    assert all(abs(a[1] - b[1]) < 1e-15 for a, b in zip(hits_host, hits_ref))
+    for n in out_ref:
+        err = np.abs(out_host[n][3:-3, 3:-3, 3:-3] - out_ref[n][3:-3, 3:-3, 3:-3]).max() / np.abs(out_ref[n]).max()
+        assert err <= 1e-12, (n, err)
+
+
+def test_cell_diffusion_timescale_with_eddy_coefficients(ocn, arch):
+    """cell_diffusion_timescale for AnisotropicMinimumDissipation: Δ² / max(νₑ, κₑ) over the diffusivity fields
+    (Simulations' diffusive CFL; the closure has no constant ν, κ) -- the wizard accepts diffusive_cfl on the configs[4] physics"""
+    grid = ocn.RectilinearGrid(arch, size=(16, 12, 10), x=(0, 1), y=(0, 1), z=(-1, 0), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), closure=ocn.AnisotropicMinimumDissipation())
+    rng = np.random.default_rng(2)
+    ocn.set_model(model, **{n: rng.standard_normal(grid.interior_size(f.loc)) for n, f in model.fields().items()})
+    D = model.diffusivity_fields
+    biggest = max(float(D[0].parent().max()), *(float(k.parent().max()) for k in D[1]))
+    assert biggest > 0
+    delta = min(grid.Δxᶜᵃᵃ, grid.Δyᵃᶜᵃ, float(np.min(grid.Δzᵃᵃᶜ[3:-4])))
+    assert ocn.cell_diffusion_timescale(model) == delta ** 2 / biggest
+    wizard = ocn.TimeStepWizard(cfl=0.5, diffusive_cfl=0.1)
+    dt = ocn.new_time_step(1e-3, wizard, model)
+    assert 0 < dt <= 1.1e-3

@@ -10,10 +10,12 @@ int main(int argc, char **argv) {
     bool destroy = argc > 1 && atoi(argv[1]);
     bool nullstream = argc > 2 && atoi(argv[2]);
     bool with_c2c = !(argc > 3 && atoi(argv[3]));
+    int only = argc > 4 ? atoi(argv[4]) : 0;      // 0: strided and contiguous C2R plans, 1: contiguous only, 2: strided only
     hipStream_t st = 0;
     if (!nullstream) hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     int sizes[][3] = {{32,16,8},{16,16,16},{8,16,32},{32,32,32},{64,16,8},{32,16,16}};
     for (auto &sz : sizes) for (int strided = 1; strided >= 0; --strided) {
+        if ((only == 1 && strided) || (only == 2 && !strided)) continue;
         int Nx = sz[0], Ny = sz[1], Nz = sz[2], Nxh = Nx / 2 + 1;
         size_t n = (size_t)Nx * Ny * Nz, nh = (size_t)Nxh * Ny * Nz;
         std::vector<double> h(n);
@@ -48,6 +50,29 @@ int main(int argc, char **argv) {
             for (size_t q = 0; q < n; ++q) err = fmax(err, fabs(out[q] - h[q]));
         }
         printf("%dx%dx%d strided %d err %.2e\n", Nx, Ny, Nz, strided, err);
+        if (!strided || only == 2) {
+            // the unit-stride batched 1-D complex plans of the library's per-direction ("general") path, created while everything above
+            // is alive: round trip over the whole array for each line length
+            int lens[3] = {Nx, Ny, Nz};
+            for (int d = 0; d < 3; ++d) {
+                hipfftHandle l;
+                int nn[1] = {lens[d]};
+                hipfftPlanMany(&l, 1, nn, nullptr, 1, lens[d], nullptr, 1, lens[d], HIPFFT_Z2Z, (int)(n / lens[d]));
+                hipfftSetStream(l, st);
+                std::vector<double> hc2(2 * n);
+                for (auto &x : hc2) x = rand() / (double)RAND_MAX - 0.5;
+                hipMemcpyAsync(dstor, hc2.data(), n * 16, hipMemcpyHostToDevice, st);
+                hipfftExecZ2Z(l, dstor, dstor, HIPFFT_FORWARD);
+                hipfftExecZ2Z(l, dstor, dstor, HIPFFT_BACKWARD);
+                std::vector<double> back(2 * n);
+                hipStreamSynchronize(st);
+                hipMemcpy(back.data(), dstor, n * 16, hipMemcpyDeviceToHost);
+                double e1 = 0;
+                for (size_t q = 0; q < 2 * n; ++q) e1 = fmax(e1, fabs(back[q] / lens[d] - hc2[q]));
+                printf("    1-D Z2Z len %d batch %d err %.2e\n", lens[d], (int)(n / lens[d]), e1);
+                if (destroy) hipfftDestroy(l);
+            }
+        }
         if (destroy) { if (with_c2c) hipfftDestroy(c); hipfftDestroy(f); hipfftDestroy(b); hipFree(din); hipFree(dc); hipFree(dout); hipFree(dstor); }
     }
     return 0;
