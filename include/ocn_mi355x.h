@@ -32,6 +32,8 @@ extern "C" {
 #define OCN_PERIODIC 0
 #define OCN_BOUNDED 1
 #define OCN_CONNECTED 2     /* FullyConnected: halo owned by a neighbouring rank (distributed_grids.jl:339-346); x only */
+#define OCN_RIGHT_CONNECTED 4   /* first rank of a Bounded partitioned x: wall on the WEST side, neighbour on the east (distributed_grids.jl:339-346) */
+#define OCN_LEFT_CONNECTED 5    /* last rank: neighbour on the west side, wall on the EAST side; Face-in-x fields hold Nx + 1 faces (grid_utils.jl:43-68) */
 #define OCN_FLAT 3          /* Flat: size 1, halo 0, unit spacing and extent; differences 0, interpolations the identity
                              * (Grids/grid_utils.jl, Operators/difference_operators.jl:30-49, Advection/flat_advective_fluxes.jl) */
 #define OCN_CENTER 0
@@ -419,6 +421,13 @@ int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracer
  * GLOBAL grid (a fallback, not the scaling path). */
 int ocn_dist_model_create_sizes(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
                                 const int *local_sizes);
+/* ... and for a Bounded partitioned direction (global_x_topology = OCN_BOUNDED; OCN_PERIODIC: as above): insert_connected_topology
+ * (distributed_grids.jl:339-346) -- the first rank's local grid is OCN_RIGHT_CONNECTED (wall on its west side), the last one's
+ * OCN_LEFT_CONNECTED, the others OCN_CONNECTED. Boundary conditions and the advection scheme's wall fallbacks
+ * (topologically_conditional_interpolation.jl:54-70) act on the wall side only; local_sizes may be NULL (equal slabs). The pressure
+ * solve takes the gathered form on the global Bounded grid (cosine transform along x). */
+int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                    const int *local_sizes, int global_x_topology);
 int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus

@@ -12,7 +12,8 @@ from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, Fl
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
 from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
-from .grids import Bounded, Center, Face, Flat, FullyConnected, Periodic, RectilinearGrid, with_halo
+from .grids import (Bounded, Center, Face, Flat, FullyConnected, LeftConnected, Periodic, RectilinearGrid, RightConnected,
+                    with_halo)
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
 from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
                       solve_for_pressure)

@@ -61,6 +61,7 @@ SYMBOLS = {
     "ocn_dist_barrier": (C.c_int, [_vp]),
     "ocn_dist_model_create": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double]),
     "ocn_dist_model_create_sizes": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip]),
+    "ocn_dist_model_create_partition": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip, C.c_int]),
     "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_sync": (C.c_int, []),

@@ -151,7 +151,8 @@ struct ocn_grid_s {
 
 static void parent_size(const DGrid &g, const int loc[3], int P[3]) {
     const int N[3] = {g.Nx, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, T[3] = {g.tx, g.ty, g.tz};
-    for (int d = 0; d < 3; ++d) P[d] = N[d] + 2 * H[d] + ((loc[d] == OCN_FACE && T[d] == OCN_BOUNDED) ? 1 : 0);
+    // Face fields hold N + 1 points where the direction ends in a wall on the HIGH side: Bounded and LeftConnected (grid_utils.jl:43-68)
+    for (int d = 0; d < 3; ++d) P[d] = N[d] + 2 * H[d] + ((loc[d] == OCN_FACE && wall_hi(T[d])) ? 1 : 0);
 }
 
 static FView make_view(const DGrid &g, const double *p, const int loc[3]) {
@@ -183,8 +184,9 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
             if (spacing != 1.0 || L[d] != 1.0 || (d == 2 && dzc)) return fail(OCN_EINVAL, "a Flat direction has unit spacing and extent (dimension %d)", d);
             continue;
         }
-        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(topo[d] == OCN_CONNECTED && d == 0))
-            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) FullyConnected "
+        const bool connected = topo[d] == OCN_CONNECTED || topo[d] == OCN_RIGHT_CONNECTED || topo[d] == OCN_LEFT_CONNECTED;
+        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(connected && d == 0))
+            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) Fully / Right / LeftConnected "
                                      "are accelerated", topo[d], d);
         // adapt_advection_order (Advection/adapt_advection_order.jl:90-96): WENO(order=5) stays where N >= 3 and becomes
         // WENO(order = 2N-1) = WENO{2} where N = 2; the halo must hold the adapted scheme's buffer (nonhydrostatic_model.jl:184,
@@ -272,7 +274,9 @@ static Range6 default_range(const DGrid &g, const int loc[3], bool exclude_perip
     const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
     int lo[3];
     for (int d = 0; d < 3; ++d)
-        lo[d] = 1 + ((exclude_periphery && loc[d] == OCN_FACE && T[d] == OCN_BOUNDED && N[d] > 1) ? 1 : 0);
+        // periphery_offset (kernel_launching.jl:145-146) is defined for Bounded; a RightConnected rank owns the same wall face and gets
+        // the same exclusion here, so its fields equal the serial run's (the reference launches over that face and resets it by the fill)
+        lo[d] = 1 + ((exclude_periphery && loc[d] == OCN_FACE && wall_lo(T[d]) && N[d] > 1) ? 1 : 0);
     return Range6{lo[0], N[0], lo[1], N[1], lo[2], N[2]};
 }
 
@@ -325,7 +329,8 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
     // order: boundary_condition_ordering.jl:17-46 -- non-periodic first, then periodic; insertion sort with an
     // always-true `lt` reverses same-class entries => z, y, x inside each class.
     for (int d = 2; d >= 0; --d) {
-        if (T[d] != OCN_BOUNDED) continue;
+        const bool do_lo = wall_lo(T[d]), do_hi = wall_hi(T[d]);            // one wall only on Right / LeftConnected x
+        if (!do_lo && !do_hi) continue;
         const bool face = loc[d] == OCN_FACE;
         if (face && !fill_open) continue;
         BcSides bc;
@@ -341,7 +346,7 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
         const long total = (long)Na * Nb;
         const int nb = (int)((total + 255) / 256);
-        if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open);
+        if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open, do_lo, do_hi);
         if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open);
         if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open);
     }
@@ -383,7 +388,8 @@ static int validate_bc(const DGrid &g, const int loc[3], int side, int kind) {
     if (kind < OCN_BC_DEFAULT || kind > OCN_BC_OPEN) return fail(OCN_EINVAL, "unknown boundary condition kind %d", kind);
     if (kind == OCN_BC_DEFAULT) return OCN_OK;
     const int d = side / 2;
-    if (T[d] != OCN_BOUNDED) return fail(OCN_EINVAL, "a non-default boundary condition needs a Bounded topology in dimension %d", d);
+    if (!((side & 1) ? wall_hi(T[d]) : wall_lo(T[d])))
+        return fail(OCN_EINVAL, "a non-default boundary condition needs a wall on that side (Bounded topology) in dimension %d", d);
     if (kind == OCN_BC_OPEN ? loc[d] != OCN_FACE : loc[d] != OCN_CENTER)
         return fail(OCN_EINVAL, "Flux/Value/Gradient conditions apply to fields at Center, Open to fields at Face along the boundary direction");
     return OCN_OK;
@@ -408,7 +414,7 @@ static int fill_halo_regions(const ocn_grid_s *grid, double *const *fields, cons
             bool same = P0[0] == P1[0] && P0[1] == P1[1] && P0[2] == P1[2];
             for (int d = 0; d < 3 && same; ++d) {
                 const int T[3] = {g.tx, g.ty, g.tz};
-                if (T[d] == OCN_BOUNDED && locs[h][d] != locs[f][d]) same = false;
+                if ((wall_lo(T[d]) || wall_hi(T[d])) && locs[h][d] != locs[f][d]) same = false;
             }
             if (same) {
                 if (bcs) memcpy(gbc[n], bcs[h], sizeof(ocn_bc_t) * 6);
@@ -445,8 +451,7 @@ static int compute_flux_bcs(const DGrid &g, double *G, const int loc[3], const o
     const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
     FView view = make_view(g, G, loc);
     for (int d = 0; d < 3; ++d) {
-        if (T[d] != OCN_BOUNDED) continue;
-        const bool lo = bcs[2 * d].kind == OCN_BC_FLUX, hi = bcs[2 * d + 1].kind == OCN_BC_FLUX;
+        const bool lo = wall_lo(T[d]) && bcs[2 * d].kind == OCN_BC_FLUX, hi = wall_hi(T[d]) && bcs[2 * d + 1].kind == OCN_BC_FLUX;
         if (!lo && !hi) continue;
         const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
         const int nb = (int)(((long)Na * Nb + 255) / 256);
@@ -463,7 +468,7 @@ static int compute_flux_bcs(const DGrid &g, double *G, const int loc[3], const o
 static int compute_linear_flux_bc(const DGrid &g, double *G, const int loc[3], int side6, double a, double b, const double *dep) {
     const int N[3] = {g.Nx, g.Ny, g.Nz}, T[3] = {g.tx, g.ty, g.tz};
     const int d = side6 / 2, side = side6 % 2;
-    if (T[d] != OCN_BOUNDED) return fail(OCN_EINVAL, "a Flux condition needs a Bounded direction");
+    if (!(side ? wall_hi(T[d]) : wall_lo(T[d]))) return fail(OCN_EINVAL, "a Flux condition needs a wall on that side (Bounded direction)");
     if (loc[d] != OCN_CENTER) return fail(OCN_EINVAL, "a Flux condition needs a field at Center along the boundary direction");
     const FView vG = make_view(g, G, loc), vP = make_view(g, dep, loc);
     const int Na = d == 0 ? N[1] : N[0], Nb = d == 2 ? N[1] : N[2];
@@ -1478,6 +1483,8 @@ extern "C" int ocn_batched_tridiagonal_solve_z(int Nx, int Ny, int Nz, const dou
 // ---------------------------------------------------------------------------------------------------------------------
 static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east, bool pack,
                           int depth = 0) {
+    // a wall side has no neighbour: nothing is unpacked there (what was packed for it is ignored by the other end of the ring)
+    const bool do_west = pack || !wall_lo(g.tx), do_east = pack || !wall_hi(g.tx);
     if (n <= 0) return OCN_OK;
     if (depth <= 0) depth = g.Hx;
     if (depth > g.Hx || depth > g.Nx) return fail(OCN_EINVAL, "exchange depth %d exceeds the halo (%d) or the local interior (%d)", depth, g.Hx, g.Nx);
@@ -1490,8 +1497,8 @@ static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*loc
     for (int f = 0; f < n; ++f) {
         int P[3];
         parent_size(g, locs[f], P);
-        if (f == 0) P0 = P[0];
-        if (P[0] != P0) return fail(OCN_EINVAL, "fields of one exchange must share the parent extent in x");
+        P0 = std::max(P0, P[0]);
+        sl.p0[f] = P[0];                            // Face-in-x fields of a LeftConnected rank are one column longer
         fl.p[f] = fields[f];
         sl.off[f] = off;
         sl.rows[f] = (long)P[1] * P[2];
@@ -1500,8 +1507,9 @@ static int x_halo_buffers(const DGrid &g, double *const *fields, const int (*loc
     }
     const long threads = (long)depth * maxrows;
     const int nb = (int)((threads + 255) / 256);
-    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, depth, west, east);
-    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, sl, P0, g.Nx, g.Hx, depth, west, east);
+    (void)P0;
+    if (pack) hipLaunchKernelGGL(x_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, sl, g.Nx, g.Hx, depth, west, east, true, true);
+    else      hipLaunchKernelGGL(x_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, sl, g.Nx, g.Hx, depth, west, east, do_west, do_east);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -2202,7 +2210,8 @@ static int model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers, bool 
 
 extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
     NEED_INIT();
-    if (grid && grid->d.tx == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected x direction needs ocn_dist_model_create");
+    if (grid && (grid->d.tx == OCN_CONNECTED || grid->d.tx == OCN_RIGHT_CONNECTED || grid->d.tx == OCN_LEFT_CONNECTED))
+        return fail(OCN_EINVAL, "a connected x direction needs ocn_dist_model_create");
     return model_create(model, grid, ntracers, true);
 }
 
@@ -2325,7 +2334,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     const int T[3] = {g.tx, g.ty, g.tz};
     for (int f = 0; f < OCN_MAX_FIELDS; ++f)
         for (int sd = 0; sd < 6; ++sd) {
-            a.has_flux[f][sd] = f < m->nf && T[sd / 2] == OCN_BOUNDED && m->bcs[f][sd].kind == OCN_BC_FLUX &&
+            a.has_flux[f][sd] = f < m->nf && ((sd & 1) ? wall_hi(T[sd / 2]) : wall_lo(T[sd / 2])) && m->bcs[f][sd].kind == OCN_BC_FLUX &&
                                 (m->bcs[f][sd].value != 0.0 || m->bcs[f][sd].array);
             a.flux[f][sd] = f < m->nf ? m->bcs[f][sd].value : 0.0;
             a.flux_arr[f][sd] = f < m->nf ? m->bcs[f][sd].array : nullptr;

@@ -149,29 +149,37 @@ __device__ __forceinline__ double weno3_biased(double s0, double s1, double s2, 
     return __builtin_fma(w1, q1, w0 * q0);
 }
 
-// topologically_conditional_interpolation.jl:46-52 (Bounded). `i` = index the _interpolate function is called with.
-__device__ __forceinline__ bool outside_symmetric_halo(int i, bool center, int N, int R) {
-    return center ? ((i >= R) & (i <= N + 1 - R)) : ((i >= R + 1) & (i <= N + 1 - R));
+// walls of a direction by topology code (ocn_mi355x.h): Bounded has both, RightConnected the low (west) one, LeftConnected the high one
+__host__ __device__ __forceinline__ bool wall_lo(int t) { return t == 1 || t == 4; }
+__host__ __device__ __forceinline__ bool wall_hi(int t) { return t == 1 || t == 5; }
+
+// topologically_conditional_interpolation.jl:46-70. `i` = index the _interpolate function is called with. Bounded tests both sides
+// (:46-52); RightConnected only the left, bounded, side (:54-61); LeftConnected only the right one (:63-70).
+__device__ __forceinline__ bool outside_symmetric_halo(int i, bool center, int N, int R, bool lo = true, bool hi = true) {
+    const bool okl = !lo || (center ? i >= R : i >= R + 1);
+    const bool okh = !hi || i <= N + 1 - R;
+    return okl & okh;
 }
-__device__ __forceinline__ bool outside_biased_halo(int i, bool center, int N, int R) {
-    return center ? ((i >= R) & (i <= N + 1 - (R - 1)) & (i >= R - 1) & (i <= N + 1 - R))
-                  : ((i >= R + 1) & (i <= N + 1 - (R - 1)) & (i >= R) & (i <= N + 1 - R));
+__device__ __forceinline__ bool outside_biased_halo(int i, bool center, int N, int R, bool lo = true, bool hi = true) {
+    const bool okl = !lo || (center ? ((i >= R) & (i >= R - 1)) : ((i >= R + 1) & (i >= R)));
+    const bool okh = !hi || ((i <= N + 1 - (R - 1)) & (i <= N + 1 - R));
+    return okl & okh;
 }
 
 // _symmetric_interpolate (scheme WENO{3} -> Centered{2}; near walls -> Centered{1}); q0..q3 = q[f-2 .. f+1]
 __device__ __forceinline__ double symmetric_interp(double q0, double q1, double q2, double q3, bool bounded, int i,
-                                                   bool center, int N) {
-    bool order4 = !bounded || outside_symmetric_halo(i, center, N, 3);
-    double hi = __builtin_fma(OCN_C4_1, q3, __builtin_fma(OCN_C4_2, q2, __builtin_fma(OCN_C4_3, q1, OCN_C4_4 * q0)));
-    if (order4) return hi;
+                                                   bool center, int N, bool lo = true, bool hi = true) {
+    bool order4 = !bounded || outside_symmetric_halo(i, center, N, 3, lo, hi);
+    double c4 = __builtin_fma(OCN_C4_1, q3, __builtin_fma(OCN_C4_2, q2, __builtin_fma(OCN_C4_3, q1, OCN_C4_4 * q0)));
+    if (order4) return c4;
     return __builtin_fma(OCN_C2_1, q2, OCN_C2_2 * q1);
 }
 
 // _biased_interpolate (WENO{3} -> WENO{2} -> UpwindBiased{1}); s0..s5 = psi[f-3 .. f+2]
 __device__ __forceinline__ double biased_interp(double s0, double s1, double s2, double s3, double s4, double s5,
-                                                bool left, bool bounded, int i, bool center, int N) {
-    if (!bounded || outside_biased_halo(i, center, N, 3)) return weno5_biased(s0, s1, s2, s3, s4, s5, left);
-    if (outside_biased_halo(i, center, N, 2)) return weno3_biased(s1, s2, s3, s4, left);
+                                                bool left, bool bounded, int i, bool center, int N, bool lo = true, bool hi = true) {
+    if (!bounded || outside_biased_halo(i, center, N, 3, lo, hi)) return weno5_biased(s0, s1, s2, s3, s4, s5, left);
+    if (outside_biased_halo(i, center, N, 2, lo, hi)) return weno3_biased(s1, s2, s3, s4, left);
     return left ? 1.0 * s2 : 1.0 * s3;
 }
 
@@ -182,7 +190,7 @@ __device__ __forceinline__ double biased_interp(double s0, double s1, double s2,
 // UpwindBiased{1}: Centered(order = 2), no buffer scheme (upwind_biased_reconstruction.jl:26-29).
 __device__ __forceinline__ double symmetric_interp_low(double q1, double q2) { return __builtin_fma(OCN_C2_1, q2, OCN_C2_2 * q1); }
 __device__ __forceinline__ double biased_interp_low(double s1, double s2, double s3, double s4, bool left, bool bounded, int i,
-                                                    bool center, int N, int B) {
-    if (B == 2 && (!bounded || outside_biased_halo(i, center, N, 2))) return weno3_biased(s1, s2, s3, s4, left);
+                                                    bool center, int N, int B, bool lo = true, bool hi = true) {
+    if (B == 2 && (!bounded || outside_biased_halo(i, center, N, 2, lo, hi))) return weno3_biased(s1, s2, s3, s4, left);
     return left ? 1.0 * s2 : 1.0 * s3;
 }

@@ -277,6 +277,7 @@ struct DistModel {
     int thin_halos = 1;         // pressure step: exchange the ONE column that is read (u[Nx+1], p[0]) instead of Hx columns
     int early_exchange = 1;     // start update_state!'s exchange from make_pressure_correction!
     int strip_width = 0;        // 0 automatic
+    bool bounded_x = false;     // the partitioned direction is Bounded: Right / LeftConnected end ranks, no wrap-around neighbour
     bool partitioned() const { return dist->world > 1 || dist->self_loop; }
 };
 
@@ -388,7 +389,7 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     int rc;
     auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], dm->p2, range, m->p, dtp); };
-    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx)) {
+    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx) || dm->bounded_x) {
         return pc(nullptr);
     }
     const int west[6] = {1, g.Hx, 1, g.Ny, 1, g.Nz}, east[6] = {g.Nx - g.Hx + 1, g.Nx, 1, g.Ny, 1, g.Nz};
@@ -411,8 +412,9 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     const ocn_bc_t(*bcs)[6] = m->any_bc ? m->bcs : nullptr;
     // eddy diffusivities at i = 0 and Nx + 1 are evaluated by the rank itself from the exchanged halos (the numbers a serial
     // Periodic grid's fill copies from the other side): no exchange of the diffusivity fields
+    // (on a wall side the halo of the diffusivities comes from their boundary condition, like on a serial Bounded grid)
     const int ext = dm->partitioned() ? 1 : 0;
-    const int amd_range[6] = {1 - ext, g.Nx + ext, 1, g.Ny, 1, g.Nz};
+    const int amd_range[6] = {1 - (wall_lo(g.tx) ? 0 : ext), g.Nx + (wall_hi(g.tx) ? 0 : ext), 1, g.Ny, 1, g.Nz};
     int rc;
     if (dm->halos_in_flight) {
         // the x exchange was started by make_pressure_correction!: finish the local fills (all columns are final now), take the
@@ -425,7 +427,7 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     }
     const bool physics = has_physics(m) || m->any_flux_bc || m->any_linear_flux;
     const bool overlap = dm->async_halos < 0 ? g.Nx >= 3 * 64 : dm->async_halos != 0;
-    if (!compute_tend || !dm->partitioned() || !overlap || g.Nx <= 2 * g.Hx || physics) {
+    if (!compute_tend || !dm->partitioned() || !overlap || g.Nx <= 2 * g.Hx || physics || dm->bounded_x) {
         if ((rc = dist_fill_halo_regions(m, m->U, m->loc, m->nf, false, bcs))) return rc;
         return update_state_tail(m, compute_tend, sub, amd_range);
     }
@@ -456,9 +458,10 @@ static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow)
 
 // NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected
 // (OCN_CONNECTED) when the direction is partitioned; `Lx_global`: extent of the global domain along x (the solver's eigenvalues)
-static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes);
+static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
+                             int global_x_topology);
 extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global) {
-    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, nullptr);
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, nullptr, OCN_PERIODIC);
 }
 // the same for an irregular partition: local_sizes[r] = Nx of rank r (local_size, distributed_grids.jl:44-58: N ÷ R cells per rank and
 // the remainder on the last one; or any `Sizes`). Equal sizes take the solvers above; otherwise the pressure solve gathers the source
@@ -467,10 +470,19 @@ extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, 
 extern "C" int ocn_dist_model_create_sizes(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
                                            const int *local_sizes) {
     if (!local_sizes) return fail(OCN_EINVAL, "NULL argument");
-    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, local_sizes);
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, local_sizes, OCN_PERIODIC);
+}
+// ... and for a Bounded partitioned direction (global_x_topology = OCN_BOUNDED): insert_connected_topology (distributed_grids.jl:339-346)
+// makes the first rank's local grid RightConnected (wall on its west side), the last one's LeftConnected, the others FullyConnected;
+// walls get their boundary conditions and the advection scheme's fallbacks on the wall side only, the ring has no wrap-around
+// neighbour. local_sizes as above (NULL: equal slabs). The pressure solve takes the gathered form on the global Bounded grid.
+extern "C" int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                               const int *local_sizes, int global_x_topology) {
+    if (global_x_topology != OCN_PERIODIC && global_x_topology != OCN_BOUNDED) return fail(OCN_EINVAL, "the partitioned direction is Periodic or Bounded");
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, local_sizes, global_x_topology);
 }
 
-static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes) {
+static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes, int global_tx) {
     const DGrid &g = local_grid->d;
     const int R = dm->dist->world;
     if (R > OCN_MAX_RANKS) return fail(OCN_ENOTSUP, "irregular partitions take at most %d ranks", OCN_MAX_RANKS);
@@ -485,7 +497,7 @@ static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx
     }
     q->table.first[R] = q->Nxg;
     if (sizes[dm->dist->rank] != g.Nx) return fail(OCN_EINVAL, "local_sizes[%d] = %d but the local grid has Nx = %d", dm->dist->rank, sizes[dm->dist->rank], g.Nx);
-    const int N[3] = {q->Nxg, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {OCN_PERIODIC, g.ty, g.tz};
+    const int N[3] = {q->Nxg, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {global_tx, g.ty, g.tz};
     const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
     const bool zr = local_grid->z_regular;
     int rc = ocn_grid_create(&q->ggrid, N, H, topo, L, Lx_global / (double)q->Nxg, g.dy, local_grid->h_dzc[g.Hz],
@@ -504,13 +516,20 @@ static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx
     return OCN_OK;
 }
 
-static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes) {
+static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
+                             int global_x_topology) {
     NEED_INIT();
     if (!model || !local_grid || !dist) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
     const bool part = dist->world > 1 || dist->self_loop;
-    if (part && g.tx != OCN_CONNECTED) return fail(OCN_EINVAL, "the local grid of a partitioned x direction must be FullyConnected in x");
-    if (!part && g.tx == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected x direction needs more than one rank");
+    const bool bounded_x = global_x_topology == OCN_BOUNDED;
+    // insert_connected_topology (distributed_grids.jl:339-346)
+    const int expect = !part ? global_x_topology
+                             : (!bounded_x ? OCN_CONNECTED
+                                           : (dist->rank == 0 ? OCN_RIGHT_CONNECTED : (dist->rank == dist->world - 1 ? OCN_LEFT_CONNECTED : OCN_CONNECTED)));
+    if (bounded_x && dist->self_loop) return fail(OCN_EINVAL, "self_loop closes a Periodic direction");
+    if (g.tx != expect)
+        return fail(OCN_EINVAL, "rank %d of %d: the local grid's x topology code is %d, insert_connected_topology gives %d", dist->rank, dist->world, g.tx, expect);
     int rc = model_create(model, local_grid, ntracers, /*with_solver=*/false);
     if (rc) return rc;
     ocn_model_s *m = *model;
@@ -536,9 +555,11 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
     bool irregular = false;
     if (local_sizes)
         for (int r = 0; r < dist->world; ++r) irregular = irregular || local_sizes[r] != local_sizes[0];
-    if (irregular) {
+    dm->bounded_x = bounded_x && part;
+    if (irregular || dm->bounded_x) {
         if (dist->self_loop) return bail(fail(OCN_EINVAL, "self_loop has one slab"));
-        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes))) return bail(rc);
+        std::vector<int> equal((size_t)dist->world, g.Nx);
+        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes ? local_sizes : equal.data(), global_x_topology))) return bail(rc);
         return OCN_OK;
     }
     if ((rc = ocn_dist_poisson_create(&dm->solver, local_grid, dist->world, dist->rank, Lx_global))) return bail(rc);

@@ -31,9 +31,10 @@ __device__ __forceinline__ double sym_transport(const DGrid &g, const FView &f, 
         q[n] = D == 0 ? area_q<AQ>(g, f, i + m, j, k) : (D == 1 ? area_q<AQ>(g, f, i, j + m, k) : area_q<AQ>(g, f, i, j, k + m));
     }
     if (B < 3) return symmetric_interp_low(q[1], q[2]);
-    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
+    const int T = D == 0 ? g.tx : (D == 1 ? g.ty : g.tz);
+    const bool lo = wall_lo(T), hi = wall_hi(T);
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
-    return symmetric_interp(q[0], q[1], q[2], q[3], bounded, idx, CEN, N);
+    return symmetric_interp(q[0], q[1], q[2], q[3], lo | hi, idx, CEN, N, lo, hi);
 }
 
 template <int D, bool CEN>
@@ -42,16 +43,17 @@ __device__ __forceinline__ double biased_field(const DGrid &g, const FView &c, b
     const int o = CEN ? 1 : 0;
     const long st = c.stride<D>();
     const double *p = c.p + c.lin(i, j, k) + (o - 3) * st;
-    const bool bounded = (D == 0 ? g.tx : (D == 1 ? g.ty : g.tz)) == 1;
+    const int T = D == 0 ? g.tx : (D == 1 ? g.ty : g.tz);
+    const bool lo = wall_lo(T), hi = wall_hi(T), bounded = lo | hi;
     const int N = D == 0 ? g.Nx : (D == 1 ? g.Ny : g.Nz);
     const int B = D == 0 ? g.Bx : (D == 1 ? g.By : g.Bz);
     if (B < 3) {                                                         // reduced scheme: the halo may be only B cells deep
         const double s2 = p[2 * st], s3 = p[3 * st];
         const double s1 = B == 2 ? p[st] : 0.0, s4 = B == 2 ? p[4 * st] : 0.0;
-        return biased_interp_low(s1, s2, s3, s4, left, bounded, idx, CEN, N, B);
+        return biased_interp_low(s1, s2, s3, s4, left, bounded, idx, CEN, N, B, lo, hi);
     }
     double s0 = p[0], s1 = p[st], s2 = p[2 * st], s3 = p[3 * st], s4 = p[4 * st], s5 = p[5 * st];
-    return biased_interp(s0, s1, s2, s3, s4, s5, left, bounded, idx, CEN, N);
+    return biased_interp(s0, s1, s2, s3, s4, s5, left, bounded, idx, CEN, N, lo, hi);
 }
 
 // advective_momentum_flux_{U,V,W}{u,v,w}: transport AQ interpolated along DS (CS), advected field reconstructed along
@@ -441,7 +443,7 @@ __global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FVie
 // tendencies holding the advective part.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool inactive_cell(const DGrid &g, int i, int j, int k) {
-    return (g.tx == OCN_BOUNDED && (i < 1 || i > g.Nx)) | (g.ty == OCN_BOUNDED && (j < 1 || j > g.Ny)) |
+    return ((wall_lo(g.tx) && i < 1) || (wall_hi(g.tx) && i > g.Nx)) || (g.ty == OCN_BOUNDED && (j < 1 || j > g.Ny)) ||
            (g.tz == OCN_BOUNDED && (k < 1 || k > g.Nz));
 }
 
@@ -665,7 +667,7 @@ struct BcSides {
 
 template <int D>
 __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides bc, FView view, int Na, int Nb, int N, bool face,
-                                                           bool fill_open) {
+                                                           bool fill_open, bool do_lo = true, bool do_hi = true) {   // one-sided: Left / RightConnected x
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long)Na * Nb) return;
     int a = 1 + t % Na, b = 1 + t / Na;
@@ -684,11 +686,11 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides
             else if (kl == OCN_BC_GRADIENT) h0 = c1 + bc.get(f, 0, ab) * (-bc.dlo);
             if (kh == OCN_BC_VALUE) h1 = cN + ((bc.get(f, 1, ab) - cN) / (bc.dhi / 2)) * bc.dhi;
             else if (kh == OCN_BC_GRADIENT) h1 = cN + bc.get(f, 1, ab) * bc.dhi;
-            p[lo] = h0;
-            p[hi] = h1;
+            if (do_lo) p[lo] = h0;
+            if (do_hi) p[hi] = h1;
         } else if (fill_open) {
-            p[lo] = bc.kind[f][0] == OCN_BC_OPEN ? bc.get(f, 0, ab) : 0.0;
-            p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.get(f, 1, ab) : 0.0;
+            if (do_lo) p[lo] = bc.kind[f][0] == OCN_BC_OPEN ? bc.get(f, 0, ab) : 0.0;
+            if (do_hi) p[hi] = bc.kind[f][1] == OCN_BC_OPEN ? bc.get(f, 1, ab) : 0.0;
         }
     }
 }
@@ -1887,24 +1889,26 @@ __global__ void __launch_bounds__(256) rcp64_check_kernel(unsigned long long n, 
 struct SlabList {
     long off[OCN_MAX_FIELDS];
     long rows[OCN_MAX_FIELDS];
+    int p0[OCN_MAX_FIELDS];                    // parent extent in x of each field
 };
 template <bool PACK>
-__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabList sl, int P0, int N, int HX, int H, double *west, double *east) {
+__global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabList sl, int N, int HX, int H, double *west, double *east,
+                                                            bool do_west, bool do_east) {
     const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int h = t % H;
     const long r = t / H;                      // j + P1 * k
-    const long row = r * P0;
     for (int f = 0; f < fl.n; ++f) {
         if (r >= sl.rows[f]) continue;
         double *p = fl.p[f];
+        const long row = r * sl.p0[f];
         const long b = sl.off[f] + t;
         // H = exchanged depth (<= Hx = HX): the depth interior columns next to each side <-> the depth halo columns nearest to it
         if (PACK) {
             west[b] = p[row + HX + h];
             east[b] = p[row + HX + N - H + h];
         } else {
-            p[row + HX - H + h] = west[b];
-            p[row + N + HX + h] = east[b];
+            if (do_west) p[row + HX - H + h] = west[b];
+            if (do_east) p[row + N + HX + h] = east[b];
         }
     }
 }

@@ -27,7 +27,8 @@ from . import _lib
 from .advection import WENO
 from .closures import AnisotropicMinimumDissipation
 from .fields import Field, _loc_array, _ptr_array
-from .grids import Bounded, Center, Face, FullyConnected, Periodic, RectilinearGrid, _regular_coordinate
+from .grids import (Bounded, Center, Face, FullyConnected, LeftConnected, Periodic, RectilinearGrid, RightConnected,
+                    _regular_coordinate)
 
 RK3 = dict(γ1=8 / 15, γ2=5 / 12, γ3=3 / 4, ζ2=-17 / 60, ζ3=-5 / 12)   # runge_kutta_3.jl:69-74 (FT rationals)
 
@@ -264,8 +265,9 @@ class DistributedRectilinearGrid:
         if extent is not None:
             x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
         self.global_size = tuple(int(n) for n in size)
-        if topology[0] is not Periodic:
-            raise NotImplementedError("only a Periodic partitioned direction is accelerated (Left / RightConnected ends: not yet)")
+        if topology[0] not in (Periodic, Bounded):
+            raise ValueError("the partitioned direction is Periodic or Bounded")
+        self.global_x_topology = topology[0]
         # local_size (distributed_grids.jl:44-58): the remainder of Nx / R goes to the last rank
         self.local_sizes = local_sizes(self.global_size[0], R)
         self.irregular = len(set(self.local_sizes)) > 1
@@ -273,7 +275,14 @@ class DistributedRectilinearGrid:
         self.x_global = (float(x[0]), float(x[1]))
         self.Lx_global = _regular_coordinate(x, self.global_size[0], "x")[1]
         xl = x if R == 1 else partition_coordinate(x, self.local_sizes, R, r)
-        topo = (FullyConnected if ctx.partitioned else topology[0], topology[1], topology[2])
+        # insert_connected_topology (distributed_grids.jl:339-346)
+        if not ctx.partitioned:
+            tx = topology[0]
+        elif topology[0] is Periodic:
+            tx = FullyConnected
+        else:
+            tx = RightConnected if r == 0 else (LeftConnected if r == R - 1 else FullyConnected)
+        topo = (tx, topology[1], topology[2])
         self.local_size = (nxl, self.global_size[1], self.global_size[2])
         self.i_offset = sum(self.local_sizes[:r])    # global index of local i = 1 minus one
         if make_local_grid is None:
@@ -290,8 +299,8 @@ class DistributedRectilinearGrid:
 # ----------------------------------------------------------------------------------------------------------------------
 class DeviceBackend:
     def __init__(self, ctx, grid, ntracers):
-        if getattr(grid, "irregular", False):
-            raise NotImplementedError("irregular partitions (Nx % R != 0) run through LibraryDistributedModel (gathered pressure solve)")
+        if getattr(grid, "irregular", False) or getattr(grid, "global_x_topology", Periodic) is Bounded:
+            raise NotImplementedError("irregular and Bounded partitions run through LibraryDistributedModel (gathered pressure solve)")
         self.ctx, self.grid, self.ntracers = ctx, grid, ntracers
         torch = ctx.torch
         g = grid.local
@@ -1013,10 +1022,11 @@ class LibraryDistributedModel(_NonhydrostaticModel):
 
     def _create_handle(self, grid, ntracers):
         h = C.c_void_p()
-        if getattr(grid, "irregular", False):
+        bounded = getattr(grid, "global_x_topology", Periodic) is Bounded
+        if getattr(grid, "irregular", False) or bounded:
             sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
-            _lib.check(_lib.lib().ocn_dist_model_create_sizes(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
-                                                              float(grid.Lx_global), sizes))
+            _lib.check(_lib.lib().ocn_dist_model_create_partition(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
+                                                                  float(grid.Lx_global), sizes, 1 if bounded else 0))
         else:
             _lib.check(_lib.lib().ocn_dist_model_create(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global)))
         return h

@@ -25,6 +25,16 @@ class Flat:
     code = 3
 
 
+class RightConnected:
+    """first rank of a Bounded partitioned direction: a wall on the left, a neighbour on the right (distributed_grids.jl:339-346)"""
+    code = 4
+
+
+class LeftConnected:
+    """last rank: a neighbour on the left, a wall on the right; Face fields hold N + 1 points like on Bounded (grid_utils.jl:43-68)"""
+    code = 5
+
+
 class Center:
     code = 0
 
@@ -175,11 +185,11 @@ class RectilinearGrid:
 
     def total_size(self, loc):
         """total_size(loc, topo, N, H) (grid_utils.jl:138-169)"""
-        return tuple(n + 2 * h + (1 if (l is Face and t is Bounded) else 0)
+        return tuple(n + 2 * h + (1 if (l is Face and t in (Bounded, LeftConnected)) else 0)
                      for n, h, l, t in zip(self.size, self.halo_size, loc, self.topology))
 
     def interior_size(self, loc):
-        return tuple(n + (1 if (l is Face and t is Bounded) else 0) for n, l, t in zip(self.size, loc, self.topology))
+        return tuple(n + (1 if (l is Face and t in (Bounded, LeftConnected)) else 0) for n, l, t in zip(self.size, loc, self.topology))
 
     def nodes(self, loc):
         """interior node coordinates (xnodes, ynodes, znodes) as broadcastable arrays"""
@@ -187,7 +197,7 @@ class RectilinearGrid:
         for d, (n, l, t) in enumerate(zip(self.size, loc, self.topology)):
             delta = (self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ, self._dz)[d]
             origin = (self.x0, self.y0, getattr(self, "z0", 0.0))[d]
-            m = n + (1 if (l is Face and t is Bounded) else 0)
+            m = n + (1 if (l is Face and t in (Bounded, LeftConnected)) else 0)
             if d == 2 and not self.z_regular:
                 arr = self.zᵃᵃᶠ[self.Hz:self.Hz + m] if l is Face else self.zᵃᵃᶜ[self.Hz:self.Hz + m]
             else:

@@ -26,8 +26,13 @@ def _own_stream():
     _lib.check(_lib.lib().ocn_own_stream())
 
 
-def _single_gpu(ocn, arch, size, zkind, nsteps):
+def _xb(ocn, topo, xbounded, ybounded=False):
+    return ((ocn.Bounded if xbounded else topo[0]), (ocn.Bounded if ybounded else topo[1]), topo[2])
+
+
+def _single_gpu(ocn, arch, size, zkind, nsteps, xbounded=False, ybounded=False):
     z, topo = _z_and_topology(ocn, zkind, size[2])
+    topo = _xb(ocn, topo, xbounded, ybounded)
     grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
                                     buoyancy=_tracers_and_buoyancy(ocn, zkind)[1], coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
@@ -40,8 +45,9 @@ def _single_gpu(ocn, arch, size, zkind, nsteps):
     return out, model.clock.time, dt
 
 
-def _library_model(ocn, dist, ctx, size, zkind):
+def _library_model(ocn, dist, ctx, size, zkind, xbounded=False, ybounded=False):
     z, topo = _z_and_topology(ocn, zkind, size[2])
+    topo = _xb(ocn, topo, xbounded, ybounded)
     grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
                                          buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
@@ -53,7 +59,8 @@ def _library_model(ocn, dist, ctx, size, zkind):
 def _compare(out, ref, r, nxl, size, offset=None):
     i0 = r * nxl if offset is None else offset
     for name, a in out.items():
-        want = ref[name][3 + i0:3 + i0 + nxl, 3:-3, 3:-3]
+        n = a.shape[0] - 6                  # nxl, or nxl + 1 for the Face-in-x field of a LeftConnected rank (its wall face)
+        want = ref[name][3 + i0:3 + i0 + n, 3:3 + a.shape[1] - 6, 3:3 + a.shape[2] - 6]
         scale = np.abs(ref[name]).max()
         err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / scale
         assert err <= 1e-12, (r, name, err, int(np.isnan(a).sum()))
@@ -135,7 +142,7 @@ def test_library_collectives_over_rccl_world_1(ocn, arch):
     _lib.check(L.ocn_dist_destroy(d))
 
 
-def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options):
+def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=False, ybounded=False):
     from oldoceananigans_jl_amd import _lib, distributed as dist
     from loopback import PointerLoopbackWorld
     world = PointerLoopbackWorld(R, _lib.lib())
@@ -145,7 +152,7 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options):
     def worker(rank):
         try:
             ctx = dist.Distributed.transport(arch, world.collectives(rank), R, rank)
-            grid, model = _library_model(ocn, dist, ctx, size, zkind)
+            grid, model = _library_model(ocn, dist, ctx, size, zkind, xbounded, ybounded)
             for k, v in options.items():
                 model.set_option(k, v)
             for _ in range(nsteps):
@@ -158,6 +165,8 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options):
                 f.set_parent(np.full(f.shape, 100.0 * n + rank))
             ocn.update_state(model, False)
             west, east = (rank - 1) % R, (rank + 1) % R
+            if xbounded:                        # a wall side has no neighbour: the halo keeps what the local boundary fill leaves (own id)
+                west, east = (rank if rank == 0 else west), (rank if rank == R - 1 else east)
             for n, f in enumerate(model.fields().values()):
                 a = f.parent()
                 assert np.all(a[:3, 3:-3, 3:-3] == 100 * n + west) and np.all(a[-3:, 3:-3, 3:-3] == 100 * n + east), (rank, n)
@@ -224,6 +233,31 @@ def test_library_irregular_partition_matches_single_gpu(ocn, arch, R, size, zkin
     for r, (out, div, t) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, sizes[r], size, offset=sum(sizes[:r]))
+
+
+@pytest.mark.parametrize("R,size,zkind,ybounded", [
+    (3, (25, 8, 6), "periodic", False),     # (Bounded, Periodic, Periodic), 8 + 8 + 9 columns: Right-, Fully-, LeftConnected ranks
+    (2, (16, 8, 6), "periodic", False),     # two ranks: a RightConnected and a LeftConnected one, no FullyConnected rank
+    (4, (32, 8, 8), "bounded", False),      # (Bounded, Periodic, Bounded): Fourier-tridiagonal solver, ScalarDiffusivity, buoyancy
+    (3, (24, 9, 6), "bounded", True),       # (Bounded, Bounded, Bounded): the one Bounded-x topology the reference's distributed solvers take
+    (4, (30, 8, 8), "stretched", False),    # stretched z, Coriolis next to the walls, boundary conditions, irregular slabs
+    (3, (24, 8, 8), "amd", False),          # the configs[4] physics next to walls
+])
+def test_library_bounded_partition_matches_single_gpu(ocn, arch, R, size, zkind, ybounded):
+    """a Bounded partitioned direction: insert_connected_topology (distributed_grids.jl:339-346) gives the first rank a RightConnected
+    local grid (wall on its west side), the last one a LeftConnected one (wall on the east side, Nx + 1 x-faces), the others
+    FullyConnected; the advection scheme falls back next to the wall side only (topologically_conditional_interpolation.jl:54-70),
+    boundary conditions fill the wall side, the ring has no wrap-around neighbour. Against the single-GPU model on the global grid."""
+    _own_stream()
+    from oldoceananigans_jl_amd import distributed as dist
+    nsteps = 3
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, {}, xbounded=True, ybounded=ybounded)
+    ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps, xbounded=True, ybounded=ybounded)
+    sizes = dist.local_sizes(size[0], R)
+    for r, (out, div, t) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, sizes[r], size, offset=sum(sizes[:r]))
+        assert out["u"].shape[0] == sizes[r] + 6 + (1 if r == R - 1 else 0)
 
 
 def test_library_transposing_solver_matches(ocn, arch):
