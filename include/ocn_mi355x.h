@@ -391,6 +391,10 @@ typedef struct {
     int (*all_gather)(void *user, const double *send, double *recv, size_t count, void *stream);
     int (*allreduce_max)(void *user, double *value);
     void *user;
+    /* pencil partitions only (may be NULL otherwise): one exchange with an explicit pair of peer ranks, complete in stream order when it
+     * returns -- `lo_send` goes to peer_lo and lands in ITS hi_recv, `hi_send` goes to peer_hi and lands in its lo_recv */
+    int (*exchange_peers)(void *user, int peer_lo, int peer_hi, const double *lo_send, const double *hi_send, double *lo_recv,
+                          double *hi_recv, size_t count, void *stream);
 } ocn_transport_t;
 int ocn_dist_create_transport(ocn_dist_t *dist, const ocn_transport_t *transport, int world, int rank);
 int ocn_dist_destroy(ocn_dist_t dist);
@@ -428,6 +432,15 @@ int ocn_dist_model_create_sizes(ocn_model_t *model, ocn_grid_t local_grid, int n
  * solve takes the gathered form on the global Bounded grid (cosine transform along x). */
 int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
                                     const int *local_sizes, int global_x_topology);
+/* Partition(Rx, Ry) pencils (distributed_architectures.jl:354-434: rank = ix * Ry + iy, periodic wrap of the four neighbours):
+ * ocn_dist_set_layout fixes the layout of a communicator (ocn_dist_model_create_pencil calls it); the local grid is connected in x when
+ * Rx > 1 (codes as above) and OCN_CONNECTED in y when Ry > 1 (global y Periodic). sizes_x[Rx] / sizes_y[Ry]: slab widths (NULL: equal).
+ * Every fill makes two hops -- x, then y over the whole x extent -- so corners arrive without corner messages
+ * (fill_corners!, halo_communication.jl:137-162); solve! is the gathered solve on the global grid (the reference's pencil transposes,
+ * distributed_transpose.jl:12-15, are not built). */
+int ocn_dist_set_layout(ocn_dist_t dist, int Rx, int Ry);
+int ocn_dist_model_create_pencil(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                 double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology);
 int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus

@@ -40,11 +40,13 @@ class Transport(C.Structure):
     ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     ALLREDUCE_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
+    EXCHANGE_PEERS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 Transport._fields_ = [("exchange_start", Transport.EXCHANGE_START), ("exchange_wait", Transport.EXCHANGE_WAIT),
                       ("all_to_all", Transport.ALL_TO_ALL), ("all_gather", Transport.ALL_GATHER),
-                      ("allreduce_max", Transport.ALLREDUCE_MAX), ("user", C.c_void_p)]
+                      ("allreduce_max", Transport.ALLREDUCE_MAX), ("user", C.c_void_p),
+                      ("exchange_peers", Transport.EXCHANGE_PEERS)]
 
 SYMBOLS = {
     "ocn_dist_unique_id": (C.c_int, [_vp]),
@@ -62,6 +64,8 @@ SYMBOLS = {
     "ocn_dist_model_create": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double]),
     "ocn_dist_model_create_sizes": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip]),
     "ocn_dist_model_create_partition": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip, C.c_int]),
+    "ocn_dist_set_layout": (C.c_int, [_vp, C.c_int, C.c_int]),
+    "ocn_dist_model_create_pencil": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, C.c_int]),
     "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_sync": (C.c_int, []),

@@ -185,7 +185,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
             continue;
         }
         const bool connected = topo[d] == OCN_CONNECTED || topo[d] == OCN_RIGHT_CONNECTED || topo[d] == OCN_LEFT_CONNECTED;
-        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(connected && d == 0))
+        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(connected && d == 0) && !(topo[d] == OCN_CONNECTED && d == 1))
             return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) Fully / Right / LeftConnected "
                                      "are accelerated", topo[d], d);
         // adapt_advection_order (Advection/adapt_advection_order.jl:90-96): WENO(order=5) stays where N >= 3 and becomes
@@ -2210,8 +2210,8 @@ static int model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers, bool 
 
 extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
     NEED_INIT();
-    if (grid && (grid->d.tx == OCN_CONNECTED || grid->d.tx == OCN_RIGHT_CONNECTED || grid->d.tx == OCN_LEFT_CONNECTED))
-        return fail(OCN_EINVAL, "a connected x direction needs ocn_dist_model_create");
+    if (grid && (grid->d.tx == OCN_CONNECTED || grid->d.tx == OCN_RIGHT_CONNECTED || grid->d.tx == OCN_LEFT_CONNECTED || grid->d.ty == OCN_CONNECTED))
+        return fail(OCN_EINVAL, "a connected x or y direction needs ocn_dist_model_create");
     return model_create(model, grid, ntracers, true);
 }
 

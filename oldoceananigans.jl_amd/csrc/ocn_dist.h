@@ -64,6 +64,7 @@ static int rccl_load() {
 
 struct ocn_dist_s {
     int world = 1, rank = 0, west = 0, east = 0;
+    int Rx = 1, Ry = 1, south = 0, north = 0;    // pencil layout (ocn_dist_set_layout): rank = ix * Ry + iy
     int kind = 0;                       // 0 RCCL, 1 caller-supplied transport
     void *comm = nullptr;               // ncclComm_t
     hipStream_t comm_stream = nullptr;  // halo transfers (overlap with kernels on the compute stream)
@@ -99,6 +100,7 @@ static int dist_common_init(ocn_dist_s *d, int world, int rank) {
     d->world = world; d->rank = rank;
     d->west = (rank - 1 + world) % world;          // periodic wrap of the x neighbours (distributed_architectures.jl:391-434)
     d->east = (rank + 1) % world;
+    d->Rx = world; d->Ry = 1; d->south = d->north = rank;
     HIP_TRY(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d->done, hipEventDisableTiming));
     HIP_TRY(dev_alloc((void **)&d->scalar, 2 * sizeof(double)));
@@ -156,6 +158,37 @@ extern "C" int ocn_dist_info(ocn_dist_t d, int *world, int *rank, int *west, int
     if (rank) *rank = d->rank;
     if (west) *west = d->west;
     if (east) *east = d->east;
+    return OCN_OK;
+}
+
+// Partition(Rx, Ry): rank2index / index2rank with the LAST index fastest (distributed_architectures.jl:354-389) and periodic wrap of
+// the four neighbours (:391-434). Call before the model is created.
+extern "C" int ocn_dist_set_layout(ocn_dist_t d, int Rx, int Ry) {
+    if (!d || Rx < 1 || Ry < 1 || Rx * Ry != d->world) return fail(OCN_EINVAL, "Rx * Ry must equal the number of ranks");
+    d->Rx = Rx; d->Ry = Ry;
+    const int ix = d->rank / Ry, iy = d->rank % Ry;
+    d->west = ((ix - 1 + Rx) % Rx) * Ry + iy;
+    d->east = ((ix + 1) % Rx) * Ry + iy;
+    d->south = ix * Ry + (iy - 1 + Ry) % Ry;
+    d->north = ix * Ry + (iy + 1) % Ry;
+    return OCN_OK;
+}
+
+// one exchange with an explicit pair of peers, ordered on the compute stream (pencil partitions: the x and the y hop of a fill):
+// what leaves through the low side arrives in peer_lo's HIGH halo
+static int dist_exchange_pair(ocn_dist_t d, int peer_lo, int peer_hi, const double *lo_send, const double *hi_send, double *lo_recv,
+                              double *hi_recv, size_t count) {
+    if (d->kind == 1) {
+        if (!d->tr.exchange_peers) return fail(OCN_ENOTSUP, "this transport has no exchange_peers entry (needed by pencil partitions)");
+        int rc = d->tr.exchange_peers(d->tr.user, peer_lo, peer_hi, lo_send, hi_send, lo_recv, hi_recv, count, (void *)g_stream);
+        return rc ? fail(rc, "transport exchange_peers failed") : OCN_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY(g_rccl.Send(lo_send, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
+    NCCL_TRY(g_rccl.Recv(hi_recv, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
+    NCCL_TRY(g_rccl.Send(hi_send, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
+    NCCL_TRY(g_rccl.Recv(lo_recv, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
+    NCCL_TRY(g_rccl.GroupEnd());
     return OCN_OK;
 }
 
@@ -260,7 +293,7 @@ struct GatheredSolve {
     ocn_poisson_s *solver = nullptr;    // the single-GPU solver on it
     double *loc = nullptr, *all = nullptr, *gp = nullptr;   // own source term (nmax, Ny, Nz); all ranks' (.., R); global haloed solution
     SlabTable table = {};
-    int nmax = 0, Nxg = 0;
+    int nmax = 0, Nxg = 0, nymax = 0, Nyg = 0;
 };
 
 struct DistModel {
@@ -278,6 +311,9 @@ struct DistModel {
     int early_exchange = 1;     // start update_state!'s exchange from make_pressure_correction!
     int strip_width = 0;        // 0 automatic
     bool bounded_x = false;     // the partitioned direction is Bounded: Right / LeftConnected end ranks, no wrap-around neighbour
+    bool pencil = false;        // Partition(Rx, Ry) with Ry > 1: a second hop along y per fill (corners ride along)
+    double *ss = nullptr, *ns = nullptr, *sr = nullptr, *nr = nullptr;     // y-halo buffers: Hy rows of every prognostic field per side
+    bool general() const { return bounded_x || pencil; }                    // no overlap / thin exchanges on such partitions
     bool partitioned() const { return dist->world > 1 || dist->self_loop; }
 };
 
@@ -291,6 +327,7 @@ static void dist_model_free(DistModel *dm) {
         delete dm->gs;
     }
     hipFree(dm->ws); hipFree(dm->es); hipFree(dm->wr); hipFree(dm->er); hipFree(dm->p2); hipFree(dm->buf_a);
+    hipFree(dm->ss); hipFree(dm->ns); hipFree(dm->sr); hipFree(dm->nr);
     if (dm->buf_b != dm->buf_a) hipFree(dm->buf_b);
     delete dm;
 }
@@ -301,6 +338,33 @@ static size_t dist_slab(const DGrid &g, const int loc[3], int depth) {
     return (size_t)depth * P[1] * P[2];
 }
 
+static size_t dist_rows(const DGrid &g, const int loc[3], int depth) {
+    int P[3];
+    parent_size(g, loc, P);
+    return (size_t)depth * P[0] * P[2];
+}
+
+static int y_halo_buffers(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *south, double *north, bool pack) {
+    FieldList fl;
+    RowList rl;
+    fl.n = n;
+    long off = 0, maxt = 0;
+    for (int f = 0; f < n; ++f) {
+        int P[3];
+        parent_size(g, locs[f], P);
+        fl.p[f] = fields[f];
+        rl.off[f] = off; rl.p0[f] = P[0]; rl.p1[f] = P[1]; rl.p2[f] = P[2];
+        const long cnt = (long)g.Hy * P[0] * P[2];
+        off += cnt;
+        maxt = std::max(maxt, cnt);
+    }
+    const int nb = (int)((maxt + 255) / 256);
+    if (pack) hipLaunchKernelGGL(y_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north, true, true);
+    else      hipLaunchKernelGGL(y_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north, true, true);
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
 // fill_halo_regions! of partitioned fields (halo_communication.jl:87-110): local boundary conditions first
 // (boundary_condition_ordering.jl: the communication condition last), then the x exchange of `nx` leading fields, `depth` columns
 static int dist_fill_halo_regions(ocn_model_s *m, double *const *fields, const int (*locs)[3], int n, bool fill_open,
@@ -309,14 +373,28 @@ static int dist_fill_halo_regions(ocn_model_s *m, double *const *fields, const i
     int rc = fill_halo_regions(m->grid, fields, locs, n, fill_open, bcs);
     if (rc || !dm->partitioned()) return rc;
     const DGrid &g = m->grid->d;
-    if (nx < 0) nx = n;
-    if (depth <= 0) depth = g.Hx;
+    if (nx < 0 || dm->pencil) nx = n;
+    if (depth <= 0 || dm->pencil) depth = g.Hx;
     size_t count = 0;
     for (int f = 0; f < nx; ++f) count += dist_slab(g, locs[f], depth);
-    if ((rc = x_halo_buffers(g, fields, locs, nx, dm->ws, dm->es, true, depth))) return rc;
-    if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, count))) return rc;
-    if ((rc = ocn_dist_exchange_wait(dm->dist))) return rc;
-    return x_halo_buffers(g, fields, locs, nx, dm->wr, dm->er, false, depth);
+    if (dm->dist->Rx > 1 || dm->dist->self_loop) {
+        if ((rc = x_halo_buffers(g, fields, locs, nx, dm->ws, dm->es, true, depth))) return rc;
+        if (dm->pencil) {
+            if ((rc = dist_exchange_pair(dm->dist, dm->dist->west, dm->dist->east, dm->ws, dm->es, dm->wr, dm->er, count))) return rc;
+        } else {
+            if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, count))) return rc;
+            if ((rc = ocn_dist_exchange_wait(dm->dist))) return rc;
+        }
+        if ((rc = x_halo_buffers(g, fields, locs, nx, dm->wr, dm->er, false, depth))) return rc;
+    }
+    if (!dm->pencil) return OCN_OK;
+    // second hop: Hy rows over the whole x extent -- the x halos received above included, which carries the corners
+    // (fill_corners!, halo_communication.jl:137-162, as two one-dimensional hops)
+    size_t county = 0;
+    for (int f = 0; f < n; ++f) county += dist_rows(g, locs[f], g.Hy);
+    if ((rc = y_halo_buffers(g, fields, locs, n, dm->ss, dm->ns, true))) return rc;
+    if ((rc = dist_exchange_pair(dm->dist, dm->dist->south, dm->dist->north, dm->ss, dm->ns, dm->sr, dm->nr, county))) return rc;
+    return y_halo_buffers(g, fields, locs, n, dm->sr, dm->nr, false);
 }
 
 // solve_for_pressure! + solve!(::DistributedFFTBasedPoissonSolver | ::DistributedFourierTridiagonalPoissonSolver)
@@ -328,21 +406,21 @@ static int dist_solve_for_pressure(ocn_model_s *m) {
         GatheredSolve *q = dm->gs;
         const DGrid &g = m->grid->d, &G = q->ggrid->d;
         ocn_poisson_s *ps = q->solver;
-        const size_t piece = (size_t)q->nmax * g.Ny * g.Nz;
-        if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], q->loc, ps->kind == 1, true, q->nmax, (long)q->nmax * g.Ny))) return rc;
+        const size_t piece = (size_t)q->nmax * q->nymax * g.Nz;
+        if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], q->loc, ps->kind == 1, true, q->nmax, (long)q->nmax * q->nymax))) return rc;
         if ((rc = ocn_dist_all_gather(dm->dist, q->loc, q->all, piece))) return rc;
         const bool real_path = g_real_fft && !ps->general;
         if (!real_path && (rc = ensure_complex(ps))) return rc;
         if (real_path)
             hipLaunchKernelGGL(gather_assemble_kernel<false>, grid3(G.Nx, G.Ny, G.Nz, BLK), BLK, 0, g_stream, (const double *)q->all, (void *)ps->rrhs,
-                               q->table, q->nmax, G.Nx, G.Ny, G.Nz);
+                               q->table, q->nmax, q->nymax, G.Nx, G.Ny, G.Nz);
         else
             hipLaunchKernelGGL(gather_assemble_kernel<true>, grid3(G.Nx, G.Ny, G.Nz, BLK), BLK, 0, g_stream, (const double *)q->all,
-                               (void *)(ps->kind == 0 ? ps->storage : ps->source), q->table, q->nmax, G.Nx, G.Ny, G.Nz);
+                               (void *)(ps->kind == 0 ? ps->storage : ps->source), q->table, q->nmax, q->nymax, G.Nx, G.Ny, G.Nz);
         KERNEL_CHECK();
         if ((rc = real_path ? poisson_solve_real(ps, q->gp) : poisson_solve(ps, q->gp))) return rc;
         hipLaunchKernelGGL(slab_extract_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, dm->p2, LOC_C),
-                           make_view(G, q->gp, LOC_C), q->table.first[dm->dist->rank]);
+                           make_view(G, q->gp, LOC_C), q->table.first[dm->dist->rank / dm->dist->Ry], q->table.firsty[dm->dist->rank % dm->dist->Ry]);
         KERNEL_CHECK();
         return OCN_OK;
     }
@@ -370,7 +448,7 @@ static int dist_solve_for_pressure(ocn_model_s *m) {
 // p here; `thin_halos` exchanges the one column of u and of p -- identical results in every cell that is read.
 static int dist_compute_pressure_correction(ocn_model_s *m) {
     DistModel *dm = m->dm;
-    const bool thin = dm->thin_halos != 0;
+    const bool thin = dm->thin_halos != 0 && !dm->pencil;
     int rc = dist_fill_halo_regions(m, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr, thin ? 1 : 3, thin ? 1 : 0);
     if (rc) return rc;
     if ((rc = dist_solve_for_pressure(m))) return rc;
@@ -389,7 +467,7 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     int rc;
     auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], dm->p2, range, m->p, dtp); };
-    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx) || dm->bounded_x) {
+    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx) || dm->general()) {
         return pc(nullptr);
     }
     const int west[6] = {1, g.Hx, 1, g.Ny, 1, g.Nz}, east[6] = {g.Nx - g.Hx + 1, g.Nx, 1, g.Ny, 1, g.Nz};
@@ -414,7 +492,8 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     // Periodic grid's fill copies from the other side): no exchange of the diffusivity fields
     // (on a wall side the halo of the diffusivities comes from their boundary condition, like on a serial Bounded grid)
     const int ext = dm->partitioned() ? 1 : 0;
-    const int amd_range[6] = {1 - (wall_lo(g.tx) ? 0 : ext), g.Nx + (wall_hi(g.tx) ? 0 : ext), 1, g.Ny, 1, g.Nz};
+    const int ey = dm->pencil ? 1 : 0;                 // ... and along y on pencils
+    const int amd_range[6] = {1 - (wall_lo(g.tx) ? 0 : ext), g.Nx + (wall_hi(g.tx) ? 0 : ext), 1 - ey, g.Ny + ey, 1, g.Nz};
     int rc;
     if (dm->halos_in_flight) {
         // the x exchange was started by make_pressure_correction!: finish the local fills (all columns are final now), take the
@@ -427,7 +506,7 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     }
     const bool physics = has_physics(m) || m->any_flux_bc || m->any_linear_flux;
     const bool overlap = dm->async_halos < 0 ? g.Nx >= 3 * 64 : dm->async_halos != 0;
-    if (!compute_tend || !dm->partitioned() || !overlap || g.Nx <= 2 * g.Hx || physics || dm->bounded_x) {
+    if (!compute_tend || !dm->partitioned() || !overlap || g.Nx <= 2 * g.Hx || physics || dm->general()) {
         if ((rc = dist_fill_halo_regions(m, m->U, m->loc, m->nf, false, bcs))) return rc;
         return update_state_tail(m, compute_tend, sub, amd_range);
     }
@@ -459,9 +538,21 @@ static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow)
 // NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected
 // (OCN_CONNECTED) when the direction is partitioned; `Lx_global`: extent of the global domain along x (the solver's eigenvalues)
 static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
-                             int global_x_topology);
+                             int global_x_topology, double Ly_global = 0.0, const int *sizes_y = nullptr);
 extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global) {
     return dist_model_create(model, local_grid, ntracers, dist, Lx_global, nullptr, OCN_PERIODIC);
+}
+// Partition(Rx, Ry) pencils (f.4 of SURVEY.md 8): rank = ix * Ry + iy, the local grid is connected in x (Rx > 1) and FullyConnected in y
+// (Ry > 1, global y Periodic); sizes_x[Rx], sizes_y[Ry] list the slab widths (NULL: equal). Every fill makes two hops -- x, then y over
+// the whole x extent, so the corners arrive without corner messages (halo_communication.jl:137-162) --; the pressure solve is the
+// gathered one (the reference's pencil transposes, distributed_transpose.jl:12-15, are not built).
+extern "C" int ocn_dist_model_create_pencil(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
+                                            double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology) {
+    if (!dist) return fail(OCN_EINVAL, "NULL argument");
+    if (global_x_topology != OCN_PERIODIC && global_x_topology != OCN_BOUNDED) return fail(OCN_EINVAL, "the x direction is Periodic or Bounded");
+    int rc = ocn_dist_set_layout(dist, Rx, Ry);
+    if (rc) return rc;
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, sizes_x, global_x_topology, Ly_global, sizes_y);
 }
 // the same for an irregular partition: local_sizes[r] = Nx of rank r (local_size, distributed_grids.jl:44-58: N ÷ R cells per rank and
 // the remainder on the last one; or any `Sizes`). Equal sizes take the solvers above; otherwise the pressure solve gathers the source
@@ -482,54 +573,68 @@ extern "C" int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t lo
     return dist_model_create(model, local_grid, ntracers, dist, Lx_global, local_sizes, global_x_topology);
 }
 
-static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes, int global_tx) {
+static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes, int global_tx, double Ly_global,
+                                 const int *sizes_y) {
     const DGrid &g = local_grid->d;
-    const int R = dm->dist->world;
-    if (R > OCN_MAX_RANKS) return fail(OCN_ENOTSUP, "irregular partitions take at most %d ranks", OCN_MAX_RANKS);
+    const int R = dm->dist->Rx, Ry = dm->dist->Ry, ix = dm->dist->rank / Ry, iy = dm->dist->rank % Ry;
+    if (dm->dist->world > OCN_MAX_RANKS) return fail(OCN_ENOTSUP, "gathered solves take at most %d ranks", OCN_MAX_RANKS);
     GatheredSolve *q = new GatheredSolve();
     dm->gs = q;
-    q->table.R = R;
+    q->table.R = R; q->table.Ry = Ry;
     for (int r = 0; r < R; ++r) {
-        if (sizes[r] < g.Hx) return fail(OCN_EINVAL, "rank %d holds %d columns, fewer than the halo %d", r, sizes[r], g.Hx);
+        if (R > 1 && sizes[r] < g.Hx) return fail(OCN_EINVAL, "x slab %d holds %d columns, fewer than the halo %d", r, sizes[r], g.Hx);
         q->table.first[r] = q->Nxg;
         q->Nxg += sizes[r];
         q->nmax = std::max(q->nmax, sizes[r]);
     }
     q->table.first[R] = q->Nxg;
-    if (sizes[dm->dist->rank] != g.Nx) return fail(OCN_EINVAL, "local_sizes[%d] = %d but the local grid has Nx = %d", dm->dist->rank, sizes[dm->dist->rank], g.Nx);
-    const int N[3] = {q->Nxg, g.Ny, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {global_tx, g.ty, g.tz};
-    const double L[3] = {Lx_global, local_grid->L[1], local_grid->L[2]};
+    for (int r = 0; r < Ry; ++r) {
+        const int ny = sizes_y ? sizes_y[r] : g.Ny;
+        if (Ry > 1 && ny < g.Hy) return fail(OCN_EINVAL, "y slab %d holds %d rows, fewer than the halo %d", r, ny, g.Hy);
+        q->table.firsty[r] = q->Nyg;
+        q->Nyg += ny;
+        q->nymax = std::max(q->nymax, ny);
+    }
+    q->table.firsty[Ry] = q->Nyg;
+    if (sizes[ix] != g.Nx) return fail(OCN_EINVAL, "sizes_x[%d] = %d but the local grid has Nx = %d", ix, sizes[ix], g.Nx);
+    if ((sizes_y ? sizes_y[iy] : g.Ny) != g.Ny) return fail(OCN_EINVAL, "sizes_y[%d] = %d but the local grid has Ny = %d", iy, sizes_y[iy], g.Ny);
+    const int N[3] = {q->Nxg, q->Nyg, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {global_tx, Ry > 1 ? OCN_PERIODIC : g.ty, g.tz};
+    const double L[3] = {Lx_global, Ry > 1 ? Ly_global : local_grid->L[1], local_grid->L[2]};
     const bool zr = local_grid->z_regular;
-    int rc = ocn_grid_create(&q->ggrid, N, H, topo, L, Lx_global / (double)q->Nxg, g.dy, local_grid->h_dzc[g.Hz],
+    int rc = ocn_grid_create(&q->ggrid, N, H, topo, L, Lx_global / (double)q->Nxg, Ry > 1 ? Ly_global / (double)q->Nyg : g.dy, local_grid->h_dzc[g.Hz],
                              zr ? nullptr : local_grid->h_dzc.data(), zr ? nullptr : local_grid->h_dzf.data());
     if (rc) return rc;
     if ((rc = ocn_poisson_create(&q->solver, q->ggrid, -1))) return rc;
     int P[3];
     parent_size(q->ggrid->d, LOC_C, P);
-    const size_t piece = (size_t)q->nmax * g.Ny * g.Nz;
+    const size_t piece = (size_t)q->nmax * q->nymax * g.Nz;
     HIP_TRY(dev_alloc((void **)&q->loc, piece * sizeof(double)));
-    HIP_TRY(dev_alloc((void **)&q->all, piece * (size_t)R * sizeof(double)));
+    HIP_TRY(dev_alloc((void **)&q->all, piece * (size_t)dm->dist->world * sizeof(double)));
     HIP_TRY(dev_alloc((void **)&q->gp, (size_t)P[0] * P[1] * P[2] * sizeof(double)));
     HIP_TRY(hipMemsetAsync(q->loc, 0, piece * sizeof(double), g_stream));
-    HIP_TRY(hipMemsetAsync(q->all, 0, piece * (size_t)R * sizeof(double), g_stream));
+    HIP_TRY(hipMemsetAsync(q->all, 0, piece * (size_t)dm->dist->world * sizeof(double), g_stream));
     HIP_TRY(hipMemsetAsync(q->gp, 0, (size_t)P[0] * P[1] * P[2] * sizeof(double), g_stream));
     return OCN_OK;
 }
 
 static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
-                             int global_x_topology) {
+                             int global_x_topology, double Ly_global, const int *sizes_y) {
     NEED_INIT();
     if (!model || !local_grid || !dist) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
-    const bool part = dist->world > 1 || dist->self_loop;
+    const bool pencil = dist->Ry > 1;
+    const int Rx = dist->Rx, ix = dist->rank / dist->Ry;
+    const bool part = Rx > 1 || dist->self_loop;         // the x direction is partitioned
     const bool bounded_x = global_x_topology == OCN_BOUNDED;
     // insert_connected_topology (distributed_grids.jl:339-346)
     const int expect = !part ? global_x_topology
-                             : (!bounded_x ? OCN_CONNECTED
-                                           : (dist->rank == 0 ? OCN_RIGHT_CONNECTED : (dist->rank == dist->world - 1 ? OCN_LEFT_CONNECTED : OCN_CONNECTED)));
+                             : (!bounded_x ? OCN_CONNECTED : (ix == 0 ? OCN_RIGHT_CONNECTED : (ix == Rx - 1 ? OCN_LEFT_CONNECTED : OCN_CONNECTED)));
     if (bounded_x && dist->self_loop) return fail(OCN_EINVAL, "self_loop closes a Periodic direction");
     if (g.tx != expect)
         return fail(OCN_EINVAL, "rank %d of %d: the local grid's x topology code is %d, insert_connected_topology gives %d", dist->rank, dist->world, g.tx, expect);
+    if (pencil && g.ty != OCN_CONNECTED) return fail(OCN_EINVAL, "the local grid of a pencil partition is FullyConnected in y (global y Periodic)");
+    if (!pencil && g.ty == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected y direction needs Ry > 1 (ocn_dist_model_create_pencil)");
+    if (pencil && dist->self_loop) return fail(OCN_EINVAL, "self_loop has one rank");
     int rc = model_create(model, local_grid, ntracers, /*with_solver=*/false);
     if (rc) return rc;
     ocn_model_s *m = *model;
@@ -554,12 +659,24 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
     }
     bool irregular = false;
     if (local_sizes)
-        for (int r = 0; r < dist->world; ++r) irregular = irregular || local_sizes[r] != local_sizes[0];
+        for (int r = 0; r < Rx; ++r) irregular = irregular || local_sizes[r] != local_sizes[0];
     dm->bounded_x = bounded_x && part;
-    if (irregular || dm->bounded_x) {
+    dm->pencil = pencil;
+    if (pencil) {
+        size_t rows = 0;
+        for (int f = 0; f < m->nf; ++f) rows += dist_rows(g, m->loc[f], g.Hy);
+        double **yb[4] = {&dm->ss, &dm->ns, &dm->sr, &dm->nr};
+        for (auto b : yb) {
+            hipError_t e = dev_alloc((void **)b, rows * sizeof(double));
+            if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(y halo buffers): %s", hipGetErrorString(e)));
+            hipMemsetAsync(*b, 0, rows * sizeof(double), g_stream);
+        }
+    }
+    if (irregular || dm->bounded_x || pencil) {
         if (dist->self_loop) return bail(fail(OCN_EINVAL, "self_loop has one slab"));
-        std::vector<int> equal((size_t)dist->world, g.Nx);
-        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes ? local_sizes : equal.data(), global_x_topology))) return bail(rc);
+        std::vector<int> equal((size_t)Rx, g.Nx);
+        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes ? local_sizes : equal.data(), global_x_topology, Ly_global, sizes_y)))
+            return bail(rc);
         return OCN_OK;
     }
     if ((rc = ocn_dist_poisson_create(&dm->solver, local_grid, dist->world, dist->rank, Lx_global))) return bail(rc);

@@ -1078,28 +1078,31 @@ __global__ void __launch_bounds__(256) copy_dense_real_kernel(DGrid g, FView phi
 // the R gathered pieces, and -- after the single-GPU solver ran on it -- take the own slab back out of the global solution.
 // first[q] = global index (0-based) of rank q's first column, first[R] = Nx_global.
 // ---------------------------------------------------------------------------------------------------------------------
+// With a pencil (Rx x Ry) partition the pieces are (nxmax, nymax, Nz) blocks, rank = ix * Ry + iy (index2rank, distributed_architectures.jl:354).
 #define OCN_MAX_RANKS 64
-struct SlabTable { int first[OCN_MAX_RANKS + 1]; int R; };
+struct SlabTable { int first[OCN_MAX_RANKS + 1]; int R; int firsty[OCN_MAX_RANKS + 1]; int Ry; };
 template <bool COMPLEX>
-__global__ void __launch_bounds__(256) gather_assemble_kernel(const double *all, void *dst, SlabTable t, int nmax, int Nxg, int Ny, int Nz) {
+__global__ void __launch_bounds__(256) gather_assemble_kernel(const double *all, void *dst, SlabTable t, int nmax, int nymax, int Nxg, int Nyg, int Nz) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int j = blockIdx.y * blockDim.y + threadIdx.y;
     const int k = blockIdx.z;
-    if (i >= Nxg || j >= Ny || k >= Nz) return;
-    int q = 0;
+    if (i >= Nxg || j >= Nyg || k >= Nz) return;
+    int q = 0, qy = 0;
     while (q + 1 < t.R && i >= t.first[q + 1]) ++q;
-    const double v = all[(size_t)(i - t.first[q]) + (size_t)nmax * (j + (size_t)Ny * (k + (size_t)Nz * q))];
-    const size_t d = (size_t)i + (size_t)Nxg * (j + (size_t)Ny * k);
+    while (qy + 1 < t.Ry && j >= t.firsty[qy + 1]) ++qy;
+    const size_t r = (size_t)q * t.Ry + qy;
+    const double v = all[(size_t)(i - t.first[q]) + (size_t)nmax * ((j - t.firsty[qy]) + (size_t)nymax * (k + (size_t)Nz * r))];
+    const size_t d = (size_t)i + (size_t)Nxg * (j + (size_t)Nyg * k);
     if (COMPLEX) ((double2 *)dst)[d] = make_double2(v, 0.0);
     else ((double *)dst)[d] = v;
 }
-// local haloed phi(i, j, k) = global haloed gphi(off + i, j, k) over the local interior
-__global__ void __launch_bounds__(256) slab_extract_kernel(DGrid g, FView phi, FView gphi, int off) {
+// local haloed phi(i, j, k) = global haloed gphi(off + i, offy + j, k) over the local interior
+__global__ void __launch_bounds__(256) slab_extract_kernel(DGrid g, FView phi, FView gphi, int off, int offy) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
-    phi.at(i, j, k) = gphi.at(off + i, j, k);
+    phi.at(i, j, k) = gphi.at(off + i, offy + j, k);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1909,6 +1912,35 @@ __global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabLi
         } else {
             if (do_west) p[row + HX - H + h] = west[b];
             if (do_east) p[row + N + HX + h] = east[b];
+        }
+    }
+}
+
+// the same along y for pencil partitions: the south / north buffers hold Hy rows of the WHOLE parent extent in x and z, so the x halos
+// just received -- the corners of halo_communication.jl:137-162 -- ride along on the second hop
+struct RowList {
+    long off[OCN_MAX_FIELDS];
+    int p0[OCN_MAX_FIELDS], p1[OCN_MAX_FIELDS], p2[OCN_MAX_FIELDS];
+};
+template <bool PACK>
+__global__ void __launch_bounds__(256) y_halo_buffer_kernel(FieldList fl, RowList rl, int N, int HY, int H, double *south, double *north,
+                                                            bool do_south, bool do_north) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int f = 0; f < fl.n; ++f) {
+        const int p0 = rl.p0[f];
+        const long per = (long)p0 * H;
+        if (t >= per * rl.p2[f]) continue;
+        const int i = t % p0, h = (t / p0) % H;
+        const long k = t / per;
+        double *p = fl.p[f];
+        const long base = i + (long)p0 * (long)rl.p1[f] * k;
+        const long b = rl.off[f] + t;
+        if (PACK) {
+            south[b] = p[base + (long)p0 * (HY + h)];
+            north[b] = p[base + (long)p0 * (HY + N - H + h)];
+        } else {
+            if (do_south) p[base + (long)p0 * (HY - H + h)] = south[b];
+            if (do_north) p[base + (long)p0 * (N + HY + h)] = north[b];
         }
     }
 }

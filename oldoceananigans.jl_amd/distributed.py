@@ -259,9 +259,15 @@ class DistributedRectilinearGrid:
     an x-slab partition. `local` is the RectilinearGrid-like object the kernels run on."""
 
     def __init__(self, ctx, size, x=None, y=None, z=None, extent=None, topology=(Periodic, Periodic, Periodic),
-                 halo=(3, 3, 3), make_local_grid=None):
+                 halo=(3, 3, 3), make_local_grid=None, partition=None):
         self.ctx = ctx
-        R, r = ctx.world, ctx.rank
+        # Partition(Rx, Ry) (distributed_architectures.jl:14-63): rank = ix * Ry + iy (index2rank, :354-389). Default: x-slabs.
+        Rx, Ry = (ctx.world, 1) if partition is None else (int(partition[0]), int(partition[1]))
+        if Rx * Ry != ctx.world:
+            raise ValueError(f"Partition({Rx}, {Ry}) needs {Rx * Ry} ranks, the architecture has {ctx.world}")
+        self.partition = (Rx, Ry)
+        R, r = Rx, ctx.rank // Ry
+        iy = ctx.rank % Ry
         if extent is not None:
             x, y, z = (0.0, float(extent[0])), (0.0, float(extent[1])), (-float(extent[2]), 0.0)
         self.global_size = tuple(int(n) for n in size)
@@ -276,14 +282,25 @@ class DistributedRectilinearGrid:
         self.Lx_global = _regular_coordinate(x, self.global_size[0], "x")[1]
         xl = x if R == 1 else partition_coordinate(x, self.local_sizes, R, r)
         # insert_connected_topology (distributed_grids.jl:339-346)
-        if not ctx.partitioned:
+        if not ctx.partitioned or (R == 1 and Ry > 1):     # y-slabs only: x stays what it is
             tx = topology[0]
         elif topology[0] is Periodic:
             tx = FullyConnected
         else:
             tx = RightConnected if r == 0 else (LeftConnected if r == R - 1 else FullyConnected)
-        topo = (tx, topology[1], topology[2])
-        self.local_size = (nxl, self.global_size[1], self.global_size[2])
+        # the y direction of a pencil partition (global y Periodic): FullyConnected local grids, the remainder on the last row of ranks
+        self.local_sizes_y = local_sizes(self.global_size[1], Ry)
+        self.Ly_global = _regular_coordinate(y, self.global_size[1], "y")[1]
+        nyl = self.local_sizes_y[iy]
+        ty = topology[1]
+        if Ry > 1:
+            if topology[1] is not Periodic:
+                raise NotImplementedError("the y direction of a pencil partition is Periodic")
+            ty = FullyConnected
+            y = partition_coordinate(y, self.local_sizes_y, Ry, iy)
+        self.j_offset = sum(self.local_sizes_y[:iy])
+        topo = (tx, ty, topology[2])
+        self.local_size = (nxl, nyl, self.global_size[2])
         self.i_offset = sum(self.local_sizes[:r])    # global index of local i = 1 minus one
         if make_local_grid is None:
             self.local = RectilinearGrid(ctx.arch, self.local_size, x=xl, y=y, z=z, topology=topo, halo=halo)
@@ -299,8 +316,8 @@ class DistributedRectilinearGrid:
 # ----------------------------------------------------------------------------------------------------------------------
 class DeviceBackend:
     def __init__(self, ctx, grid, ntracers):
-        if getattr(grid, "irregular", False) or getattr(grid, "global_x_topology", Periodic) is Bounded:
-            raise NotImplementedError("irregular and Bounded partitions run through LibraryDistributedModel (gathered pressure solve)")
+        if getattr(grid, "irregular", False) or getattr(grid, "global_x_topology", Periodic) is Bounded or getattr(grid, "partition", (1, 1))[1] > 1:
+            raise NotImplementedError("irregular, Bounded and pencil partitions run through LibraryDistributedModel (gathered pressure solve)")
         self.ctx, self.grid, self.ntracers = ctx, grid, ntracers
         torch = ctx.torch
         g = grid.local
@@ -941,6 +958,8 @@ class Distributed:
             all_to_all=T.ALL_TO_ALL(guard(lambda u, s_, r_, n, st: collectives.all_to_all(s_, r_, n))),
             all_gather=T.ALL_GATHER(guard(lambda u, s_, r_, n, st: collectives.all_gather(s_, r_, n))),
             allreduce_max=T.ALLREDUCE_MAX(guard(allreduce)))
+        if hasattr(collectives, "exchange_peers"):      # pencil partitions: exchange with an explicit pair of peers
+            cbs["exchange_peers"] = T.EXCHANGE_PEERS(guard(lambda u, pl, ph, ls, hs, lr, hr, n, st: collectives.exchange_peers(pl, ph, ls, hs, lr, hr, n)))
         t = T(user=None, **cbs)
         h = C.c_void_p()
         _lib.check(_lib.lib().ocn_dist_create_transport(C.byref(h), C.byref(t), int(world), int(rank)))
@@ -1023,7 +1042,13 @@ class LibraryDistributedModel(_NonhydrostaticModel):
     def _create_handle(self, grid, ntracers):
         h = C.c_void_p()
         bounded = getattr(grid, "global_x_topology", Periodic) is Bounded
-        if getattr(grid, "irregular", False) or bounded:
+        Rx, Ry = getattr(grid, "partition", (grid.ctx.world, 1))
+        if Ry > 1:
+            sx = (C.c_int * Rx)(*grid.local_sizes)
+            sy = (C.c_int * Ry)(*grid.local_sizes_y)
+            _lib.check(_lib.lib().ocn_dist_model_create_pencil(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global),
+                                                               float(grid.Ly_global), Rx, Ry, sx, sy, 1 if bounded else 0))
+        elif getattr(grid, "irregular", False) or bounded:
             sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
             _lib.check(_lib.lib().ocn_dist_model_create_partition(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
                                                                   float(grid.Lx_global), sizes, 1 if bounded else 0))

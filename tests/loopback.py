@@ -106,6 +106,15 @@ class PointerLoopback:
     def exchange_wait(self):
         pass
 
+    def exchange_peers(self, peer_lo, peer_hi, lo_send, hi_send, lo_recv, hi_recv, n):
+        """pencil partitions: what leaves through the low side lands in peer_lo's HIGH halo"""
+        w = self.w
+        w.slots[self.rank] = (lo_send, hi_send)
+        w.barrier_obj.wait()
+        self._copy(hi_recv, w.slots[peer_hi][0], n)
+        self._copy(lo_recv, w.slots[peer_lo][1], n)
+        w.barrier_obj.wait()
+
     def all_to_all(self, send, recv, n):
         w = self.w
         w.slots[self.rank] = send

@@ -45,10 +45,10 @@ def _single_gpu(ocn, arch, size, zkind, nsteps, xbounded=False, ybounded=False):
     return out, model.clock.time, dt
 
 
-def _library_model(ocn, dist, ctx, size, zkind, xbounded=False, ybounded=False):
+def _library_model(ocn, dist, ctx, size, zkind, xbounded=False, ybounded=False, partition=None):
     z, topo = _z_and_topology(ocn, zkind, size[2])
     topo = _xb(ocn, topo, xbounded, ybounded)
-    grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
+    grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo, partition=partition)
     model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
                                          buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
                                          coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
@@ -56,11 +56,11 @@ def _library_model(ocn, dist, ctx, size, zkind, xbounded=False, ybounded=False):
     return grid, model
 
 
-def _compare(out, ref, r, nxl, size, offset=None):
+def _compare(out, ref, r, nxl, size, offset=None, joffset=0):
     i0 = r * nxl if offset is None else offset
     for name, a in out.items():
         n = a.shape[0] - 6                  # nxl, or nxl + 1 for the Face-in-x field of a LeftConnected rank (its wall face)
-        want = ref[name][3 + i0:3 + i0 + n, 3:3 + a.shape[1] - 6, 3:3 + a.shape[2] - 6]
+        want = ref[name][3 + i0:3 + i0 + n, 3 + joffset:3 + joffset + a.shape[1] - 6, 3:3 + a.shape[2] - 6]
         scale = np.abs(ref[name]).max()
         err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / scale
         assert err <= 1e-12, (r, name, err, int(np.isnan(a).sum()))
@@ -142,7 +142,7 @@ def test_library_collectives_over_rccl_world_1(ocn, arch):
     _lib.check(L.ocn_dist_destroy(d))
 
 
-def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=False, ybounded=False):
+def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=False, ybounded=False, partition=None):
     from oldoceananigans_jl_amd import _lib, distributed as dist
     from loopback import PointerLoopbackWorld
     world = PointerLoopbackWorld(R, _lib.lib())
@@ -152,7 +152,7 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=Fals
     def worker(rank):
         try:
             ctx = dist.Distributed.transport(arch, world.collectives(rank), R, rank)
-            grid, model = _library_model(ocn, dist, ctx, size, zkind, xbounded, ybounded)
+            grid, model = _library_model(ocn, dist, ctx, size, zkind, xbounded, ybounded, partition)
             for k, v in options.items():
                 model.set_option(k, v)
             for _ in range(nsteps):
@@ -164,13 +164,26 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=Fals
             for n, f in enumerate(model.fields().values()):
                 f.set_parent(np.full(f.shape, 100.0 * n + rank))
             ocn.update_state(model, False)
-            west, east = (rank - 1) % R, (rank + 1) % R
+            Rx_, Ry_ = partition if partition else (R, 1)
+            ix_, iy_ = rank // Ry_, rank % Ry_
+            west, east = ((ix_ - 1) % Rx_) * Ry_ + iy_, ((ix_ + 1) % Rx_) * Ry_ + iy_
+            south, north = ix_ * Ry_ + (iy_ - 1) % Ry_, ix_ * Ry_ + (iy_ + 1) % Ry_
             if xbounded:                        # a wall side has no neighbour: the halo keeps what the local boundary fill leaves (own id)
                 west, east = (rank if rank == 0 else west), (rank if rank == R - 1 else east)
             for n, f in enumerate(model.fields().values()):
                 a = f.parent()
+                if xbounded and ix_ == 0:
+                    west = rank
+                if xbounded and ix_ == Rx_ - 1:
+                    east = rank
                 assert np.all(a[:3, 3:-3, 3:-3] == 100 * n + west) and np.all(a[-3:, 3:-3, 3:-3] == 100 * n + east), (rank, n)
-            results[rank] = (out, div, model.clock.time)
+                if Ry_ > 1:         # pencils: y halos from the south / north ranks, corners from the diagonal ones (two hops)
+                    assert np.all(a[3:-3, :3, 3:-3] == 100 * n + south) and np.all(a[3:-3, -3:, 3:-3] == 100 * n + north), (rank, n)
+                    if not xbounded and Rx_ > 1:
+                        sw = ((ix_ - 1) % Rx_) * Ry_ + (iy_ - 1) % Ry_
+                        ne = ((ix_ + 1) % Rx_) * Ry_ + (iy_ + 1) % Ry_
+                        assert np.all(a[:3, :3, 3:-3] == 100 * n + sw) and np.all(a[-3:, -3:, 3:-3] == 100 * n + ne), (rank, n)
+            results[rank] = (out, div, model.clock.time, (grid.i_offset, grid.j_offset))
             model.close()
             ctx.close()
         except BaseException as e:          # noqa: BLE001
@@ -206,7 +219,7 @@ def test_library_virtual_ranks_match_single_gpu(ocn, arch, R, size, zkind, optio
     results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options)
     ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps)
     nxl = size[0] // R
-    for r, (out, div, t) in enumerate(results):
+    for r, (out, div, t, _off) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, nxl, size)
 
@@ -230,7 +243,7 @@ def test_library_irregular_partition_matches_single_gpu(ocn, arch, R, size, zkin
     results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, {})
     ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps)
     sizes = dist.local_sizes(size[0], R)
-    for r, (out, div, t) in enumerate(results):
+    for r, (out, div, t, _off) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, sizes[r], size, offset=sum(sizes[:r]))
 
@@ -254,10 +267,33 @@ def test_library_bounded_partition_matches_single_gpu(ocn, arch, R, size, zkind,
     results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, {}, xbounded=True, ybounded=ybounded)
     ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps, xbounded=True, ybounded=ybounded)
     sizes = dist.local_sizes(size[0], R)
-    for r, (out, div, t) in enumerate(results):
+    for r, (out, div, t, _off) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, sizes[r], size, offset=sum(sizes[:r]))
         assert out["u"].shape[0] == sizes[r] + 6 + (1 if r == R - 1 else 0)
+
+
+@pytest.mark.parametrize("partition,size,zkind,xbounded", [
+    ((2, 2), (16, 16, 8), "periodic", False),     # four pencils, every rank has four distinct neighbours + diagonals
+    ((1, 3), (16, 18, 6), "periodic", False),     # y-slabs only: x stays Periodic locally
+    ((3, 2), (25, 14, 6), "periodic", False),     # six ranks, irregular in x (8 + 8 + 9), 7 + 7 rows
+    ((2, 2), (16, 13, 8), "bounded", False),      # z Bounded: Fourier-tridiagonal solver + diffusivity + buoyancy; 6 + 7 rows
+    ((2, 2), (16, 12, 8), "amd", False),          # the configs[4] physics on pencils (eddy diffusivities extended into x AND y halos)
+    ((2, 2), (16, 12, 8), "stretched", True),     # Bounded x + pencils: Right / LeftConnected columns of ranks
+])
+def test_library_pencil_partition_matches_single_gpu(ocn, arch, partition, size, zkind, xbounded):
+    """Partition(Rx, Ry) (row (f).4 of SURVEY.md 8: pencil decomposition + corner exchange): rank = ix * Ry + iy
+    (distributed_architectures.jl:354-434), local grids connected in x and FullyConnected in y; a fill makes two hops (x, then y over
+    the whole x extent) so the corners hold the diagonal neighbours' data like after fill_corners! (halo_communication.jl:137-162) --
+    asserted with rank ids --; the pressure solve is the gathered one. Against the single-GPU model on the global grid."""
+    _own_stream()
+    nsteps = 3
+    R = partition[0] * partition[1]
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, zkind, {}, xbounded=xbounded, partition=partition)
+    ref, time, _ = _single_gpu(ocn, arch, size, zkind, nsteps, xbounded=xbounded)
+    for r, (out, div, t, (i0, j0)) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, None, size, offset=i0, joffset=j0)
 
 
 def test_library_transposing_solver_matches(ocn, arch):
@@ -269,7 +305,7 @@ def test_library_transposing_solver_matches(ocn, arch):
     finally:
         ocn.set_option("dist_substructured", 1)
     ref, time, _ = _single_gpu(ocn, arch, (36, 12, 10), "periodic", 3)
-    for r, (out, div, t) in enumerate(results):
+    for r, (out, div, t, _off) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, 9, (36, 12, 10))
 
