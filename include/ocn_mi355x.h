@@ -296,6 +296,10 @@ int ocn_model_time_step_ab2(ocn_model_t model, double dt, double chi, int euler)
 int ocn_model_reset(ocn_model_t model);
 int ocn_model_clock(ocn_model_t model, double *time, int64_t *iteration, int *stage, double *last_dt,
                     double *last_stage_dt);
+/* set!(model, checkpointed_clock) (OutputWriters/checkpointer.jl:199-231): restore the clock of a checkpointed state; the fields and
+ * the tendencies Gⁿ, G⁻ are restored by copying the checkpointed parent arrays (halos included, like the reference's files) into the
+ * arrays ocn_model_field returns, followed by ocn_model_update_state */
+int ocn_model_set_clock(ocn_model_t model, double time, int64_t iteration, int stage, double last_dt, double last_stage_dt);
 /* max |∇·u| over the interior (test helper: test/test_time_stepping.jl:124-160); synchronous */
 int ocn_model_max_abs_divergence(ocn_model_t model, double *value);
 /* cell_advection_timescale(grid, velocities) (Advection/cell_advection_timescale.jl:13-34): min over cells of

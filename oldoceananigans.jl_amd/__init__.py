@@ -10,6 +10,7 @@ from .architectures import GPU, architecture, own_stream, set_option, synchroniz
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, LinearFieldFlux, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy
+from .checkpointer import set_from_checkpoint, write_checkpoint
 from .closures import AnisotropicMinimumDissipation, ScalarDiffusivity
 from .fields import (CenterField, Field, XFaceField, YFaceField, ZFaceField, fill_halo_regions, interior, set_)
 from .grids import (Bounded, Center, Face, Flat, FullyConnected, LeftConnected, Periodic, RectilinearGrid, RightConnected,

@@ -153,6 +153,7 @@ SYMBOLS = {
     "ocn_model_set_finalize": (C.c_int, [_vp, C.c_int]),
     "ocn_model_time_step": (C.c_int, [_vp, C.c_double]),
     "ocn_model_clock": (C.c_int, [_vp, _dp, C.POINTER(C.c_int64), _ip, _dp, _dp]),
+    "ocn_model_set_clock": (C.c_int, [_vp, C.c_double, C.c_int64, C.c_int, C.c_double, C.c_double]),
     "ocn_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_max_abs_divergence": (C.c_int, [_vp, _vp, _vp, _vp, _dp]),
     "ocn_model_set_option": (C.c_int, [_vp, C.c_char_p, C.c_int]),

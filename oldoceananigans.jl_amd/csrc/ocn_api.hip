@@ -2820,6 +2820,16 @@ extern "C" int ocn_model_clock(ocn_model_t m, double *time, int64_t *iteration, 
     return OCN_OK;
 }
 
+// set!(model, checkpointed_clock) (OutputWriters/checkpointer.jl:226-229): the clock of a restored state. The caller then copies the
+// checkpointed parent arrays into the model's fields and tendencies (ocn_model_field) and calls ocn_model_update_state.
+extern "C" int ocn_model_set_clock(ocn_model_t m, double time, int64_t iteration, int stage, double last_dt, double last_stage_dt) {
+    if (!m) return fail(OCN_EINVAL, "NULL argument");
+    if (iteration < 0 || stage < 1 || stage > 3) return fail(OCN_EINVAL, "invalid clock (iteration %lld, stage %d)", (long long)iteration, stage);
+    m->epoch += 1;
+    m->time = time; m->iteration = iteration; m->stage = stage; m->last_dt = last_dt; m->last_stage_dt = last_stage_dt;
+    return OCN_OK;
+}
+
 extern "C" int ocn_model_profile_read(ocn_model_t m, double *tendency_ms, int *count) {
     NEED_INIT();
     if (!m || !tendency_ms || !count) return fail(OCN_EINVAL, "NULL argument");
