@@ -147,6 +147,10 @@ struct ocn_grid_s {
     bool z_regular;
     double *tables;   // one device allocation holding dzc, dzf, ax, ay, vinv_c, vinv_f, rdzf
     std::vector<double> h_dzc, h_dzf;
+    // why the advection scheme cannot be evaluated on this grid (empty: it can). A grid whose halo is smaller than the scheme needs
+    // -- RectilinearGrid(halo = (1, 1, 1)), what test/test_halo_regions.jl fills -- serves fields, halo fills and the Poisson
+    // solvers; tendencies and models need the halo the reference's model constructor would inflate it to.
+    std::string advection_error;
 };
 
 static void parent_size(const DGrid &g, const int loc[3], int P[3]) {
@@ -175,6 +179,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
                                double dx, double dy, double dz, const double *dzc, const double *dzf) {
     NEED_INIT();
     if (!grid || !N || !H || !topo || !L) return fail(OCN_EINVAL, "NULL argument");
+    std::string adv_error;
     for (int d = 0; d < 3; ++d) {
         if (N[d] < 1) return fail(OCN_EINVAL, "size must be positive (dimension %d)", d);
         if (topo[d] == OCN_FLAT) {
@@ -192,11 +197,14 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
         // WENO(order = 2N-1) = WENO{2} where N = 2; the halo must hold the adapted scheme's buffer (nonhydrostatic_model.jl:184,
         // inflate_grid_halo_size). N = 1 in a non-Flat direction is refused: the reference keeps Centered(order=4) for the
         // advecting velocities of the OTHER directions' fluxes, which reads two cells into a one-cell halo there.
-        if (N[d] < 2) return fail(OCN_ENOTSUP, "size 1 in non-Flat dimension %d: make the direction Flat (the reference's adapted "
-                                               "UpwindBiased(order=1) scheme reads beyond its one-cell halo)", d);
+        char why[256] = "";
         const int B = N[d] >= 3 ? 3 : N[d];
-        if (H[d] < B) return fail(OCN_EINVAL, "halo %d < %d in dimension %d: %s requires halo >= %d", H[d], B, d,
-                                  B == 3 ? "WENO(order=5)" : "WENO(order=3)", B);
+        if (N[d] < 2) snprintf(why, sizeof why, "size 1 in non-Flat dimension %d: make the direction Flat (the reference's adapted "
+                                                "UpwindBiased(order=1) scheme reads beyond its one-cell halo)", d);
+        else if (H[d] < B) snprintf(why, sizeof why, "halo %d < %d in dimension %d: %s requires halo >= %d", H[d], B, d,
+                                    B == 3 ? "WENO(order=5)" : "WENO(order=3)", B);
+        if (why[0] && adv_error.empty()) adv_error = why;
+        if (H[d] < 1) return fail(OCN_EINVAL, "halo %d < 1 in dimension %d", H[d], d);
         if (N[d] < H[d]) return fail(OCN_EINVAL, "size %d < halo %d in dimension %d", N[d], H[d], d);
         if (!(L[d] > 0)) return fail(OCN_EINVAL, "extent must be positive");
     }
@@ -207,6 +215,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
         return fail(OCN_ENOTSUP, "stretched z requires Bounded z topology (FourierTridiagonalPoissonSolver, "
                                  "fourier_tridiagonal_poisson_solver.jl:88-92)");
     ocn_grid_s *g = new ocn_grid_s();
+    g->advection_error = adv_error;
     DGrid &D = g->d;
     D.Nx = N[0]; D.Ny = N[1]; D.Nz = N[2];
     D.Hx = H[0]; D.Hy = H[1]; D.Hz = H[2];
@@ -518,22 +527,26 @@ static int launch_tendency(const DGrid &g, const double *u, const double *v, con
 extern "C" int ocn_compute_Gu(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gu, const int *range) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !Gu) return fail(OCN_EINVAL, "NULL argument");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     return launch_tendency<F_U>(grid->d, u, v, w, nullptr, Gu, range);
 }
 extern "C" int ocn_compute_Gv(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gv, const int *range) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !Gv) return fail(OCN_EINVAL, "NULL argument");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     return launch_tendency<F_V>(grid->d, u, v, w, nullptr, Gv, range);
 }
 extern "C" int ocn_compute_Gw(ocn_grid_t grid, const double *u, const double *v, const double *w, double *Gw, const int *range) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !Gw) return fail(OCN_EINVAL, "NULL argument");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     return launch_tendency<F_W>(grid->d, u, v, w, nullptr, Gw, range);
 }
 extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v, const double *w, const double *c, double *Gc,
                               const int *range) {
     NEED_INIT();
     if (!grid || !u || !v || !w || !c || !Gc) return fail(OCN_EINVAL, "NULL argument");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     return launch_tendency<F_C>(grid->d, u, v, w, c, Gc, range);
 }
 
@@ -574,6 +587,7 @@ extern "C" int ocn_compute_tendencies(ocn_grid_t grid, const double *u, const do
     if (!grid || !u || !v || !w || !Gu || !Gv || !Gw || ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3 ||
         (ntracers > 0 && (!tracers || !Gc)))
         return fail(OCN_EINVAL, "invalid argument");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     int rc = compute_tendencies(grid->d, u, v, w, tracers, ntracers, Gu, Gv, Gw, Gc, range, g_tendency_impl ? g_tendency_impl : 1);
     if (rc) return rc;
     KERNEL_CHECK();
@@ -732,6 +746,7 @@ extern "C" int ocn_compute_tendencies_and_substep(ocn_grid_t grid, const double 
     if (!grid || !fields || !Gn || !next || ntracers < 0 || ntracers > 3 || (has_zeta && !Gm)) return fail(OCN_EINVAL, "invalid argument");
     for (int f = 0; f < 3 + ntracers; ++f)
         if (!fields[f] || !Gn[f] || !next[f] || (has_zeta && !Gm[f])) return fail(OCN_EINVAL, "NULL field pointer");
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     const int impl = g_tendency_impl ? g_tendency_impl : 1;
     if (!fused_path(grid->d, range, ntracers, impl))
         return fail(OCN_ENOTSUP, "the fused tendency + substep pass needs Periodic / FullyConnected x and y");
@@ -2173,6 +2188,9 @@ extern "C" int ocn_model_destroy(ocn_model_t m) {
 static int model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers, bool with_solver) {
     if (!model || !grid) return fail(OCN_EINVAL, "NULL argument");
     if (ntracers < 0 || ntracers > OCN_MAX_FIELDS - 3) return fail(OCN_EINVAL, "ntracers must be in 0..%d", OCN_MAX_FIELDS - 3);
+    // the reference's constructor would inflate the halo (inflate_grid_halo_size, nonhydrostatic_model.jl:184); the binder does that
+    // before it creates the handle
+    if (!grid->advection_error.empty()) return fail(OCN_EINVAL, "%s", grid->advection_error.c_str());
     ocn_model_s *m = new ocn_model_s();
     m->grid = grid; m->ntr = ntracers; m->nf = 3 + ntracers;
     for (int f = 0; f < OCN_MAX_FIELDS; ++f) m->U[f] = m->U2[f] = m->Gn[f] = m->Gm[f] = nullptr;

@@ -1039,3 +1039,38 @@ def test_checkpoint_and_restore_continue_bit_identically(ocn, arch, tmp_path, ca
     other = ocn.RectilinearGrid(arch, size=(8, 8, 8), extent=(1, 1, 1))
     with pytest.raises(ValueError):
         ocn.set_from_checkpoint(ocn.NonhydrostaticModel(grid=other, tracers=("T", "S")), path)
+
+
+HALO_NS = [(8, 8, 8), (8, 8, 4), (10, 7, 5), (1, 8, 8), (1, 9, 5), (8, 1, 8), (5, 1, 9), (8, 8, 1), (5, 9, 1), (1, 1, 8)]
+
+
+@pytest.mark.parametrize("N", HALO_NS)
+def test_halo_regions_as_the_reference_tests_them(ocn, oracle, arch, N):
+    """test/test_halo_regions.jl:1-65 as written: RectilinearGrid(size = N, extent = (100, 200, 300), halo = (1, 1, 1)) -- degenerate
+    one-cell directions included --, a CenterField with a random interior: the halos are zero before the fill; after
+    fill_halo_regions! on (Periodic, Periodic, Bounded) the x / y halos hold the periodic copies and the z halos the no-flux mirror, `==`.
+    (A halo of 1 cannot carry the advection scheme: tendencies and models on such a grid are refused with the reason.)"""
+    grid = ocn.RectilinearGrid(arch, size=N, extent=(100, 200, 300), halo=(1, 1, 1), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    assert grid.halo_size == (1, 1, 1)
+    field = ocn.CenterField(grid)
+    rng = np.random.default_rng(sum(N))
+    field.set(rng.random(N))
+    d = field.parent()
+    Nx, Ny, Nz = N
+    assert np.all(d[0] == 0) and np.all(d[-1] == 0) and np.all(d[:, 0] == 0) and np.all(d[:, -1] == 0) and np.all(d[:, :, 0] == 0) and np.all(d[:, :, -1] == 0)
+    ocn.fill_halo_regions(field)
+    d = field.parent()
+    I = (slice(1, 1 + Nx), slice(1, 1 + Ny), slice(1, 1 + Nz))
+    assert np.array_equal(d[0:1, I[1], I[2]], d[Nx:Nx + 1, I[1], I[2]])          # data[1-Hx:0] == data[Nx-Hx+1:Nx]
+    assert np.array_equal(d[I[0], 0:1, I[2]], d[I[0], Ny:Ny + 1, I[2]])
+    assert np.array_equal(d[I[0], I[1], 0:1], d[I[0], I[1], 1:2])                # data[0] == data[1]
+    assert np.array_equal(d[I[0], I[1], Nz + 1:Nz + 2], d[I[0], I[1], Nz:Nz + 1])
+    # ... and the whole parent array equals the oracle's ordered fills
+    g_cpu = oracle.Grid(N, halo=(1, 1, 1), topology=(0, 0, 1), x=(0, 100), y=(0, 200), z=(-300, 0))
+    b = g_cpu.zeros((0, 0, 0))
+    b[1:-1, 1:-1, 1:-1] = d[1:-1, 1:-1, 1:-1]
+    g_cpu.fill_halo_regions(b, (0, 0, 0))
+    assert np.array_equal(d, b)
+    with pytest.raises(ocn.OcnError, match="halo|size 1"):
+        U, G = [ocn.XFaceField(grid), ocn.YFaceField(grid), ocn.ZFaceField(grid)], [ocn.XFaceField(grid), ocn.YFaceField(grid), ocn.ZFaceField(grid)]
+        ocn.kernels.compute_tendencies(grid, U[0], U[1], U[2], [], G[0], G[1], G[2], [])
