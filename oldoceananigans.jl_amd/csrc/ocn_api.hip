@@ -565,6 +565,7 @@ static int compute_tendencies(const DGrid &g, const double *u, const double *v, 
     if (fused_path(g, range, ntr, impl)) {
         int rc = check_range(g, range, nullptr);
         if (rc) return rc;
+        if (impl == 2 && !role_tendency_supported(g)) impl = 1;          // parent arrays of 2 GiB and more: the all-fields kernel
         rc = impl == 2 ? launch_role_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub)
                        : launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub);
         if (rc) return fail(rc, "fused tendency launch failed");

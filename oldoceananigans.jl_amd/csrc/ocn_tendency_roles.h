@@ -429,6 +429,14 @@ __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_k
     else role_march<ROLE_C, TY, SUB>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
 }
 
+// The role kernel addresses a parent array with a 31-bit byte offset (bit 31 is the out-of-range flag of its buffer descriptor, whose
+// num_records is 2 GiB): plane offset + up to four planes of look-ahead + the row / column offsets must stay below 2^31. Larger arrays
+// (e.g. a single-GPU 1024 x 1024 x 256 grid: 2.2 GB per field) take the all-fields kernel, whose offsets are full 32-bit.
+static inline bool role_tendency_supported(const DGrid &g) {
+    const double plane = 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy);
+    return plane * (g.Nz + 2.0 * g.Hz + 1.0 + 4.0) < 2147483648.0;
+}
+
 static int g_role_kchunk = 0;      // 0: automatic
 static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgroup (bytes) to limit the workgroups per CU
 

@@ -241,3 +241,60 @@ def test_config4_local_slab_through_the_partitioned_path(ocn, arch):
                                          "T": F(top=ocn.FluxBoundaryCondition(5e-5), bottom=ocn.GradientBoundaryCondition(0.01)),
                                          "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-1e-3 / 3600.0), field_dependencies="S"))})
     _slab_pair(ocn, arch, (128, 1024, 256), tanh_faces(256), physics)
+
+
+def test_config3_global_512_cubed_over_8_ranks(ocn, arch, monkeypatch):
+    """BASELINE.json configs[3] at FULL size as a GLOBAL problem: 512^3 triply periodic over Partition(8) -- eight ranks of the library's
+    partitioned model (64 x 512 x 512 each: halo pack / exchange / unpack, early exchange, substructured x solve with its all-gather),
+    run as threads that share the one card over the caller-supplied transport (tests/loopback.py; RCCL itself needs eight cards) --
+    against the single-GPU model on the 512^3 grid: every rank's slab of every field after two RK3 steps."""
+    import test_gpu_dist_library as T
+    from dist_worker import analytic as base_analytic
+    # S without its offset of 35: see _slab_pair (conditioning of the reference's smoothness indicators on a 512-point direction)
+    monkeypatch.setattr(T, "analytic", lambda name, x, y, z: base_analytic(name, x, y, z) - (35.0 if name == "S" else 0.0))
+    T._own_stream()
+    size, R, nsteps = (512, 512, 512), 8, 2
+    results = T._run_library_ranks(ocn, arch, R, size, nsteps, "periodic", {})
+    host = [(out, div, t) for out, div, t, _ in results]
+    del results
+    ref, time, _ = T._single_gpu(ocn, arch, size, "periodic", nsteps)
+    nxl = size[0] // R
+    dmin = min(2.0 / size[0], 1.0 / size[1], 1.0 / size[2])
+    cond = (3 * 4.0 / dmin ** 2) / (2 * np.pi / 2.0) ** 2          # lambda_max / lambda_min of the discrete Laplacian (error model of p)
+    for r, (out, div, t) in enumerate(host):
+        assert div < 5e-8 and t == time
+        for name, a in out.items():
+            want = ref[name][3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]
+            err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / np.abs(ref[name]).max()
+            assert err <= (1e-12 if name != "p" else max(1e-12, 4 * np.finfo(float).eps * cond)), (r, name, err)
+        # exchanged x halos are exact copies of the neighbour's interior columns
+        for name in ("u", "T"):
+            east = host[(r + 1) % R][0][name]
+            assert np.array_equal(out[name][-3:, 3:-3, 3:-3], east[3:6, 3:-3, 3:-3]), (r, name)
+
+
+def test_config4_global_1024x1024x256_over_8_ranks(ocn, arch, monkeypatch):
+    """BASELINE.json configs[4] at FULL size as a GLOBAL problem: 1024 x 1024 x 256, stretched Bounded z, the
+    ocean_wind_mixing_and_convection physics (AnisotropicMinimumDissipation evaluated in the x-halo columns, linear seawater buoyancy,
+    wind stress / heat flux / bottom gradient / evaporation conditions), eight ranks of 128 x 1024 x 256 through the library's
+    partitioned step (transposing Fourier-tridiagonal solver: two all-to-alls per solve) as threads sharing the card, against the
+    single-GPU model on the global grid after two RK3 steps."""
+    import test_gpu_dist_library as T
+    from dist_worker import analytic as base_analytic
+    monkeypatch.setattr(T, "analytic", lambda name, x, y, z: base_analytic(name, x, y, z) - (35.0 if name == "S" else 0.0))
+    T._own_stream()
+    size, R, nsteps = (1024, 1024, 256), 8, 2
+    results = T._run_library_ranks(ocn, arch, R, size, nsteps, "amd", {})
+    host = [(out, div, t) for out, div, t, _ in results]
+    del results
+    ref, time, _ = T._single_gpu(ocn, arch, size, "amd", nsteps)
+    nxl = size[0] // R
+    from helpers import tanh_faces
+    dzmin = float(np.diff(tanh_faces(size[2])).min())
+    cond = (4.0 / (2.0 / size[0]) ** 2 + 4.0 * size[1] ** 2 + 4.0 / dzmin ** 2) / (2 * np.pi / 2.0) ** 2
+    for r, (out, div, t) in enumerate(host):
+        assert div < 5e-8 and t == time
+        for name, a in out.items():
+            want = ref[name][3 + r * nxl:3 + (r + 1) * nxl, 3:-3, 3:-3]
+            err = np.abs(a[3:-3, 3:-3, 3:-3] - want).max() / np.abs(ref[name]).max()
+            assert err <= (1e-12 if name != "p" else max(1e-12, 4 * np.finfo(float).eps * cond)), (r, name, err)
