@@ -109,3 +109,44 @@ def test_partition_coordinate_is_contiguous():
         pieces = [partition_coordinate((0.0, float(R)), 64, R, r) for r in range(R)]
         assert pieces[0][0] == 0.0 and pieces[-1][1] == float(R)
         assert all(a[1] == b[0] for a, b in zip(pieces[:-1], pieces[1:]))
+
+
+class _FakeCtx:
+    """enough of a Distributed architecture for the host-side grid logic (no device: grid handles are created lazily)"""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.partitioned, self.arch = world, rank, world > 1, None
+
+
+def test_distributed_grid_partitions_on_the_host():
+    """local sizes (remainder on the last rank, distributed_grids.jl:44-58), insert_connected_topology (:339-346), Face extents of
+    LeftConnected grids (grid_utils.jl:43-68), chained coordinates (partition_assemble.jl:63-76), pencil layout rank = ix * Ry + iy
+    (distributed_architectures.jl:354-389) -- test_distributed_models.jl:225-280 checks the same local extents"""
+    import oldoceananigans_jl_amd as ocn
+    from oldoceananigans_jl_amd import distributed as dist
+    # x-slabs of a Bounded direction, 25 columns over 3 ranks
+    grids = [dist.DistributedRectilinearGrid(_FakeCtx(3, r), size=(25, 8, 6), x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0),
+                                             topology=(ocn.Bounded, ocn.Periodic, ocn.Periodic)) for r in range(3)]
+    assert [g.local_size for g in grids] == [(8, 8, 6), (8, 8, 6), (9, 8, 6)]
+    assert [g.i_offset for g in grids] == [0, 8, 16] and all(g.irregular for g in grids)
+    assert [g.local.topology[0] for g in grids] == [ocn.RightConnected, ocn.FullyConnected, ocn.LeftConnected]
+    u_loc = (ocn.Face, ocn.Center, ocn.Center)
+    assert [g.local.total_size(u_loc)[0] for g in grids] == [8 + 6, 8 + 6, 9 + 1 + 6]          # N + 1 faces on the LeftConnected rank only
+    assert [g.local.interior_size(u_loc)[0] for g in grids] == [8, 8, 10]
+    edges = [(g.local.x0, g.local.x0 + g.local.Lx) for g in grids]
+    assert edges[0][0] == 0.0 and abs(edges[-1][1] - 2.0) < 1e-15
+    assert all(abs(a[1] - b[0]) < 1e-15 for a, b in zip(edges[:-1], edges[1:]))
+    # a Periodic direction: every rank FullyConnected
+    g = dist.DistributedRectilinearGrid(_FakeCtx(4, 2), size=(32, 8, 6), x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0))
+    assert g.local.topology[0] is ocn.FullyConnected and not g.irregular and g.i_offset == 16
+    # pencils: Partition(3, 2) of (25, 14): rank = ix * 2 + iy
+    for rank in range(6):
+        g = dist.DistributedRectilinearGrid(_FakeCtx(6, rank), size=(25, 14, 6), x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(3, 2))
+        ix, iy = rank // 2, rank % 2
+        assert g.local_size == ([8, 8, 9][ix], 7, 6) and (g.i_offset, g.j_offset) == ([0, 8, 16][ix], [0, 7][iy])
+        assert g.local.topology[:2] == (ocn.FullyConnected, ocn.FullyConnected)
+    # y-slabs only: x stays Periodic locally
+    g = dist.DistributedRectilinearGrid(_FakeCtx(3, 1), size=(16, 18, 6), x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(1, 3))
+    assert g.local.topology[:2] == (ocn.Periodic, ocn.FullyConnected) and g.local_size == (16, 6, 6) and g.j_offset == 6
+    with pytest.raises(ValueError):
+        dist.DistributedRectilinearGrid(_FakeCtx(4, 0), size=(16, 16, 6), x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(3, 2))
