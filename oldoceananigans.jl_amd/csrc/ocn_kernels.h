@@ -863,6 +863,22 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // pressure: source term, correction, scaling (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl)
 // ---------------------------------------------------------------------------------------------------------------------
+#define OCN_ZL 8      // lines (rows) of a line-FFT workgroup: 8 complex numbers = one 128-B row
+// the source term of the pressure equation at cell (i, j, k): divᶜᶜᶜ(u*) [x Δzᶜ for the Fourier-tridiagonal solver]
+// (solve_for_pressure.jl:12-84, Operators/divergence_operators.jl:16-19)
+__device__ __forceinline__ double source_value(const DGrid &g, const FView &u, const FView &v, const FView &w, int i, int j, int k,
+                                               bool weight_by_dz, bool wrap) {
+    const int kk = k - 1 + g.Hz;
+    const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
+    const int ip = (wrap && i == g.Nx) ? 1 : i + 1, jp = (wrap && j == g.Ny) ? 1 : j + 1, kp = (wrap && k == g.Nz) ? 1 : k + 1;
+    // δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49)
+    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(ip, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
+    double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, jp, k) - ay * v.at(i, j, k);
+    double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, kp) - az * w.at(i, j, k);
+    double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
+    return weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
+}
+
 template <bool REAL_OUT>
 // rhs element (i, j, k) is stored at (i-1) + sj*(j-1) + sk*(k-1); `pad` (real output only): the row has one extra, zero,
 // element after i = Nx (odd local Nx on the distributed solver's paired-column layout)
@@ -874,15 +890,7 @@ __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FVie
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
-    const int kk = k - 1 + g.Hz;
-    const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
-    const int ip = (wrap && i == g.Nx) ? 1 : i + 1, jp = (wrap && j == g.Ny) ? 1 : j + 1, kp = (wrap && k == g.Nz) ? 1 : k + 1;
-    // δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49)
-    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(ip, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
-    double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, jp, k) - ay * v.at(i, j, k);
-    double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, kp) - az * w.at(i, j, k);
-    double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
-    double val = weight_by_dz ? (1.0 * g.dzc[kk]) * div : 1.0 * div;
+    const double val = source_value(g, u, v, w, i, j, k, weight_by_dz, wrap);
     const long q = (long)(i - 1) + sj * (j - 1) + sk * (k - 1);
     if (REAL_OUT) {                                         // real-transform paths (rhs is real by construction)
         ((double *)rhs)[q] = val;
@@ -1174,7 +1182,6 @@ __global__ void __launch_bounds__(256) line_scatter_kernel(const double2 *B, dou
 // runs in bit-reversed order, inverse = radix-2 decimation in time (bit-reversed -> natural): in place, no reordering pass.
 // tw[m] = exp(-2πi m / Nz), m < Nz/2 (host-computed). `scale` folds the normalisation of the whole 3-D inverse transform.
 // ---------------------------------------------------------------------------------------------------------------------
-#define OCN_ZL 8
 __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const double2 *tw, const double *lx, const double *ly,
                                                           const double *lz, int Nxs, int Ny, int Nz, int logn, double scale, int pitch = 0) {
     extern __shared__ double2 zbuf[];                 // [Nz][OCN_ZL]

@@ -746,7 +746,8 @@ def test_simulation_run_loop(ocn, arch):
     assert np.allclose(times, [0.0, 0.7, 1.4], rtol=1e-14, atol=0) and np.isclose(model.clock.time, 2.0, rtol=1e-14)
 
 
-@pytest.mark.parametrize("size,zb", [((20, 8, 8), False), ((36, 16, 10), True), ((64, 32, 16), False), ((10, 64, 12), True)])
+@pytest.mark.parametrize("size,zb", [((20, 8, 8), False), ((36, 16, 10), True), ((64, 32, 16), False), ((10, 64, 12), True),
+                                     ((16, 8, 8), False), ((32, 16, 10), True), ((128, 16, 12), True)])
 def test_split_pressure_step_equals_library_plans(ocn, arch, size, zb):
     """the model's pressure step in split form (1-D x plans on 128-B-padded rows + the LDS column-FFT kernel for y + one kernel for the
     correction and p / Δt from the dense solution; option split_solve) against the 2-D library plans + separate kernels: same fields"""
@@ -767,9 +768,15 @@ def test_split_pressure_step_equals_library_plans(ocn, arch, size, zb):
             del model
         finally:
             ocn.set_option("split_solve", 1)
-    for name in outs[0]:
-        a, b = outs[0][name][3:-3, 3:-3, 3:-3], outs[1][name][3:-3, 3:-3, 3:-3]
-        assert np.abs(a - b).max() <= 1e-12 * max(np.abs(b).max(), 1e-30), name
+    # error model of the pressure: two exact-arithmetic-equivalent transforms differ by round-off times the condition number of the
+    # discrete Laplacian (anisotropic cells: 128 x 16 x 12 stretched has 1.8e3); velocities and tracers keep the 1e-12 bar
+    dzmin = float(np.diff(np.asarray(z)).min()) if zb else 1.0 / size[2]
+    cond = (4.0 * size[0] ** 2 + 4.0 * size[1] ** 2 + 4.0 / dzmin ** 2) / (2 * np.pi) ** 2
+    for other in outs[1:]:
+        for name in outs[0]:
+            a, b = outs[0][name][3:-3, 3:-3, 3:-3], other[name][3:-3, 3:-3, 3:-3]
+            tol = 1e-12 if name != "p" else max(1e-12, 4 * np.finfo(float).eps * cond)
+            assert np.abs(a - b).max() <= tol * max(np.abs(b).max(), 1e-30), name
 
 
 @pytest.mark.parametrize("N", [8, 9, 2, 3, 16, 27, 128])
