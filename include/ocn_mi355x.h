@@ -438,13 +438,16 @@ int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t local_grid, i
                                     const int *local_sizes, int global_x_topology);
 /* Partition(Rx, Ry) pencils (distributed_architectures.jl:354-434: rank = ix * Ry + iy, periodic wrap of the four neighbours):
  * ocn_dist_set_layout fixes the layout of a communicator (ocn_dist_model_create_pencil calls it); the local grid is connected in x when
- * Rx > 1 (codes as above) and OCN_CONNECTED in y when Ry > 1 (global y Periodic). sizes_x[Rx] / sizes_y[Ry]: slab widths (NULL: equal).
+ * Rx > 1 (codes as above) and in y when Ry > 1: OCN_CONNECTED where the global y direction is Periodic, OCN_RIGHT_CONNECTED (first row
+ * of ranks) / OCN_CONNECTED / OCN_LEFT_CONNECTED (last row) where global_y_topology = OCN_BOUNDED. sizes_x[Rx] / sizes_y[Ry]: slab
+ * widths (NULL: equal).
  * Every fill makes two hops -- x, then y over the whole x extent -- so corners arrive without corner messages
  * (fill_corners!, halo_communication.jl:137-162); solve! is the gathered solve on the global grid (the reference's pencil transposes,
  * distributed_transpose.jl:12-15, are not built). */
 int ocn_dist_set_layout(ocn_dist_t dist, int Rx, int Ry);
 int ocn_dist_model_create_pencil(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
-                                 double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology);
+                                 double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology,
+                                 int global_y_topology);
 int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus

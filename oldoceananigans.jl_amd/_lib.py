@@ -65,7 +65,7 @@ SYMBOLS = {
     "ocn_dist_model_create_sizes": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip]),
     "ocn_dist_model_create_partition": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, _ip, C.c_int]),
     "ocn_dist_set_layout": (C.c_int, [_vp, C.c_int, C.c_int]),
-    "ocn_dist_model_create_pencil": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, C.c_int]),
+    "ocn_dist_model_create_pencil": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int]),
     "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_sync": (C.c_int, []),

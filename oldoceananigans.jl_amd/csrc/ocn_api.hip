@@ -190,8 +190,8 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
             continue;
         }
         const bool connected = topo[d] == OCN_CONNECTED || topo[d] == OCN_RIGHT_CONNECTED || topo[d] == OCN_LEFT_CONNECTED;
-        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(connected && d == 0) && !(topo[d] == OCN_CONNECTED && d == 1))
-            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x only) Fully / Right / LeftConnected "
+        if (topo[d] != OCN_PERIODIC && topo[d] != OCN_BOUNDED && !(connected && d < 2))
+            return fail(OCN_ENOTSUP, "topology code %d in dimension %d: only Periodic, Bounded, Flat and (x, y only) Fully / Right / LeftConnected "
                                      "are accelerated", topo[d], d);
         // adapt_advection_order (Advection/adapt_advection_order.jl:90-96): WENO(order=5) stays where N >= 3 and becomes
         // WENO(order = 2N-1) = WENO{2} where N = 2; the halo must hold the adapted scheme's buffer (nonhydrostatic_model.jl:184,
@@ -338,7 +338,7 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
     // order: boundary_condition_ordering.jl:17-46 -- non-periodic first, then periodic; insertion sort with an
     // always-true `lt` reverses same-class entries => z, y, x inside each class.
     for (int d = 2; d >= 0; --d) {
-        const bool do_lo = wall_lo(T[d]), do_hi = wall_hi(T[d]);            // one wall only on Right / LeftConnected x
+        const bool do_lo = wall_lo(T[d]), do_hi = wall_hi(T[d]);            // one wall only on Right / LeftConnected x, y
         if (!do_lo && !do_hi) continue;
         const bool face = loc[d] == OCN_FACE;
         if (face && !fill_open) continue;
@@ -356,7 +356,7 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         const long total = (long)Na * Nb;
         const int nb = (int)((total + 255) / 256);
         if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open, do_lo, do_hi);
-        if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open);
+        if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open, do_lo, do_hi);
         if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open);
     }
     // triply periodic with N >= H everywhere: one launch writes every halo cell from its wrapped interior source
@@ -2229,7 +2229,8 @@ static int model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers, bool 
 
 extern "C" int ocn_model_create(ocn_model_t *model, ocn_grid_t grid, int ntracers) {
     NEED_INIT();
-    if (grid && (grid->d.tx == OCN_CONNECTED || grid->d.tx == OCN_RIGHT_CONNECTED || grid->d.tx == OCN_LEFT_CONNECTED || grid->d.ty == OCN_CONNECTED))
+    auto connected = [](int t) { return t == OCN_CONNECTED || t == OCN_RIGHT_CONNECTED || t == OCN_LEFT_CONNECTED; };
+    if (grid && (connected(grid->d.tx) || connected(grid->d.ty)))
         return fail(OCN_EINVAL, "a connected x or y direction needs ocn_dist_model_create");
     return model_create(model, grid, ntracers, true);
 }

@@ -313,7 +313,8 @@ struct DistModel {
     bool bounded_x = false;     // the partitioned direction is Bounded: Right / LeftConnected end ranks, no wrap-around neighbour
     bool pencil = false;        // Partition(Rx, Ry) with Ry > 1: a second hop along y per fill (corners ride along)
     double *ss = nullptr, *ns = nullptr, *sr = nullptr, *nr = nullptr;     // y-halo buffers: Hy rows of every prognostic field per side
-    bool general() const { return bounded_x || pencil; }                    // no overlap / thin exchanges on such partitions
+    bool plain_y = true;        // the non-partitioned y direction is Periodic (what the partitioned solvers transform); Bounded / Flat y: gathered solve
+    bool general() const { return bounded_x || pencil || !plain_y; }                    // no overlap / thin exchanges on such partitions
     bool partitioned() const { return dist->world > 1 || dist->self_loop; }
 };
 
@@ -359,8 +360,10 @@ static int y_halo_buffers(const DGrid &g, double *const *fields, const int (*loc
         maxt = std::max(maxt, cnt);
     }
     const int nb = (int)((maxt + 255) / 256);
+    // a wall side (Right / LeftConnected y) keeps what the local boundary fill left there: the ring still wraps, the data is dropped
     if (pack) hipLaunchKernelGGL(y_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north, true, true);
-    else      hipLaunchKernelGGL(y_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north, true, true);
+    else      hipLaunchKernelGGL(y_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north,
+                                 !wall_lo(g.ty), !wall_hi(g.ty));
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -493,7 +496,8 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     // (on a wall side the halo of the diffusivities comes from their boundary condition, like on a serial Bounded grid)
     const int ext = dm->partitioned() ? 1 : 0;
     const int ey = dm->pencil ? 1 : 0;                 // ... and along y on pencils
-    const int amd_range[6] = {1 - (wall_lo(g.tx) ? 0 : ext), g.Nx + (wall_hi(g.tx) ? 0 : ext), 1 - ey, g.Ny + ey, 1, g.Nz};
+    const int amd_range[6] = {1 - (wall_lo(g.tx) ? 0 : ext), g.Nx + (wall_hi(g.tx) ? 0 : ext), 1 - (wall_lo(g.ty) ? 0 : ey), g.Ny + (wall_hi(g.ty) ? 0 : ey),
+                              1, g.Nz};
     int rc;
     if (dm->halos_in_flight) {
         // the x exchange was started by make_pressure_correction!: finish the local fills (all columns are final now), take the
@@ -538,21 +542,24 @@ static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow)
 // NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected
 // (OCN_CONNECTED) when the direction is partitioned; `Lx_global`: extent of the global domain along x (the solver's eigenvalues)
 static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
-                             int global_x_topology, double Ly_global = 0.0, const int *sizes_y = nullptr);
+                             int global_x_topology, double Ly_global = 0.0, const int *sizes_y = nullptr, int global_y_topology = OCN_PERIODIC);
 extern "C" int ocn_dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global) {
     return dist_model_create(model, local_grid, ntracers, dist, Lx_global, nullptr, OCN_PERIODIC);
 }
-// Partition(Rx, Ry) pencils (f.4 of SURVEY.md 8): rank = ix * Ry + iy, the local grid is connected in x (Rx > 1) and FullyConnected in y
-// (Ry > 1, global y Periodic); sizes_x[Rx], sizes_y[Ry] list the slab widths (NULL: equal). Every fill makes two hops -- x, then y over
+// Partition(Rx, Ry) pencils (f.4 of SURVEY.md 8): rank = ix * Ry + iy, the local grid is connected in x (Rx > 1) and in y (Ry > 1):
+// FullyConnected where the global direction is Periodic, Right / Fully / LeftConnected along a Bounded one (insert_connected_topology,
+// distributed_grids.jl:339-346); sizes_x[Rx], sizes_y[Ry] list the slab widths (NULL: equal). Every fill makes two hops -- x, then y over
 // the whole x extent, so the corners arrive without corner messages (halo_communication.jl:137-162) --; the pressure solve is the
 // gathered one (the reference's pencil transposes, distributed_transpose.jl:12-15, are not built).
 extern "C" int ocn_dist_model_create_pencil(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
-                                            double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology) {
+                                            double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology,
+                                            int global_y_topology) {
     if (!dist) return fail(OCN_EINVAL, "NULL argument");
     if (global_x_topology != OCN_PERIODIC && global_x_topology != OCN_BOUNDED) return fail(OCN_EINVAL, "the x direction is Periodic or Bounded");
+    if (global_y_topology != OCN_PERIODIC && global_y_topology != OCN_BOUNDED) return fail(OCN_EINVAL, "the y direction is Periodic or Bounded");
     int rc = ocn_dist_set_layout(dist, Rx, Ry);
     if (rc) return rc;
-    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, sizes_x, global_x_topology, Ly_global, sizes_y);
+    return dist_model_create(model, local_grid, ntracers, dist, Lx_global, sizes_x, global_x_topology, Ly_global, sizes_y, global_y_topology);
 }
 // the same for an irregular partition: local_sizes[r] = Nx of rank r (local_size, distributed_grids.jl:44-58: N ÷ R cells per rank and
 // the remainder on the last one; or any `Sizes`). Equal sizes take the solvers above; otherwise the pressure solve gathers the source
@@ -574,7 +581,7 @@ extern "C" int ocn_dist_model_create_partition(ocn_model_t *model, ocn_grid_t lo
 }
 
 static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx_global, const int *sizes, int global_tx, double Ly_global,
-                                 const int *sizes_y) {
+                                 const int *sizes_y, int global_ty) {
     const DGrid &g = local_grid->d;
     const int R = dm->dist->Rx, Ry = dm->dist->Ry, ix = dm->dist->rank / Ry, iy = dm->dist->rank % Ry;
     if (dm->dist->world > OCN_MAX_RANKS) return fail(OCN_ENOTSUP, "gathered solves take at most %d ranks", OCN_MAX_RANKS);
@@ -598,7 +605,7 @@ static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx
     q->table.firsty[Ry] = q->Nyg;
     if (sizes[ix] != g.Nx) return fail(OCN_EINVAL, "sizes_x[%d] = %d but the local grid has Nx = %d", ix, sizes[ix], g.Nx);
     if ((sizes_y ? sizes_y[iy] : g.Ny) != g.Ny) return fail(OCN_EINVAL, "sizes_y[%d] = %d but the local grid has Ny = %d", iy, sizes_y[iy], g.Ny);
-    const int N[3] = {q->Nxg, q->Nyg, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {global_tx, Ry > 1 ? OCN_PERIODIC : g.ty, g.tz};
+    const int N[3] = {q->Nxg, q->Nyg, g.Nz}, H[3] = {g.Hx, g.Hy, g.Hz}, topo[3] = {global_tx, Ry > 1 ? global_ty : g.ty, g.tz};
     const double L[3] = {Lx_global, Ry > 1 ? Ly_global : local_grid->L[1], local_grid->L[2]};
     const bool zr = local_grid->z_regular;
     int rc = ocn_grid_create(&q->ggrid, N, H, topo, L, Lx_global / (double)q->Nxg, Ry > 1 ? Ly_global / (double)q->Nyg : g.dy, local_grid->h_dzc[g.Hz],
@@ -618,7 +625,7 @@ static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx
 }
 
 static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
-                             int global_x_topology, double Ly_global, const int *sizes_y) {
+                             int global_x_topology, double Ly_global, const int *sizes_y, int global_y_topology) {
     NEED_INIT();
     if (!model || !local_grid || !dist) return fail(OCN_EINVAL, "NULL argument");
     const DGrid &g = local_grid->d;
@@ -632,8 +639,13 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
     if (bounded_x && dist->self_loop) return fail(OCN_EINVAL, "self_loop closes a Periodic direction");
     if (g.tx != expect)
         return fail(OCN_EINVAL, "rank %d of %d: the local grid's x topology code is %d, insert_connected_topology gives %d", dist->rank, dist->world, g.tx, expect);
-    if (pencil && g.ty != OCN_CONNECTED) return fail(OCN_EINVAL, "the local grid of a pencil partition is FullyConnected in y (global y Periodic)");
-    if (!pencil && g.ty == OCN_CONNECTED) return fail(OCN_EINVAL, "a FullyConnected y direction needs Ry > 1 (ocn_dist_model_create_pencil)");
+    const int iy = dist->rank % dist->Ry, Ry = dist->Ry;
+    const int expect_y = !pencil ? g.ty : (global_y_topology != OCN_BOUNDED ? OCN_CONNECTED
+                                           : (iy == 0 ? OCN_RIGHT_CONNECTED : (iy == Ry - 1 ? OCN_LEFT_CONNECTED : OCN_CONNECTED)));
+    if (pencil && g.ty != expect_y)
+        return fail(OCN_EINVAL, "rank %d of %d: the local grid's y topology code is %d, insert_connected_topology gives %d", dist->rank, dist->world, g.ty, expect_y);
+    if (!pencil && (g.ty == OCN_CONNECTED || g.ty == OCN_RIGHT_CONNECTED || g.ty == OCN_LEFT_CONNECTED))
+        return fail(OCN_EINVAL, "a connected y direction needs Ry > 1 (ocn_dist_model_create_pencil)");
     if (pencil && dist->self_loop) return fail(OCN_EINVAL, "self_loop has one rank");
     int rc = model_create(model, local_grid, ntracers, /*with_solver=*/false);
     if (rc) return rc;
@@ -662,6 +674,7 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
         for (int r = 0; r < Rx; ++r) irregular = irregular || local_sizes[r] != local_sizes[0];
     dm->bounded_x = bounded_x && part;
     dm->pencil = pencil;
+    dm->plain_y = pencil || g.ty == OCN_PERIODIC;
     if (pencil) {
         size_t rows = 0;
         for (int f = 0; f < m->nf; ++f) rows += dist_rows(g, m->loc[f], g.Hy);
@@ -672,10 +685,10 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
             hipMemsetAsync(*b, 0, rows * sizeof(double), g_stream);
         }
     }
-    if (irregular || dm->bounded_x || pencil) {
+    if (irregular || dm->general()) {
         if (dist->self_loop) return bail(fail(OCN_EINVAL, "self_loop has one slab"));
         std::vector<int> equal((size_t)Rx, g.Nx);
-        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes ? local_sizes : equal.data(), global_x_topology, Ly_global, sizes_y)))
+        if ((rc = gathered_solve_create(dm, local_grid, Lx_global, local_sizes ? local_sizes : equal.data(), global_x_topology, Ly_global, sizes_y, global_y_topology)))
             return bail(rc);
         return OCN_OK;
     }

@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FVie
 // tendencies holding the advective part.
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool inactive_cell(const DGrid &g, int i, int j, int k) {
-    return ((wall_lo(g.tx) && i < 1) || (wall_hi(g.tx) && i > g.Nx)) || (g.ty == OCN_BOUNDED && (j < 1 || j > g.Ny)) ||
+    return ((wall_lo(g.tx) && i < 1) || (wall_hi(g.tx) && i > g.Nx)) || ((wall_lo(g.ty) && j < 1) || (wall_hi(g.ty) && j > g.Ny)) ||
            (g.tz == OCN_BOUNDED && (k < 1 || k > g.Nz));
 }
 

@@ -288,15 +288,19 @@ class DistributedRectilinearGrid:
             tx = FullyConnected
         else:
             tx = RightConnected if r == 0 else (LeftConnected if r == R - 1 else FullyConnected)
-        # the y direction of a pencil partition (global y Periodic): FullyConnected local grids, the remainder on the last row of ranks
+        # the y direction of a pencil partition: connected local grids (insert_connected_topology again), the remainder on the last row
         self.local_sizes_y = local_sizes(self.global_size[1], Ry)
         self.Ly_global = _regular_coordinate(y, self.global_size[1], "y")[1]
+        self.global_y_topology = topology[1]
         nyl = self.local_sizes_y[iy]
         ty = topology[1]
         if Ry > 1:
-            if topology[1] is not Periodic:
-                raise NotImplementedError("the y direction of a pencil partition is Periodic")
-            ty = FullyConnected
+            if topology[1] not in (Periodic, Bounded):
+                raise ValueError("a partitioned direction is Periodic or Bounded")
+            if topology[1] is Periodic:
+                ty = FullyConnected
+            else:
+                ty = RightConnected if iy == 0 else (LeftConnected if iy == Ry - 1 else FullyConnected)
             y = partition_coordinate(y, self.local_sizes_y, Ry, iy)
         self.j_offset = sum(self.local_sizes_y[:iy])
         topo = (tx, ty, topology[2])
@@ -1047,7 +1051,8 @@ class LibraryDistributedModel(_NonhydrostaticModel):
             sx = (C.c_int * Rx)(*grid.local_sizes)
             sy = (C.c_int * Ry)(*grid.local_sizes_y)
             _lib.check(_lib.lib().ocn_dist_model_create_pencil(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global),
-                                                               float(grid.Ly_global), Rx, Ry, sx, sy, 1 if bounded else 0))
+                                                               float(grid.Ly_global), Rx, Ry, sx, sy, 1 if bounded else 0,
+                                                               1 if getattr(grid, "global_y_topology", Periodic) is Bounded else 0))
         elif getattr(grid, "irregular", False) or bounded:
             sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
             _lib.check(_lib.lib().ocn_dist_model_create_partition(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,

@@ -145,6 +145,12 @@ def test_distributed_grid_partitions_on_the_host():
         ix, iy = rank // 2, rank % 2
         assert g.local_size == ([8, 8, 9][ix], 7, 6) and (g.i_offset, g.j_offset) == ([0, 8, 16][ix], [0, 7][iy])
         assert g.local.topology[:2] == (ocn.FullyConnected, ocn.FullyConnected)
+    # a Bounded partitioned y direction: Right / Fully / LeftConnected rows of ranks, Ny + 1 y-faces on the last row
+    gy = [dist.DistributedRectilinearGrid(_FakeCtx(3, r), size=(16, 19, 6), x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(1, 3),
+                                          topology=(ocn.Periodic, ocn.Bounded, ocn.Periodic)) for r in range(3)]
+    assert [g.local.topology[1] for g in gy] == [ocn.RightConnected, ocn.FullyConnected, ocn.LeftConnected]
+    v_loc = (ocn.Center, ocn.Face, ocn.Center)
+    assert [g.local.interior_size(v_loc)[1] for g in gy] == [6, 6, 8] and [g.j_offset for g in gy] == [0, 6, 12]
     # y-slabs only: x stays Periodic locally
     g = dist.DistributedRectilinearGrid(_FakeCtx(3, 1), size=(16, 18, 6), x=(0.0, 2.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(1, 3))
     assert g.local.topology[:2] == (ocn.Periodic, ocn.FullyConnected) and g.local_size == (16, 6, 6) and g.j_offset == 6

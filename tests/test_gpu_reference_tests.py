@@ -353,3 +353,134 @@ def test_weno_convergence_run_and_directional_symmetry(ocn, arch):
         assert np.all(np.diff(e[3:]) < 0), (name, axis, e)
         i128, i256, i512 = Ns.index(128), Ns.index(256), Ns.index(512)
         assert e[i128] / e[i256] > 16 and e[i256] / e[i512] > 16, (name, axis, e)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# boundary conditions and the "next" row's physics, again as the reference tests them
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("topology,names,sides", [
+    (("Periodic", "Bounded", "Bounded"), ("u", "c"), ("north", "south", "top", "bottom")),
+    (("Bounded", "Periodic", "Bounded"), ("v", "c"), ("east", "west", "top", "bottom")),
+    (("Bounded", "Bounded", "Periodic"), ("w", "c"), ("east", "west", "north", "south")),
+])
+def test_nonhydrostatic_flux_budget(ocn, arch, topology, names, sides):
+    """test_nonhydrostatic_flux_budget (test_boundary_conditions_integration.jl:28-52, driven at :309-358 on the plain RectilinearGrid):
+    size (2, 2, 2) on 0.3 x 0.4 x 0.5, a Flux condition of ±π on one side of a field that starts at 0, ONE step of Δt = 1:
+    mean(ϕ) ≈ flux · t / L"""
+    Lx, Ly, Lz = 0.3, 0.4, 0.5
+    L = {"east": Lx, "west": Lx, "north": Ly, "south": Ly, "top": Lz, "bottom": Lz}
+    topo = tuple(getattr(ocn, t) for t in topology)
+    for name in names:
+        for side in sides:
+            grid = ocn.RectilinearGrid(arch, size=(2, 2, 2), x=(0.0, Lx), y=(0.0, Ly), z=(0.0, Lz), topology=topo)
+            direction = 1 if side in ("west", "south", "bottom") else -1
+            bcs = {name: ocn.FieldBoundaryConditions(**{side: ocn.BoundaryCondition("Flux", np.pi * direction)})}
+            model = ocn.NonhydrostaticModel(grid=grid, boundary_conditions=bcs, tracers=("c",))
+            model.fields()[name].set(0.0)
+            ocn.time_step(model, 1.0)
+            mean = model.fields()[name].interior().mean()
+            expected = np.pi * model.clock.time / L[side]
+            assert abs(mean - expected) <= SQRT_EPS * max(abs(mean), abs(expected)), (name, side, mean, expected)
+            model.close()
+
+
+@pytest.mark.parametrize("timestepper", ["RungeKutta3", "QuasiAdamsBashforth2"])
+def test_diffusion_simple(ocn, arch, timestepper):
+    """test_diffusion_simple (test_dynamics.jl:17-32, explicit time discretisation): (1, 1, 16) on (1, 1, 1), ν = κ = 1, a field equal
+    to π, 10 steps of Δt = 1: still π. Adaptation: the one-cell x and y directions are Flat (see the convergence run above)."""
+    for name in ("u", "v", "c"):
+        grid = ocn.RectilinearGrid(arch, size=(16,), z=(-1.0, 0.0), topology=(ocn.Flat, ocn.Flat, ocn.Bounded))
+        model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=1.0, κ=1.0), timestepper=timestepper, tracers=("c",))
+        f = model.fields()[name]
+        f.set(np.pi)
+        ocn.update_state(model)
+        for _ in range(10):
+            ocn.time_step(model, 1.0)
+        assert np.allclose(f.interior(), np.pi, rtol=SQRT_EPS, atol=0), name
+        model.close()
+
+
+@pytest.mark.parametrize("timestepper", ["RungeKutta3", "QuasiAdamsBashforth2"])
+@pytest.mark.parametrize("topology", [("Periodic", "Periodic", "Periodic"), ("Periodic", "Periodic", "Bounded"),
+                                      ("Periodic", "Bounded", "Bounded"), ("Bounded", "Bounded", "Bounded")])
+def test_scalar_diffusivity_budget(ocn, arch, topology, timestepper):
+    """test_ScalarDiffusivity_budget (test_dynamics.jl:34-56, driven at :412-458 with ScalarDiffusivity, explicit): (4, 4, 4) on
+    (1, 1, 1), ν = κ = 1, the field rand(), the others 0, 10 steps of Δt = 1e-4 Δz² / ν: the mean is kept (`≈`)"""
+    names = ["c"] + [n for n, t in zip("uvw", topology) if t == "Periodic"]
+    rng = np.random.default_rng(5)
+    for name in names:
+        grid = ocn.RectilinearGrid(arch, size=(4, 4, 4), extent=(1, 1, 1), topology=tuple(getattr(ocn, t) for t in topology))
+        model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=1.0, κ=1.0), timestepper=timestepper, tracers=("c",))
+        ocn.set_model(model, u=0.0, v=0.0, w=0.0, c=0.0)
+        ocn.set_model(model, **{name: lambda x, y, z: rng.random(np.broadcast(x, y, z).shape)})
+        f = model.fields()[name]
+        before = f.interior().mean()
+        ocn.update_state(model)
+        for _ in range(10):
+            ocn.time_step(model, 1e-4 * 0.25 ** 2)
+        after = f.interior().mean()
+        assert abs(after - before) <= SQRT_EPS * max(abs(after), abs(before)), (name, before, after)
+        model.close()
+
+
+@pytest.mark.parametrize("timestepper", ["RungeKutta3", "QuasiAdamsBashforth2"])
+def test_diffusion_cosine(ocn, arch, timestepper):
+    """test_diffusion_cosine (test_dynamics.jl:65-87) on the reference's first grid (:540-552: (Periodic, Periodic, Bounded), size
+    (2, 2, 128) -> here (4, 4, 128): N >= 2 is what WENO(order = 5) adapts to, the diffusion does not care), z in (0, π/2),
+    ScalarDiffusivity(ν = κ = 1): cos(2 z) in u, v or c decays as exp(-4 t) over 5 steps of Δt = 1e-6 Lz²; isapprox(atol = rtol = 1e-6)"""
+    N, Lz = 128, np.pi / 2
+    for name in ("u", "v", "c"):
+        grid = ocn.RectilinearGrid(arch, size=(4, 4, N), x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, Lz),
+                                   topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=1.0, κ=1.0), timestepper=timestepper, tracers=("c",))
+        f = model.fields()[name]
+        x, y, z = grid.nodes(f.loc)
+        f0 = np.cos(2 * z) + 0 * (x + y)
+        f.set(f0)
+        ocn.update_state(model)
+        for _ in range(5):
+            ocn.time_step(model, 1e-6 * Lz ** 2)
+        exact = np.exp(-4 * model.clock.time) * f0
+        got = f.interior()
+        assert np.linalg.norm(got - exact) <= max(1e-6, 1e-6 * max(np.linalg.norm(got), np.linalg.norm(exact))), name
+        model.close()
+
+
+@pytest.mark.parametrize("ykind,stretched", [("Periodic", False), ("Flat", False), ("Periodic", True), ("Flat", True)])
+def test_internal_wave_dynamics(ocn, arch, ykind, stretched):
+    """internal_wave_dynamics_test (test_internal_wave_dynamics.jl:4-94) on the reference's four grids (test_dynamics.jl:640-661, driven
+    at :690-700 for NonhydrostaticModel): 128 x 128 on 2π x 2π, y Periodic | Flat, z regular | a face ARRAY of the same regular spacing
+    (the Fourier-tridiagonal solver); BuoyancyTracer, FPlane(f = 0.2), ScalarDiffusivity(ν = κ = 1e-9); 10 steps of Δt = 0.01 / σ;
+    relative_error(u) < 1e-4. Adaptation: the Periodic y direction has 4 cells instead of 1 (one-cell non-Flat directions are refused)."""
+    Lx, Nx, Nz = 2 * np.pi, 128, 128
+    z = np.linspace(-Lx, 0.0, Nz + 1) if stretched else (-Lx, 0.0)
+    if ykind == "Flat":
+        grid = ocn.RectilinearGrid(arch, size=(Nx, Nz), x=(0.0, Lx), z=z, topology=(ocn.Periodic, ocn.Flat, ocn.Bounded))
+    else:
+        grid = ocn.RectilinearGrid(arch, size=(Nx, 4, Nz), x=(0.0, Lx), y=(0.0, Lx), z=z, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    f, NN, mz, kx, a0 = 0.2, 1.0, 16, 1, 1e-3
+    z0, d = -Lx / 3, Lx / 20
+    sig = np.sqrt((NN ** 2 * kx ** 2 + f ** 2 * mz ** 2) / (kx ** 2 + mz ** 2))
+    dt = 0.01 / sig
+    cg = mz * sig / (kx ** 2 + mz ** 2) * (f ** 2 / sig ** 2 - 1)
+    U, V = a0 * kx * sig / (sig ** 2 - f ** 2), a0 * kx * f / (sig ** 2 - f ** 2)
+    W, B = a0 * mz * sig / (sig ** 2 - NN ** 2), a0 * mz * NN ** 2 / (sig ** 2 - NN ** 2)
+
+    def a(zz, t):
+        return np.exp(-(zz - cg * t - z0) ** 2 / (2 * d) ** 2)
+
+    def u(x, y, zz, t=0.0):
+        return a(zz, t) * U * np.cos(kx * x + mz * zz - sig * t) + 0 * y
+    model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=1e-9, κ=1e-9), buoyancy=ocn.BuoyancyTracer(),
+                                    tracers=("b",), coriolis=ocn.FPlane(f=f))
+    ocn.set_model(model, u=u, v=lambda x, y, zz: a(zz, 0) * V * np.sin(kx * x + mz * zz) + 0 * y,
+                  w=lambda x, y, zz: a(zz, 0) * W * np.cos(kx * x + mz * zz) + 0 * y,
+                  b=lambda x, y, zz: a(zz, 0) * B * np.sin(kx * x + mz * zz) + NN ** 2 * zz + 0 * (x + y))
+    for _ in range(10):
+        ocn.time_step(model, dt)
+    uf = model.fields()["u"]
+    x, y, zz = grid.nodes(uf.loc)
+    exact = u(x, y, zz, model.clock.time)
+    got = uf.interior()
+    assert np.mean((got - exact) ** 2) / np.mean(exact ** 2) < 1e-4
+    assert np.mean((got - u(x, y, zz, 0.0)) ** 2) / np.mean(exact ** 2) > 1e-4          # the wave did propagate
