@@ -189,6 +189,12 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=Fals
                             assert np.all(a[:3, :3, 3:-3] == 100 * n + sw), (rank, n)
                         if not (wall_e or wall_n):
                             assert np.all(a[-3:, -3:, 3:-3] == 100 * n + ne), (rank, n)
+                        se = ((ix_ + 1) % Rx_) * Ry_ + (iy_ - 1) % Ry_
+                        nw = ((ix_ - 1) % Rx_) * Ry_ + (iy_ + 1) % Ry_
+                        if not (wall_e or wall_s):
+                            assert np.all(a[-3:, :3, 3:-3] == 100 * n + se), (rank, n)
+                        if not (wall_w or wall_n):
+                            assert np.all(a[:3, -3:, 3:-3] == 100 * n + nw), (rank, n)
             results[rank] = (out, div, model.clock.time, (grid.i_offset, grid.j_offset))
             model.close()
             ctx.close()
