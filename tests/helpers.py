@@ -53,7 +53,7 @@ def make_pair(ocn, O, arch, size, topology=("Periodic", "Periodic", "Periodic"),
     zc = z if z is not None else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
     g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=zc, topology=topo_cls)
     g_cpu = O.Grid(size, topology=tuple(ORACLE_TOPO[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=zc)
-    names = ("T", "S", "C3", "C4")[:ntracers]
+    names = ("T", "S", "C3", "C4", "C5", "C6", "C7", "C8")[:ntracers]
     m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, advection=ocn.WENO(), tracers=names)
     m_cpu = O.Model(g_cpu, ntracers)
     return g_gpu, g_cpu, m_gpu, m_cpu

@@ -1081,3 +1081,67 @@ def test_halo_regions_as_the_reference_tests_them(ocn, oracle, arch, N):
     with pytest.raises(ocn.OcnError, match="halo|size 1"):
         U, G = [ocn.XFaceField(grid), ocn.YFaceField(grid), ocn.ZFaceField(grid)], [ocn.XFaceField(grid), ocn.YFaceField(grid), ocn.ZFaceField(grid)]
         ocn.kernels.compute_tendencies(grid, U[0], U[1], U[2], [], G[0], G[1], G[2], [])
+
+
+@pytest.mark.parametrize("topology", TOPOS)
+@pytest.mark.parametrize("ntracers", [0, 1, 3, 4, 8])
+def test_tracer_counts_match_oracle(ocn, oracle, arch, topology, ntracers):
+    """the model with 0, 1, 3 (the one-field-per-workgroup kernel's instantiations), 4 and 8 tracers (more than that kernel takes: the
+    per-field kernels; 8 = the library's maximum): tendencies bit-identical to the oracle for every implementation that accepts the
+    count, fields within 1e-12 after 3 RK3 steps"""
+    size = (16, 12, 10)
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else None
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=z, ntracers=ntracers)
+    set_both(ocn, m_gpu, m_cpu, seed=5, enforce_incompressibility=False)
+    m_cpu.update_state(True)
+    cpu_names = ["u", "v", "w"] + ["c%d" % t for t in range(ntracers)]
+    for impl in (0, 1, 2):
+        m_gpu.set_option("tendency_impl", impl)
+        for n in m_gpu.fields():
+            m_gpu.tendency(n).set_parent(np.zeros(m_gpu.tendency(n).shape))
+        ocn.update_state(m_gpu, True)
+        for n, cn in zip(m_gpu.fields().keys(), cpu_names):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (impl, n)
+    m_gpu.set_option("tendency_impl", 2)
+    set_both(ocn, m_gpu, m_cpu, seed=6, smooth=True)
+    dt = 0.1 * g_gpu.Δxᶜᵃᵃ / 0.6
+    for _ in range(3):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (name, ntracers)
+
+
+@pytest.mark.parametrize("size", [(65, 8, 6), (129, 15, 5), (64, 7, 7), (63, 14, 4), (130, 6, 9), (200, 3, 3)])
+@pytest.mark.parametrize("topology", TOPOS)
+def test_tile_edges_of_the_tendency_kernels(ocn, oracle, arch, size, topology):
+    """sizes around the 64 x 7 tiles of the one-field-per-workgroup kernel (one column / one row more or fewer than whole tiles, a single
+    row of tiles, Ny = 3): every implementation bit-identical to the oracle, also with the fused substep (3 steps within 1e-12)"""
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else None
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=z)
+    set_both(ocn, m_gpu, m_cpu, seed=9, enforce_incompressibility=False)
+    m_cpu.update_state(True)
+    for impl in (0, 1, 2):
+        m_gpu.set_option("tendency_impl", impl)
+        for n in m_gpu.fields():
+            m_gpu.tendency(n).set_parent(np.zeros(m_gpu.tendency(n).shape))
+        ocn.update_state(m_gpu, True)
+        for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (impl, n)
+    m_gpu.set_option("tendency_impl", 2)
+    set_both(ocn, m_gpu, m_cpu, seed=10, smooth=True)
+    dt = 0.1 * min(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ) / 0.6
+    for _ in range(3):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    umax = max(np.abs(m_cpu.field(n)).max() for n in ("u", "v", "w"))
+    dmax = max(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.max(g_gpu.Δzᵃᵃᶜ)))
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        ia, ib = a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]
+        if name == "pNHS":
+            # strongly anisotropic cells (129 x 15 x 5 on the unit cube): p = lap^-1(div u*) / dt carries the velocities' round-off times
+            # dx / dt -- the error model of test_adapted_advection_order_matches_oracle
+            pscale = max(np.abs(ib).max(), umax * dmax / dt)
+            assert np.max(np.abs(ia - ib)) < 1e-12 * pscale, (name, size, np.max(np.abs(ia - ib)), pscale)
+            continue
+        assert rel_err(ia, ib) < 1e-12, (name, size)
