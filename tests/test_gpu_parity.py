@@ -1145,3 +1145,33 @@ def test_tile_edges_of_the_tendency_kernels(ocn, oracle, arch, size, topology):
             assert np.max(np.abs(ia - ib)) < 1e-12 * pscale, (name, size, np.max(np.abs(ia - ib)), pscale)
             continue
         assert rel_err(ia, ib) < 1e-12, (name, size)
+
+
+@pytest.mark.parametrize("size,topology", [((64, 64, 64), TOPOS[0]), ((96, 80, 40), TOPOS[1]), ((128, 49, 33), TOPOS[0])])
+def test_mid_size_parity_with_the_oracle(ocn, oracle, arch, size, topology):
+    """the largest sizes the oracle finishes in seconds: several tiles and workgroups per direction, the z march over chunks, the fused
+    substep, the split pressure solve (64^3) and the library-plan solve (other sizes) -- tendencies bit-identical, 5 RK3 steps within 1e-12"""
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else None
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=z)
+    set_both(ocn, m_gpu, m_cpu, seed=21, enforce_incompressibility=False)
+    m_cpu.update_state(True)
+    for impl in (1, 2):
+        m_gpu.set_option("tendency_impl", impl)
+        ocn.update_state(m_gpu, True)
+        for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (impl, n)
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.1 * min(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ) / 0.6
+    for _ in range(5):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    assert m_gpu.clock.time == m_cpu.time
+    umax = max(np.abs(m_cpu.field(n)).max() for n in ("u", "v", "w"))
+    dmax = max(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.max(g_gpu.Δzᵃᵃᶜ)))
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        ia, ib = a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]
+        if name == "pNHS":       # stretched cells: the error model of test_adapted_advection_order_matches_oracle (eps |u| dx / dt reaches p)
+            assert np.max(np.abs(ia - ib)) < 1e-12 * max(np.abs(ib).max(), umax * dmax / dt), (name, size)
+            continue
+        assert rel_err(ia, ib) < 1e-12, (name, size, rel_err(ia, ib))
+    assert ocn.max_abs_divergence(m_gpu) < 5e-8
