@@ -898,6 +898,24 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Poisson solvers
 // ---------------------------------------------------------------------------------------------------------------------
+// line-FFT kernels (ocn_kernels.h): lines per workgroup by line length, see strided_line_fft_kernel
+static inline int line_zl(int n) { return n >= 512 ? 4 : 8; }
+static inline void launch_strided_line_fft(double2 *data, const double2 *tw, long C, long ncols, unsigned batches, int N, int logn, int inverse,
+                                           double scale, long plane_stride = 0) {
+    const int zl = line_zl(N);
+    const dim3 grd((unsigned)((ncols + zl - 1) / zl), batches);
+    const size_t lds = (size_t)N * zl * sizeof(double2);
+    if (zl == 4) hipLaunchKernelGGL(strided_line_fft_kernel<4>, grd, dim3(256), lds, g_stream, data, tw, C, N, logn, inverse, scale, plane_stride);
+    else         hipLaunchKernelGGL(strided_line_fft_kernel<8>, grd, dim3(256), lds, g_stream, data, tw, C, N, logn, inverse, scale, plane_stride);
+}
+static inline void launch_zline_solve(double2 *hc, const double2 *tw, const double *lx, const double *ly, const double *lz, int Nxs, int Ny, int Nz,
+                                      int logn, double scale, int pitch = 0) {
+    const int zl = line_zl(Nz);
+    const dim3 grd((unsigned)((Nxs + zl - 1) / zl), (unsigned)Ny);
+    const size_t lds = (size_t)Nz * zl * sizeof(double2);
+    if (zl == 4) hipLaunchKernelGGL(zline_solve_kernel<4>, grd, dim3(256), lds, g_stream, hc, tw, lx, ly, lz, Nxs, Ny, Nz, logn, scale, pitch);
+    else         hipLaunchKernelGGL(zline_solve_kernel<8>, grd, dim3(256), lds, g_stream, hc, tw, lx, ly, lz, Nxs, Ny, Nz, logn, scale, pitch);
+}
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
@@ -1293,18 +1311,14 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
                 if (ok) {
                     // forward: the split form against the library's 2-D plan on pseudo-random data; inverse: round trip of the split form
                     const long n = (long)s->n;
-                    const dim3 grd((unsigned)(s->Nxp / OCN_ZL), (unsigned)g.Nz);
-                    const size_t lds = (size_t)g.Ny * OCN_ZL * sizeof(double2);
                     hipLaunchKernelGGL(selfcheck_fill_real, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, s->rrhs, n);
                     ok = hipfftExecD2Z(s->plan_r2c, s->rrhs, (hipfftDoubleComplex *)ref) == HIPFFT_SUCCESS &&
                          hipfftExecD2Z(s->plan_xr2c, s->rrhs, (hipfftDoubleComplex *)s->hc) == HIPFFT_SUCCESS;
-                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 0, 1.0,
-                                       (long)s->Nxp * g.Ny);
+                    launch_strided_line_fft(s->hc, s->ytw, (long)s->Nxp, (long)s->Nxp, (unsigned)g.Nz, g.Ny, s->logn_y, 0, 1.0, (long)s->Nxp * g.Ny);
                     hipLaunchKernelGGL(max_abs_diff_pitched_kernel, dim3(256), dim3(256), 0, g_stream, (const double2 *)ref, s->Nxh,
                                        (const double2 *)s->hc, s->Nxp, s->Nxh, (long)g.Ny * g.Nz, bm);
                     ok = ok && reduce_blockmax(bm, 256, &e_fwd) == OCN_OK;
-                    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 1, 1.0,
-                                       (long)s->Nxp * g.Ny);
+                    launch_strided_line_fft(s->hc, s->ytw, (long)s->Nxp, (long)s->Nxp, (unsigned)g.Nz, g.Ny, s->logn_y, 1, 1.0, (long)s->Nxp * g.Ny);
                     ok = ok && hipfftExecZ2D(s->plan_xc2r, (hipfftDoubleComplex *)s->hc, s->rrhs) == HIPFFT_SUCCESS;
                     hipLaunchKernelGGL(selfcheck_compare_real, dim3(256), dim3(256), 0, g_stream, s->rrhs, g.Nx, g.Ny, g.Nz, g.Nx, g.Ny, 0, 0, 0,
                                        1.0 / ((double)g.Nx * g.Ny), bm);
@@ -1404,8 +1418,7 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
     double2 *sol = s->hc;
     if (s->kind == 0 && s->zfused) {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
-        hipLaunchKernelGGL(zline_solve_kernel, dim3((s->Nxh + OCN_ZL - 1) / OCN_ZL, g.Ny), dim3(256), (size_t)g.Nz * OCN_ZL * sizeof(double2),
-                           g_stream, s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale);
+        launch_zline_solve(s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale);
     } else if (s->kind == 0) {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
         hipLaunchKernelGGL(spectral_divide_kernel, grid3(s->Nxh, g.Ny, g.Nz, BLK), BLK, 0, g_stream, s->hc, s->lam[0], s->lam[1],
@@ -1433,16 +1446,13 @@ static int poisson_solve_real(ocn_poisson_s *s, double *phi) {
 static int poisson_solve_real_split(ocn_poisson_s *s) {
     const DGrid &g = s->grid->d;
     { int rc_; if ((rc_ = plan_set_stream(s->plan_xr2c)) || (rc_ = plan_set_stream(s->plan_xc2r))) return rc_; }
-    const dim3 grd((unsigned)(s->Nxp / OCN_ZL), (unsigned)g.Nz);       // rows of pitch Nxp: whole, 128-B aligned 8-line groups
-    const size_t lds = (size_t)g.Ny * OCN_ZL * sizeof(double2);
+    // rows of pitch Nxp: whole, 128-B aligned groups of lines
     FFT_TRY(hipfftExecD2Z(s->plan_xr2c, s->rrhs, (hipfftDoubleComplex *)s->hc));
-    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->hc, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 0, 1.0,
-                       (long)s->Nxp * g.Ny);
+    launch_strided_line_fft(s->hc, s->ytw, (long)s->Nxp, (long)s->Nxp, (unsigned)g.Nz, g.Ny, s->logn_y, 0, 1.0, (long)s->Nxp * g.Ny);
     double2 *sol = s->hc;
     if (s->kind == 0) {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny * (double)g.Nz);
-        hipLaunchKernelGGL(zline_solve_kernel, dim3((s->Nxh + OCN_ZL - 1) / OCN_ZL, g.Ny), dim3(256), (size_t)g.Nz * OCN_ZL * sizeof(double2),
-                           g_stream, s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale, s->Nxp);
+        launch_zline_solve(s->hc, s->ztw, s->lam[0], s->lam[1], s->lam[2], s->Nxh, g.Ny, g.Nz, s->logn_z, scale, s->Nxp);
     } else {
         const double scale = 1.0 / ((double)g.Nx * (double)g.Ny);
         hipLaunchKernelGGL(tridiagonal_z_kernel, dim3((s->Nxh + 63) / 64, g.Ny), dim3(64), 0, g_stream, s->Nxh, g.Nx, g.Ny, g.Nz,
@@ -1450,8 +1460,7 @@ static int poisson_solve_real_split(ocn_poisson_s *s) {
         hipLaunchKernelGGL(remove_mean_mode_kernel, dim3(1), dim3(256), 0, g_stream, s->hc2, (long)s->Nxp * g.Ny, g.Nz);
         sol = s->hc2;
     }
-    hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, sol, s->ytw, (long)s->Nxp, g.Ny, s->logn_y, 1, 1.0,
-                       (long)s->Nxp * g.Ny);
+    launch_strided_line_fft(sol, s->ytw, (long)s->Nxp, (long)s->Nxp, (unsigned)g.Nz, g.Ny, s->logn_y, 1, 1.0, (long)s->Nxp * g.Ny);
     FFT_TRY(hipfftExecZ2D(s->plan_xc2r, (hipfftDoubleComplex *)sol, s->rrhs));
     KERNEL_CHECK();
     return OCN_OK;
@@ -1753,15 +1762,13 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
                     TRY_OR_FREE(dev_alloc((void **)&ref, pslab * sizeof(double2)));
                     TRY_OR_FREE(dev_alloc((void **)&bm, 256 * sizeof(double)));
                     const long C = (long)s->Nzp * s->Nxl;
-                    const dim3 grd((unsigned)((C + OCN_ZL - 1) / OCN_ZL));
-                    const size_t lds = (size_t)s->Ny * OCN_ZL * sizeof(double2);
                     double err[2] = {-1.0, -1.0};
                     bool ok = true;
                     for (int dir = 0; dir < 2 && ok; ++dir) {      // accept the kernel only if it reproduces the library transform
                         hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((pslab + 255) / 256)), dim3(256), 0, g_stream, s->spec, (long)pslab);
                         ok = hipMemcpyAsync(ref, s->spec, pslab * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
                              hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD) == HIPFFT_SUCCESS;
-                        hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, dir, 1.0);
+                        launch_strided_line_fft(s->spec, s->ytw, C, C, 1, s->Ny, s->logn_y, dir, 1.0);
                         hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->spec,
                                            2 * (long)pslab, bm);
                         ok = ok && reduce_blockmax(bm, 256, &err[dir]) == OCN_OK;
@@ -1867,15 +1874,13 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
             TRY_OR_FREE(dev_alloc((void **)&ref, s->nz_c * sizeof(double2)));
             TRY_OR_FREE(dev_alloc((void **)&bm, 256 * sizeof(double)));
             const long C = (long)s->Nxh * s->Nz;
-            const dim3 grd((unsigned)((C + OCN_ZL - 1) / OCN_ZL));
-            const size_t lds = (size_t)s->Ny * OCN_ZL * sizeof(double2);
             double err[2] = {-1.0, -1.0};
             bool ok = true;
             for (int dir = 0; dir < 2 && ok; ++dir) {
                 hipLaunchKernelGGL(selfcheck_fill_complex, dim3((unsigned)((s->nz_c + 255) / 256)), dim3(256), 0, g_stream, s->zfield, (long)s->nz_c);
                 ok = hipMemcpyAsync(ref, s->zfield, s->nz_c * sizeof(double2), hipMemcpyDeviceToDevice, g_stream) == hipSuccess &&
                      hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)ref, (hipfftDoubleComplex *)ref, dir ? HIPFFT_BACKWARD : HIPFFT_FORWARD) == HIPFFT_SUCCESS;
-                hipLaunchKernelGGL(strided_line_fft_kernel, grd, dim3(256), lds, g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, dir, 1.0);
+                launch_strided_line_fft(s->zfield, s->ytw, C, C, 1, s->Ny, s->logn_y, dir, 1.0);
                 hipLaunchKernelGGL(max_abs_diff_kernel, dim3(256), dim3(256), 0, g_stream, (const double *)ref, (const double *)s->zfield,
                                    2 * (long)s->nz_c, bm);
                 ok = ok && reduce_blockmax(bm, 256, &err[dir]) == OCN_OK;
@@ -1940,8 +1945,7 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
         FFT_TRY(hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec));
         if (s->yline) {
             const long C = (long)s->Nzp * s->Nxl;
-            hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
-                               (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 0, 1.0);
+            launch_strided_line_fft(s->spec, s->ytw, C, C, 1, s->Ny, s->logn_y, 0, 1.0);
         } else if (!s->zf_2d) {
             if ((rc = plan_set_stream(s->plan_y))) return rc;
             FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_FORWARD));
@@ -1978,8 +1982,7 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
         int rcz;
         if (s->yline) {
             const long C = (long)s->Nzp * s->Nxl;
-            hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256),
-                               (size_t)s->Ny * OCN_ZL * sizeof(double2), g_stream, s->spec, s->ytw, C, s->Ny, s->logn_y, 1, 1.0);
+            launch_strided_line_fft(s->spec, s->ytw, C, C, 1, s->Ny, s->logn_y, 1, 1.0);
         } else if (!s->zf_2d) {
             if ((rcz = plan_set_stream(s->plan_y))) return rcz;
             FFT_TRY(hipfftExecZ2Z(s->plan_y, (hipfftDoubleComplex *)s->spec, (hipfftDoubleComplex *)s->spec, HIPFFT_BACKWARD));
@@ -2040,8 +2043,7 @@ extern "C" int ocn_dist_poisson_forward_yz(ocn_dist_poisson_t s) {
     int rc;
     if (s->yline) {
         const long C = (long)s->Nxh * s->Nz;
-        hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256), (size_t)s->Ny * OCN_ZL * sizeof(double2),
-                           g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, 0, 1.0);
+        launch_strided_line_fft(s->zfield, s->ytw, C, C, 1, s->Ny, s->logn_y, 0, 1.0);
     } else {
         if ((rc = plan_set_stream(s->plan_loc))) return rc;
         FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_FORWARD));
@@ -2102,8 +2104,7 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
                        s->Ny, s->Nyh, s->Nyc, s->Nz, s->zmode == 0);
     if (s->yline) {
         const long C = (long)s->Nxh * s->Nz;
-        hipLaunchKernelGGL(strided_line_fft_kernel, dim3((unsigned)((C + OCN_ZL - 1) / OCN_ZL)), dim3(256), (size_t)s->Ny * OCN_ZL * sizeof(double2),
-                           g_stream, s->zfield, s->ytw, C, s->Ny, s->logn_y, 1, 1.0);
+        launch_strided_line_fft(s->zfield, s->ytw, C, C, 1, s->Ny, s->logn_y, 1, 1.0);
     } else {
         if ((rc = plan_set_stream(s->plan_loc))) return rc;
         FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));

@@ -863,7 +863,6 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // pressure: source term, correction, scaling (src/Models/NonhydrostaticModels/{solve_for_pressure,pressure_correction}.jl)
 // ---------------------------------------------------------------------------------------------------------------------
-#define OCN_ZL 8      // lines (rows) of a line-FFT workgroup: 8 complex numbers = one 128-B row
 // the source term of the pressure equation at cell (i, j, k): divᶜᶜᶜ(u*) [x Δzᶜ for the Fourier-tridiagonal solver]
 // (solve_for_pressure.jl:12-84, Operators/divergence_operators.jl:16-19)
 __device__ __forceinline__ double source_value(const DGrid &g, const FView &u, const FView &v, const FView &w, int i, int j, int k,
@@ -1182,19 +1181,20 @@ __global__ void __launch_bounds__(256) line_scatter_kernel(const double2 *B, dou
 // runs in bit-reversed order, inverse = radix-2 decimation in time (bit-reversed -> natural): in place, no reordering pass.
 // tw[m] = exp(-2πi m / Nz), m < Nz/2 (host-computed). `scale` folds the normalisation of the whole 3-D inverse transform.
 // ---------------------------------------------------------------------------------------------------------------------
+template <int ZL>
 __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const double2 *tw, const double *lx, const double *ly,
                                                           const double *lz, int Nxs, int Ny, int Nz, int logn, double scale, int pitch = 0) {
-    extern __shared__ double2 zbuf[];                 // [Nz][OCN_ZL]
-    const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;       // 32 k-rows per pass
-    const int i0 = blockIdx.x * OCN_ZL, j = blockIdx.y;
+    extern __shared__ double2 zbuf[];                 // [Nz][ZL]
+    const int il = threadIdx.x % ZL, kq = threadIdx.x / ZL;       // 32 k-rows per pass
+    const int i0 = blockIdx.x * ZL, j = blockIdx.y;
     const int i = i0 + il;
     const bool live = i < Nxs;
     const int ldx = pitch > 0 ? pitch : Nxs;          // row pitch of the spectrum (>= Nxs: padded to whole 128-B rows on the split path)
     const long plane = (long)ldx * Ny, base = (long)i + (long)ldx * j;
-    for (int k = kq; k < Nz; k += 256 / OCN_ZL) zbuf[k * OCN_ZL + il] = live ? hc[base + plane * k] : make_double2(0.0, 0.0);
+    for (int k = kq; k < Nz; k += 256 / ZL) zbuf[k * ZL + il] = live ? hc[base + plane * k] : make_double2(0.0, 0.0);
     __syncthreads();
-    const int half = Nz >> 1, quarter = Nz >> 2, KQ = 256 / OCN_ZL;
-#define ZB(n) zbuf[(n) * OCN_ZL + il]
+    const int half = Nz >> 1, quarter = Nz >> 2, KQ = 256 / ZL;
+#define ZB(n) zbuf[(n) * ZL + il]
 #define CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)        /* (ar + i ai) * w       */
 #define CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)       /* v * conj(w)           */
     // forward, decimation in frequency (natural -> bit-reversed): spans Nz/2, Nz/4, ..., 1; two radix-2 stages are fused in
@@ -1270,27 +1270,29 @@ __global__ void __launch_bounds__(256) zline_solve_kernel(double2 *hc, const dou
 #undef CMUL
 #undef CMULC
     if (live)
-        for (int k = kq; k < Nz; k += 256 / OCN_ZL) hc[base + plane * k] = zbuf[k * OCN_ZL + il];
+        for (int k = kq; k < Nz; k += 256 / ZL) hc[base + plane * k] = zbuf[k * ZL + il];
 }
 
 // One-directional FFT of length N = 2^logn along the SLOWEST dimension of a (C, N) complex array (element (c, n) at c + C*n): the
 // column transform rocFFT runs with its row kernel when it is planned as a 1-D strided transform (measured 129 us for 67 MB; this
-// kernel: the same LDS machinery as zline_solve_kernel, OCN_ZL consecutive lines = 128-B rows per workgroup).
+// kernel: the same LDS machinery as zline_solve_kernel, ZL consecutive lines per workgroup: 8 = 128-B rows; 4 for lines of 512 and more,
+// whose 64 KB of LDS per 8 lines leave two workgroups per CU -- measured at 512^3: 54.0 -> 51.9 ms/step with 4, 54.1 with 2; at 256^3 8 wins).
 // forward: natural -> radix-4 DIF -> stored through the bit-reversal; inverse: loaded through the bit-reversal -> DIT -> natural,
 // times `scale`. Same arithmetic as rocFFT's to round-off, not bitwise.
+template <int ZL>
 __global__ void __launch_bounds__(256) strided_line_fft_kernel(double2 *data, const double2 *tw, long C, int N, int logn, int inverse,
                                                                double scale, long plane_stride = 0) {
-    extern __shared__ double2 zbuf[];                 // [N][OCN_ZL]
+    extern __shared__ double2 zbuf[];                 // [N][ZL]
     data += plane_stride * blockIdx.y;                // gridDim.y independent (C, N) arrays `plane_stride` elements apart
-    const int il = threadIdx.x % OCN_ZL, kq = threadIdx.x / OCN_ZL;
-    const long c = (long)blockIdx.x * OCN_ZL + il;
+    const int il = threadIdx.x % ZL, kq = threadIdx.x / ZL;
+    const long c = (long)blockIdx.x * ZL + il;
     const bool live = c < C;
-    const int half = N >> 1, quarter = N >> 2, KQ = 256 / OCN_ZL;
-#define ZB(n) zbuf[(n) * OCN_ZL + il]
+    const int half = N >> 1, quarter = N >> 2, KQ = 256 / ZL;
+#define ZB(n) zbuf[(n) * ZL + il]
 #define CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)
 #define CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)
     if (!inverse) {
-        for (int k = kq; k < N; k += KQ) zbuf[k * OCN_ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
+        for (int k = kq; k < N; k += KQ) zbuf[k * ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
         __syncthreads();
         int h = half, st = 1;
         if (logn & 1) {
@@ -1319,10 +1321,10 @@ __global__ void __launch_bounds__(256) strided_line_fft_kernel(double2 *data, co
             __syncthreads();
         }
         if (live)
-            for (int p = kq; p < N; p += KQ) data[c + C * (long)(__brev((unsigned)p) >> (32 - logn))] = zbuf[p * OCN_ZL + il];
+            for (int p = kq; p < N; p += KQ) data[c + C * (long)(__brev((unsigned)p) >> (32 - logn))] = zbuf[p * ZL + il];
     } else {
         for (int k = kq; k < N; k += KQ)
-            zbuf[(int)(__brev((unsigned)k) >> (32 - logn)) * OCN_ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
+            zbuf[(int)(__brev((unsigned)k) >> (32 - logn)) * ZL + il] = live ? data[c + C * k] : make_double2(0.0, 0.0);
         __syncthreads();
         int h = 1, st = half;
         for (; (h << 1) <= half; h <<= 2, st >>= 2) {
@@ -1352,7 +1354,7 @@ __global__ void __launch_bounds__(256) strided_line_fft_kernel(double2 *data, co
         }
         if (live)
             for (int k = kq; k < N; k += KQ) {
-                const double2 v = zbuf[k * OCN_ZL + il];
+                const double2 v = zbuf[k * ZL + il];
                 data[c + C * k] = make_double2(v.x * scale, v.y * scale);
             }
     }
