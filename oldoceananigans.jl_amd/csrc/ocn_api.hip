@@ -898,7 +898,11 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Poisson solvers
 // ---------------------------------------------------------------------------------------------------------------------
-// line-FFT kernels (ocn_kernels.h): lines per workgroup by line length, see strided_line_fft_kernel
+// line-FFT kernels (ocn_kernels.h): lines per workgroup by line length, see strided_line_fft_kernel; the longest line they take: 1024
+// points x 4 lines x 16 B = the 64 KB of LDS a workgroup may ask for
+#ifndef OCN_LINE_MAX
+#define OCN_LINE_MAX 1024
+#endif
 static inline int line_zl(int n) { return n >= 512 ? 4 : 8; }
 static inline void launch_strided_line_fft(double2 *data, const double2 *tw, long C, long ncols, unsigned batches, int N, int logn, int inverse,
                                            double scale, long plane_stride = 0) {
@@ -919,8 +923,8 @@ static inline void launch_zline_solve(double2 *hc, const double2 *tw, const doub
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
-static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 512: z transform + divide + inverse z transform in one pass
-static int g_dist_yline = 1;           // z Bounded: local y transform by strided_line_fft_kernel (Ny = 2^m <= 512) instead of rocFFT's 1-D strided plan
+static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
+static int g_dist_yline = 1;           // z Bounded: local y transform by strided_line_fft_kernel (Ny = 2^m <= 1024) instead of rocFFT's 1-D strided plan
 static int g_dist_zfirst = 1;          // substructured solve on the z-fastest layout (R2C along z); 0: paired-column layout
 
 struct ocn_poisson_s {
@@ -944,7 +948,7 @@ struct ocn_poisson_s {
     hipfftHandle plan_r2c = 0, plan_c2r = 0;
     bool has_r2c = false, has_c2r = false, c2r_strided = false;
     bool zfused = false;         // kind 0: 2-D (x, y) plans + zline_solve_kernel instead of 3-D plans + divide kernel
-    // split form of the 2-D (x, y) transforms for the model's time-step (Ny = 2^m <= 512): 1-D R2C / C2R plans along x and the y
+    // split form of the 2-D (x, y) transforms for the model's time-step (Ny = 2^m <= 1024): 1-D R2C / C2R plans along x and the y
     // pass by strided_line_fft_kernel (61 us against the 82 us of the 2-D plan's column kernel); the inverse lands in the dense
     // real array, which pressure_correction_dense_kernel reads directly
     bool split = false;
@@ -1241,7 +1245,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             TRY_OR_FREE(hipMemset(s->hc2, 0, s->nh * sizeof(double2)));
         }
         const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy, Pz = g.Nz + 2 * g.Hz;
-        if (kind == 0 && g_fused_zfft && g.Nz >= 8 && g.Nz <= 512 && (g.Nz & (g.Nz - 1)) == 0) {
+        if (kind == 0 && g_fused_zfft && g.Nz >= 8 && g.Nz <= OCN_LINE_MAX && (g.Nz & (g.Nz - 1)) == 0) {
             s->zfused = true;
             while ((1 << s->logn_z) < g.Nz) ++s->logn_z;
             std::vector<double2> tw(g.Nz / 2);
@@ -1287,7 +1291,7 @@ extern "C" int ocn_poisson_create(ocn_poisson_t *solver, ocn_grid_t grid, int ki
             *solver = s;
             return OCN_OK;
         }
-        if (g_split_solve && (kind == 1 || s->zfused) && g.Ny >= 8 && g.Ny <= 512 && (g.Ny & (g.Ny - 1)) == 0 && g.tx == OCN_PERIODIC &&
+        if (g_split_solve && (kind == 1 || s->zfused) && g.Ny >= 8 && g.Ny <= OCN_LINE_MAX && (g.Ny & (g.Ny - 1)) == 0 && g.tx == OCN_PERIODIC &&
             g.ty == OCN_PERIODIC) {
             int nx1[1] = {g.Nx};
             int rembx[1] = {g.Nx}, cembx[1] = {s->Nxp};
@@ -1606,7 +1610,7 @@ struct ocn_dist_poisson_s {
     double2 *spec = nullptr;    // (Nzp, Nxl, Ny) complex, modes m = kz + Nzh*ky at [kz + Nzp*(i + Nxl*ky)]
     hipfftHandle plan_zr2c = 0, plan_zc2r = 0;       // 2-D (y, z) D2Z / Z2D, batched over the local x index (zf_2d) ...
     hipfftHandle plan_y = 0;                         // ... or 1-D along z plus this strided 1-D y transform
-    // z Bounded, Ny = 2^m <= 512: the local y transform by strided_line_fft_kernel instead of rocFFT's 1-D strided plan
+    // z Bounded, Ny = 2^m <= 1024: the local y transform by strided_line_fft_kernel instead of rocFFT's 1-D strided plan
     bool yline = false;
     int logn_y = 0;
     double2 *ytw = nullptr;
@@ -1727,9 +1731,9 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
             // column kernel; the same pass as a 1-D strided plan gets the 3x slower row kernel (measured: 280 vs 90 us).
             int nyz[2] = {s->Ny, s->Nz};
             int remb[2] = {s->Ny, s->Nz * s->Nxl}, cemb[2] = {s->Ny, s->Nzp * s->Nxl};
-            // ... unless Ny = 2^m <= 512: then the y pass is strided_line_fft_kernel (3x faster again than the column kernel of the 2-D
+            // ... unless Ny = 2^m <= 1024: then the y pass is strided_line_fft_kernel (3x faster again than the column kernel of the 2-D
             // plan) next to plain 1-D plans along z
-            const bool want_yline = g_dist_yline && s->Ny >= 8 && s->Ny <= 512 && (s->Ny & (s->Ny - 1)) == 0;
+            const bool want_yline = g_dist_yline && s->Ny >= 8 && s->Ny <= OCN_LINE_MAX && (s->Ny & (s->Ny - 1)) == 0;
             hipfftResult rz = want_yline ? HIPFFT_NOT_SUPPORTED
                                          : hipfftPlanMany(&s->plan_zr2c, 2, nyz, remb, 1, s->Nz, cemb, 1, s->Nzp, HIPFFT_D2Z, s->Nxl);
             if (rz == HIPFFT_SUCCESS) {
@@ -1859,7 +1863,7 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         if ((rc = plan_set_stream(s->plan_loc))) goto bad;
         const double sc = zmode == 0 ? 1.0 / ((double)s->Ny * s->Nz) : 1.0 / (double)s->Ny;
         if ((rc = verify_complex_plan(s->plan_loc, s->zfield, (long)s->nz_c, sc, "distributed local (y, z)"))) goto bad;
-        if (zmode == 1 && g_dist_yline && s->Ny >= 8 && s->Ny <= 512 && (s->Ny & (s->Ny - 1)) == 0) {
+        if (zmode == 1 && g_dist_yline && s->Ny >= 8 && s->Ny <= OCN_LINE_MAX && (s->Ny & (s->Ny - 1)) == 0) {
             while ((1 << s->logn_y) < s->Ny) ++s->logn_y;
             std::vector<double2> tw(s->Ny / 2);
             for (int m = 0; m < s->Ny / 2; ++m) {

@@ -107,7 +107,7 @@ def test_poisson_fft_solver_residual(ocn, oracle, arch):
         assert rel_err(c, p_cpu[3:-3, 3:-3, 3:-3]) < 1e-12
 
 
-@pytest.mark.parametrize("size", [(8, 8, 8), (16, 16, 16), (12, 10, 32), (4, 6, 64), (6, 5, 128), (4, 4, 512), (10, 6, 7), (8, 8, 1024)])
+@pytest.mark.parametrize("size", [(8, 8, 8), (16, 16, 16), (12, 10, 32), (4, 6, 64), (6, 5, 128), (4, 4, 512), (10, 6, 7), (8, 8, 1024), (8, 1024, 8), (16, 512, 4)])
 def test_solve_for_pressure_real_transform_path(ocn, oracle, arch, size):
     """solve_for_pressure! as the model runs it (real-to-complex transforms; for Nz = 2^m in 8..512 the z transform, the spectral
     divide and the inverse z transform are one fused pass, zline_solve_kernel -- even and odd m; other Nz: rocFFT 3-D plans)
