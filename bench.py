@@ -222,7 +222,7 @@ def main():
             ocn.set_model(model, **dist.local_initial_state(model, initial_state))
         barrier = ctx.barrier
     else:
-        arch = ocn.GPU(local_rank)
+        arch = ocn.GPU(local_rank % max(1, ocn.ndevices()))
         physics = {}
         if args.workload in ("ppb_stretched", "ppb_physics", "ppb_amd"):
             from helpers import tanh_faces

@@ -52,6 +52,7 @@ typedef struct ocn_dist_s *ocn_dist_t;
 
 /* ---------------------------------------------------------------- runtime (src/Architectures.jl:35-123) ---------- */
 int ocn_init(int device_id);                                  /* device!(arch, id) */
+int ocn_device_count(int *count);                             /* ndevices(arch) (Architectures.jl; distributed_architectures.jl:284-288 assigns node_rank % ndevices) */
 int ocn_sync(void);                                           /* sync_device! */
 const char *ocn_last_error(void);
 const char *ocn_version(void);

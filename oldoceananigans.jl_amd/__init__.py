@@ -6,7 +6,7 @@ from . import _lib
 from ._lib import OcnError, build
 from .advection import (Centered, FluxFormAdvection, UpwindBiased, WENO, adapt_advection_order, inflate_halo_size,
                         required_halo_size_x, required_halo_size_y, required_halo_size_z)
-from .architectures import GPU, architecture, own_stream, set_option, synchronize
+from .architectures import GPU, architecture, ndevices, own_stream, set_option, synchronize
 from .boundary_conditions import (BoundaryCondition, FieldBoundaryConditions, FluxBoundaryCondition,
                                   GradientBoundaryCondition, LinearFieldFlux, OpenBoundaryCondition, ValueBoundaryCondition, compute_flux_bcs)
 from .buoyancy import BuoyancyTracer, FPlane, LinearEquationOfState, SeawaterBuoyancy

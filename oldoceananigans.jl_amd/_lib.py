@@ -68,6 +68,7 @@ SYMBOLS = {
     "ocn_dist_model_create_pencil": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int]),
     "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
     "ocn_init": (C.c_int, [C.c_int]),
+    "ocn_device_count": (C.c_int, [_ip]),
     "ocn_sync": (C.c_int, []),
     "ocn_last_error": (C.c_char_p, []),
     "ocn_version": (C.c_char_p, []),

@@ -17,6 +17,14 @@ class GPU:
         return f"GPU{{MI355XNative}}(device={self.device_id})"
 
 
+def ndevices():
+    """ndevices(arch): HIP devices visible to this process"""
+    import ctypes as C
+    n = C.c_int()
+    _lib.check(_lib.lib().ocn_device_count(C.byref(n)))
+    return n.value
+
+
 def architecture(obj):
     return obj.architecture
 

@@ -65,6 +65,12 @@ static hipError_t dev_alloc(void **p, size_t bytes) {
 extern "C" const char *ocn_last_error(void) { return g_err; }
 extern "C" const char *ocn_version(void) { return "ocn_mi355x 0.1 (gfx950; reference Oceananigans v0.100.5)"; }
 
+extern "C" int ocn_device_count(int *count) {
+    if (!count) return fail(OCN_EINVAL, "NULL argument");
+    HIP_TRY(hipGetDeviceCount(count));
+    return OCN_OK;
+}
+
 extern "C" int ocn_init(int device_id) {
     int count = 0;
     HIP_TRY(hipGetDeviceCount(&count));

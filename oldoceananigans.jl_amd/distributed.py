@@ -913,7 +913,8 @@ class Distributed:
     @classmethod
     def rccl(cls, arch, unique_id, world, rank, self_loop=False):
         h = C.c_void_p()
-        _lib.check(_lib.lib().ocn_dist_create(C.byref(h), unique_id, int(world), int(rank)))
+        with _stdout_to_stderr():        # RCCL prints a version / host banner on stdout when it initialises
+            _lib.check(_lib.lib().ocn_dist_create(C.byref(h), unique_id, int(world), int(rank)))
         if self_loop:
             _lib.check(_lib.lib().ocn_dist_set_self_loop(h, 1))
         return cls(h, rank, world, arch, self_loop)
@@ -927,10 +928,14 @@ class Distributed:
         rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
         if local_rank is None:
             local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        arch = GPU(local_rank)
+        # device!(child_architecture, node_rank % ndevices(child_architecture)) (distributed_architectures.jl:284-288): also right when the
+        # launcher shows every process one card only
+        from .architectures import ndevices
+        arch = GPU(local_rank % max(1, ndevices()))
         uid = C.create_string_buffer(128)
         if rank == 0:
-            _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+            with _stdout_to_stderr():
+                _lib.check(_lib.lib().ocn_dist_unique_id(uid))
         if world > 1:
             uid = C.create_string_buffer(_broadcast_bytes(uid.raw if rank == 0 else None, rank, world), 128)
         return cls.rccl(arch, uid, world, rank, self_loop)
@@ -973,6 +978,24 @@ class Distributed:
 
 
 _BOOT_MAGIC = b"OCN-RCCL-ID-1"
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """file descriptor 1 points at stderr inside the block: what a C library prints on stdout (RCCL's start-up banner) must not land in
+    the one-JSON-line output of bench.py"""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def _broadcast_bytes(payload, rank, world, timeout=120.0):
