@@ -166,6 +166,43 @@ def test_fused_substep_equals_separate_kernels_at_config2(ocn, big_ppb):
         assert np.array_equal(results[0][n], results[1][n]), n
 
 
+def test_config4_physics_at_config2_size(ocn, arch):
+    """the physics of BASELINE.json configs[4] (AnisotropicMinimumDissipation, linear SeawaterBuoyancy with the hydrostatic pressure
+    anomaly, wind-stress / heat-flux / bottom-gradient conditions, the S-dependent evaporation flux) at 256 x 256 x 128 stretched:
+    size-independent properties -- the one-pass epilogue + fused substep leave the same bits as the stand-alone kernels + rk3_substep!,
+    max|div u| < 5e-8 (test_time_stepping.jl:124-160), the eddy diffusivities are non-negative and finite and not all zero
+    (anisotropic_minimum_dissipation.jl:199-357: max(0, .)), and the heat budget closes to the surface flux up to the diffusive flux the
+    bottom Gradient condition lets through (kappa_e dT/dz there: bounded by max kappa_e * 0.01)"""
+    from helpers import tanh_faces
+    sys_path_bench = __import__("importlib").import_module("bench")
+    size = (N, N, N // 2)
+    z = tanh_faces(size[2])
+    outs, budget = [], None
+    for fused in (1, 0):
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), **sys_path_bench.workload_physics(ocn, "ppb_amd"))
+        model.set_option("fused_epilogue", fused)
+        model.set_option("fuse_substep", fused)
+        ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=1234))
+        dz = np.diff(z)[None, None, :]
+        T0 = (model.fields()["T"].interior() * dz).sum()
+        dt = 0.05 * grid.Δxᶜᵃᵃ / 0.6
+        for _ in range(2):
+            ocn.time_step(model, dt)
+        assert ocn.max_abs_divergence(model) < 5e-8
+        if fused:
+            T1 = (model.fields()["T"].interior() * dz).sum()
+            D = model.diffusivity_fields
+            nu, kT = D[0].interior(), D[1][0].interior()
+            assert np.isfinite(nu).all() and np.isfinite(kT).all() and nu.min() >= 0 and kT.min() >= 0 and nu.max() > 0 and kT.max() > 0
+            budget = ((T1 - T0) / (size[0] * size[1]), -5e-5 * model.clock.time, float(kT.max()) * 0.01 * model.clock.time)
+        outs.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent()})
+        model.close()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
+    assert abs(budget[0] - budget[1]) <= budget[2] + 1e-12, budget
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # BASELINE.json configs[3] / configs[4]: the LOCAL shape of one of 8 x-slabs, run through the partitioned code path by a one-rank
 # RCCL communicator that is its own neighbour (ocn_dist_set_self_loop) -- against the single-GPU model on the same periodic slab
