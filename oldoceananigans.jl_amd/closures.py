@@ -14,7 +14,7 @@ class ScalarDiffusivity:
         κ = κ if kappa is None else kappa
         if callable(ν) or callable(κ) or (isinstance(κ, dict) and any(callable(x) for x in κ.values())):
             raise NotImplementedError("only constant (Number) viscosity / diffusivity is on the accelerated path")
-        self.ν, self.κ = float(ν), κ
+        self.ν, self.κ = float(ν), ({n: float(v) for n, v in κ.items()} if isinstance(κ, dict) else float(κ))   # convert_diffusivity(FT, κ)
         if self.ν < 0:
             raise ValueError("viscosity must be non-negative")
 
@@ -50,6 +50,7 @@ class AnisotropicMinimumDissipation:
         if callable(self.Cν) or callable(self.Cκ) or (isinstance(self.Cκ, dict) and any(callable(x) for x in self.Cκ.values())):
             raise NotImplementedError("only constant (Number) Poincaré coefficients are on the accelerated path")
         self.Cν = float(self.Cν)
+        self.Cb = None
 
     def Ckappa_array(self, tracer_names):
         import ctypes
