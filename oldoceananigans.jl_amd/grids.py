@@ -57,6 +57,68 @@ def _regular_coordinate(interval, N, name):
     return float(L / N), float(L), float(c1)
 
 
+def _add12(x, y):
+    """Base.add12 (twiceprecision.jl): x + y as an unevaluated sum hi + lo"""
+    if abs(y) > abs(x):
+        x, y = y, x
+    hi = x + y
+    return hi, y - (hi - x)
+
+
+def _truncbits(x, nb):
+    import struct
+    b = struct.unpack("<Q", struct.pack("<d", x))[0] & ((0xFFFFFFFFFFFFFFFF << nb) & 0xFFFFFFFFFFFFFFFF)
+    return struct.unpack("<d", struct.pack("<Q", b))[0]
+
+
+def julia_range(start, stop, length):
+    """`range(start, stop, length = length)` for Float64 end points as Julia evaluates it (base/twiceprecision.jl, `_linspace`: a
+    StepRangeLen with twice-precision reference and step; the reference element is the one of smallest magnitude): every element,
+    correctly rounded like `r[i]`. The grids take their node coordinates from such ranges (grid_generation.jl:118-119), so a node is not
+    `c₁ + (i - 1) Δ` in floating point -- e.g. the first x face of `RectilinearGrid(size=(32, 32), extent=(2π, 4π), ...)` is 3.60072e-17
+    (rectilinear_grid.jl:194, reproduced by tests/test_reference_kats.py)."""
+    import math
+    if length == 1:
+        return np.array([start], dtype=np.float64)
+    d = stop - start
+    imin = int(round(-(start / d) * (length - 1) + 1)) if d != 0 else 1        # round half to even, like round(Int, x)
+    if 1 < imin < length:
+        t = (imin - 1) / (length - 1)
+        ref = (1 - t) * start + t * stop
+        step = (ref - start) / (imin - 1) if imin - 1 < length - imin else (stop - ref) / (length - imin)
+    elif imin <= 1:
+        imin, ref, step = 1, start, d / (length - 1)
+    else:
+        imin, ref, step = length, stop, d / (length - 1)
+    nb = min(27, math.ceil(math.log2(max(imin - 1, length - imin))))            # nbitslen(Float64, len, offset)
+    step_hi = _truncbits(step, nb)
+    x1_hi, x1_lo = _add12((1 - imin) * step_hi, ref)
+    x2_hi, x2_lo = _add12((length - imin) * step_hi, ref)
+    a, b = (start - x1_hi) - x1_lo, (stop - x2_hi) - x2_lo
+    step_lo = (b - a) / (length - 1)
+    ref_lo = a - (1 - imin) * step_lo
+    out = np.empty(length, dtype=np.float64)
+    for i in range(1, length + 1):
+        u = i - imin
+        x_hi, x_lo = _add12(ref, u * step_hi)
+        out[i - 1] = x_hi + (x_lo + (u * step_lo + ref_lo))
+    return out
+
+
+def _regular_nodes(interval, N, H, topology):
+    """the face and centre coordinates of generate_coordinate (grid_generation.jl:104-125), halos included: index H = node 1"""
+    c1, c2 = Fraction(float(interval[0])), Fraction(float(interval[1]))
+    L = c2 - c1
+    D = L / N
+    bounded = topology in (Bounded, LeftConnected)
+    Fm = c1 - H * D
+    Fp = Fm + (L + 2 * H * D if bounded else L + (2 * H - 1) * D)               # total_extent (grid_utils.jl:120-121)
+    Cm = Fm + D / 2
+    Cp = Cm + L + D * (2 * H - 1)
+    TF, TC = N + 2 * H + (1 if bounded else 0), N + 2 * H                        # total_length (grid_utils.jl:63-65)
+    return julia_range(float(Fm), float(Fp), TF), julia_range(float(Cm), float(Cp), TC)
+
+
 def _stretched_coordinate(faces, N, H, bounded, name):
     """generate_coordinate for an explicit face vector / function (grid_generation.jl:34-95).
     Returns L, faces-with-halo, Δᶜ and Δᶠ as arrays indexed by position k-1+H for k = 1-H .. N+H+1 (entries the
@@ -200,8 +262,13 @@ class RectilinearGrid:
             m = n + (1 if (l is Face and t in (Bounded, LeftConnected)) else 0)
             if d == 2 and not self.z_regular:
                 arr = self.zᵃᵃᶠ[self.Hz:self.Hz + m] if l is Face else self.zᵃᵃᶜ[self.Hz:self.Hz + m]
+            elif t is Flat:
+                arr = np.full(m, origin)
             else:
-                arr = origin + delta * (np.arange(m) + (0.0 if l is Face else 0.5))
+                H = self.halo_size[d]
+                interval = (self.x0, self.x0 + self.Lx) if d == 0 else ((self.y0, self.y0 + self.Ly) if d == 1 else (self.z0, self.z0 + self.Lz))
+                F, Cn = _regular_nodes(interval, n, H, t)
+                arr = (F if l is Face else Cn)[H:H + m]
             shape = [1, 1, 1]
             shape[d] = m
             out.append(np.asarray(arr, dtype=np.float64).reshape(shape))

@@ -403,3 +403,34 @@ def test_closure_and_buoyancy_docstring_defaults(ocn_host):
     b = ocn.SeawaterBuoyancy()
     assert b.gravitational_acceleration == 9.80665
     assert (b.equation_of_state.thermal_expansion, b.equation_of_state.haline_contraction) == (1.67e-4, 7.80e-4)
+
+
+def test_node_coordinates_are_julia_ranges(ocn_host):
+    """grid_generation.jl:104-125: face and centre coordinates are `range(FT(F₋), FT(F₊), length = TF)` with F₋ = c₁ - H Δ evaluated in
+    BigFloat -- Julia's twice-precision StepRangeLen, not c₁ + (i - 1) Δ. The reference's grid summaries print the first face, which
+    pins the restatement (oldoceananigans.jl_amd/grids.py: julia_range): rectilinear_grid.jl:193-195 (halo 3) and docs/src/grids.md:311-313
+    (halo 7)."""
+    ocn = ocn_host
+    PPF = (ocn.Periodic, ocn.Periodic, ocn.Flat)
+    g = ocn.RectilinearGrid(None, size=(32, 32), extent=(2 * np.pi, 4 * np.pi), topology=PPF)
+    x, y, _ = g.nodes((ocn.Face, ocn.Face, ocn.Center))
+    assert (f"{x.ravel()[0]:.6g}", f"{y.ravel()[0]:.6g}") == ("3.60072e-17", "7.20145e-17")
+    g = ocn.RectilinearGrid(None, size=(32, 16), halo=(7, 7), x=(0, 2 * np.pi), y=(0, np.pi), topology=PPF)
+    x, y, _ = g.nodes((ocn.Face, ocn.Face, ocn.Center))
+    assert (f"{x.ravel()[0]:.6g}", f"{y.ravel()[0]:.6g}") == ("-6.90805e-17", "-1.07194e-16")
+    assert _six(g.Δxᶜᵃᵃ) == 0.19635 and _six(g.Δyᵃᶜᵃ) == 0.19635 and g.halo_size == (7, 7, 0)
+    # exactly representable spacings give exact nodes: docs/src/grids.md:26-36 (16 x 8 x 4 on 64 x 32 x 8: Δ = 4, 4, 2)
+    g = ocn.RectilinearGrid(None, size=(16, 8, 4), x=(0, 64), y=(0, 32), z=(0, 8), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    xc, yc, zf = g.nodes((ocn.Center, ocn.Center, ocn.Face))
+    assert np.array_equal(xc.ravel(), 2.0 + 4.0 * np.arange(16)) and np.array_equal(yc.ravel(), 2.0 + 4.0 * np.arange(8))
+    assert np.array_equal(zf.ravel(), [0.0, 2.0, 4.0, 6.0, 8.0]) and (g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, g.Δzᵃᵃᶜ[3]) == (4.0, 4.0, 2.0)
+    # docs/src/grids.md:54-66: z faces [0, 1, 3, 6, 10] on (Periodic, Flat, Bounded): min(Δz) = 1.0, max(Δz) = 4.0, "10×1×4 ... 3×0×3 halo"
+    g = ocn.RectilinearGrid(None, size=(10, 4), x=(0, 20), z=[0, 1, 3, 6, 10], topology=(ocn.Periodic, ocn.Flat, ocn.Bounded))
+    dz = np.asarray(g.Δzᵃᵃᶜ[3:7])
+    assert g.size == (10, 1, 4) and g.halo_size == (3, 0, 3) and (dz.min(), dz.max(), g.Δxᶜᵃᵃ) == (1.0, 4.0, 2.0)
+    # docs/src/grids.md:342-366: Chebychev-spaced z faces, Nz = 32, Lz = 1e3: min(Δz)=2.40764, max(Δz)=49.0086, z ∈ [-1000.0, -0.0]
+    Nz, Lz = 32, 1e3
+    g = ocn.RectilinearGrid(None, size=(64, 64, Nz), x=(0, 1e4), y=(0, 1e4), z=lambda k: -Lz * (1 + np.cos(np.pi * (k - 1) / Nz)) / 2,
+                            topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    dz = np.asarray(g.Δzᵃᵃᶜ[3:3 + Nz])
+    assert (_six(dz.min()), _six(dz.max()), g.Δxᶜᵃᵃ) == (2.40764, 49.0086, 156.25) and g.zᵃᵃᶠ[3] == -1000.0
