@@ -484,3 +484,38 @@ def test_internal_wave_dynamics(ocn, arch, ykind, stretched):
     got = uf.interior()
     assert np.mean((got - exact) ** 2) / np.mean(exact ** 2) < 1e-4
     assert np.mean((got - u(x, y, zz, 0.0)) ** 2) / np.mean(exact ** 2) > 1e-4          # the wave did propagate
+
+
+def test_fields_md_doctests_on_the_device(ocn, arch):
+    """docs/src/fields.md (jldoctests `fields`, :18-520): the numbers the reference prints for a 4 x 5 x 4 grid with halo (1, 1, 1) and
+    z = [0, 0.1, 0.3, 0.6, 1] -- parent shape 6 x 7 x 6, set! with a number and with a function at Center and Face locations, the
+    halo'd slice before and after fill_halo_regions!, parent vs offset indexing -- reproduced by the HIP path (fields and fills on a
+    one-cell halo: device arrays, device fills)"""
+    grid = ocn.RectilinearGrid(arch, size=(4, 5, 4), halo=(1, 1, 1), x=(0, 1), y=(0, 1), z=[0, 0.1, 0.3, 0.6, 1],
+                               topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    c = ocn.CenterField(grid)
+    assert c.parent().shape == (6, 7, 6) and not c.parent().any()                    # "data: 6×7×6 OffsetArray(...)", full of 0's
+    c.set(42)
+    p = c.parent()
+    assert p[1, 1, 1] == 42.0 and np.all(p[1:5, 1:6, 1] == 42.0) and (p.max(), c.interior().min(), c.interior().mean()) == (42.0, 42.0, 42.0)
+    c.set(lambda x, y, z: 2 * x + 0 * (y + z))                                       # fun_stuff(x, y, z) = 2x
+    a = c.interior()
+    assert (a.max(), a.min(), a.mean()) == (1.75, 0.25, 1.0)                         # "max=1.75, min=0.25, mean=1.0"
+    assert list(a[:, 0, 0]) == [0.25, 0.75, 1.25, 1.75]                             # c[1:4, 1, 1]
+    u = ocn.XFaceField(grid)
+    u.set(lambda x, y, z: 2 * x + 0 * (y + z))
+    assert list(u.interior()[:, 0, 0]) == [0.0, 0.5, 1.0, 1.5]                       # u[1:4, 1, 1]
+    before = np.zeros((6, 7))
+    before[1:5, 1:6] = np.array([0.25, 0.75, 1.25, 1.75])[:, None]
+    assert np.array_equal(c.parent()[:, :, 1], before)                               # c[:, :, 1]: "set! doesn't touch halo cells"
+    ocn.fill_halo_regions(c)
+    after = np.array([1.75, 0.25, 0.75, 1.25, 1.75, 0.25])[:, None] * np.ones((1, 7))
+    assert np.array_equal(c.parent()[:, :, 1], after)                                # c[:, :, 1] after fill_halo_regions!(c)
+    assert np.array_equal(c.parent()[:, :, 0], after) and np.array_equal(c.parent()[:, :, 5], after)    # no-flux bottom / top: ∂z c = 0 on the walls
+    assert list(c.parent()[0:2, 1, 1]) == [1.75, 0.25] and list(c.parent()[1:3, 1, 1]) == [0.25, 0.75]  # parent(c)[1:2, 2, 2], c.data[1:2, 1, 1]
+    # one-dimensional grid: size 7 on (0, 7), (Periodic, Flat, Flat): data 13 x 1 x 1, set!(c, x -> 3x): max=19.5, min=1.5, mean=10.5
+    g1 = ocn.RectilinearGrid(arch, size=7, x=(0, 7), topology=(ocn.Periodic, ocn.Flat, ocn.Flat))
+    c1 = ocn.CenterField(g1)
+    c1.set(lambda x, y, z: 3 * x + 0 * (y + z))
+    b = c1.interior()
+    assert c1.parent().shape == (13, 1, 1) and g1.halo_size == (3, 0, 0) and (b.max(), b.min(), b.mean()) == (19.5, 1.5, 10.5)

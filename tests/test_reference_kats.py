@@ -434,3 +434,23 @@ def test_node_coordinates_are_julia_ranges(ocn_host):
                             topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
     dz = np.asarray(g.Δzᵃᵃᶜ[3:3 + Nz])
     assert (_six(dz.min()), _six(dz.max()), g.Δxᶜᵃᵃ) == (2.40764, 49.0086, 156.25) and g.zᵃᵃᶠ[3] == -1000.0
+
+
+def test_stretched_coordinate_full_precision_docstring_numbers(ocn_host, oracle):
+    """docs/src/fields.md:18-99 (jldoctests): size (4, 5, 4), halo (1, 1, 1), z = [0, 0.1, 0.3, 0.6, 1] -- the reference prints
+    zspacings at Center and Face and the halo'd znodes with all 17 digits: the stretched-coordinate generation
+    (grid_generation.jl:34-95) is pinned bit for bit, in the host mirror and in the oracle's twin (the metric tables of every kernel)"""
+    ocn = ocn_host
+    dzc = [0.1, 0.19999999999999998, 0.3, 0.4]
+    dzf = [0.1, 0.15000000000000002, 0.24999999999999994, 0.3500000000000001, 0.3999999999999999]
+    zc = [-0.05, 0.05, 0.2, 0.44999999999999996, 0.8, 1.2]
+    faces = [0, 0.1, 0.3, 0.6, 1]
+    g = ocn.RectilinearGrid(None, size=(4, 5, 4), halo=(1, 1, 1), x=(0, 1), y=(0, 1), z=faces, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    assert [float(v) for v in g.Δzᵃᵃᶜ[1:5]] == dzc and [float(v) for v in g.Δzᵃᵃᶠ[1:6]] == dzf and [float(v) for v in g.zᵃᵃᶜ[0:6]] == zc
+    assert (g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ) == (0.25, 0.2) and [float(v) for v in g.nodes((ocn.Center, ocn.Center, ocn.Center))[2].ravel()] == zc[1:5]
+    assert [float(v) for v in g.nodes((ocn.Center, ocn.Center, ocn.Face))[2].ravel()] == [0.0, 0.1, 0.3, 0.6, 1.0]       # znodes(w), fields.md:183
+    # xnodes(c) = [0.125, 0.375, 0.625, 0.875], xnodes(u) = [0.0, 0.25, 0.5, 0.75] (fields.md:163-164)
+    assert [float(v) for v in g.nodes((ocn.Center, ocn.Center, ocn.Center))[0].ravel()] == [0.125, 0.375, 0.625, 0.875]
+    assert [float(v) for v in g.nodes((ocn.Face, ocn.Center, ocn.Center))[0].ravel()] == [0.0, 0.25, 0.5, 0.75]
+    go = oracle.Grid((4, 5, 4), topology=(0, 0, 1), x=(0.0, 1.0), y=(0.0, 1.0), z=np.array(faces, dtype=float), halo=(1, 1, 1))
+    assert [float(v) for v in go.dc[2][1:5]] == dzc and [float(v) for v in go.df[2][1:6]] == dzf
