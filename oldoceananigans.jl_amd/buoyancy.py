@@ -34,6 +34,34 @@ class SeawaterBuoyancy:
                 f"β={e.haline_contraction}))")
 
 
+def sind(x):
+    """sin of an angle in degrees as Julia's `sind` returns it: exact at multiples of 30 and 45 degrees, correctly rounded elsewhere
+    (math.sin(math.radians(45)) is one ulp below sind(45) = 0.7071067811865476)"""
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+    getcontext().prec = 60
+    r = Fraction(float(x)) % 360
+    sign = 1
+    if r >= 180:
+        r, sign = r - 180, -1
+    if r > 90:
+        r = 180 - r
+    if r == 0:
+        return 0.0 * sign
+    if r == 90:
+        return 1.0 * sign
+    if r == 30:
+        return 0.5 * sign
+    pi = Decimal("3.14159265358979323846264338327950288419716939937510582097494459")
+    t = Decimal(r.numerator) / Decimal(r.denominator) * pi / 180
+    term, total, n = t, t, 1
+    while abs(term) > Decimal(10) ** -55:
+        term = -term * t * t / ((2 * n) * (2 * n + 1))
+        total += term
+        n += 1
+    return float(total) * sign
+
+
 class FPlane:
     """FPlane(f = ...) | FPlane(rotation_rate = Ω, latitude = φ): f = 2 Ω sind(φ) (Coriolis/f_plane.jl:13-44)"""
 
@@ -41,7 +69,7 @@ class FPlane:
         import math
         if (f is None) == (latitude is None):
             raise ValueError("Either both keywords rotation_rate and latitude must be specified, *or* only f must be specified.")
-        self.f = float(f) if f is not None else 2 * rotation_rate * math.sin(math.radians(latitude))
+        self.f = float(f) if f is not None else 2 * rotation_rate * sind(latitude)      # f_plane.jl:38: 2rotation_rate * sind(latitude)
 
     def __repr__(self):
         return f"FPlane(f={self.f})"
