@@ -18,7 +18,7 @@ from .grids import (Bounded, Center, Face, Flat, FullyConnected, LeftConnected, 
 from .models import NonhydrostaticModel, max_abs_divergence, set_model, time_step, update_state
 from .solvers import (FFTBasedPoissonSolver, FourierTridiagonalPoissonSolver, batched_tridiagonal_solve_z, solve,
                       solve_for_pressure)
-from .simulations import (Callback, IterationInterval, NaNChecker, Simulation, TimeInterval, TimeStepWizard, cell_advection_timescale,
+from .simulations import (CFL, AdvectiveCFL, DiffusiveCFL, Callback, IterationInterval, NaNChecker, Simulation, TimeInterval, TimeStepWizard, cell_advection_timescale,
                           cell_diffusion_timescale, default_nan_checker, hasnan, new_time_step, reset, run, stop_iteration_exceeded,
                           stop_time_exceeded, wall_time_limit_exceeded)
 from . import kernels

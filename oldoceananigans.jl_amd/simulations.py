@@ -53,6 +53,28 @@ def cell_diffusion_timescale(model):
         return float(min(np.float64(delta ** 2) / np.float64(closure.ν), np.float64(delta ** 2) / np.float64(max_k)))
 
 
+class CFL:
+    """CFL(Δt [, timescale = cell_advection_timescale]) (Diagnostics/cfl.jl:3-25): `cfl(model) = Δt / timescale(model)`; Δt a number or a
+    TimeStepWizard-like object with a `Δt` (here: a Simulation)"""
+
+    def __init__(self, Δt, timescale=cell_advection_timescale):
+        self.Δt, self.timescale = Δt, timescale
+
+    def __call__(self, model):
+        dt = self.Δt.Δt if hasattr(self.Δt, "Δt") else self.Δt
+        return dt / self.timescale(model)
+
+
+def AdvectiveCFL(Δt):
+    """AdvectiveCFL(Δt) = CFL(Δt, cell_advection_timescale) (cfl.jl:27-50)"""
+    return CFL(Δt, cell_advection_timescale)
+
+
+def DiffusiveCFL(Δt):
+    """DiffusiveCFL(Δt) = CFL(Δt, cell_diffusion_timescale) (cfl.jl:52-79)"""
+    return CFL(Δt, cell_diffusion_timescale)
+
+
 class TimeStepWizard:
     """TimeStepWizard(cfl = 0.2, diffusive_cfl = Inf, max_change = 1.1, min_change = 0.5, max_Δt = Inf, min_Δt = 0)"""
 

@@ -519,3 +519,25 @@ def test_fields_md_doctests_on_the_device(ocn, arch):
     c1.set(lambda x, y, z: 3 * x + 0 * (y + z))
     b = c1.interior()
     assert c1.parent().shape == (13, 1, 1) and g1.halo_size == (3, 0, 0) and (b.max(), b.min(), b.mean()) == (19.5, 1.5, 10.5)
+
+
+def test_cfl_docstring_examples(ocn, arch):
+    """Diagnostics/cfl.jl:35-48: 16^3 on an 8^3 box, u .= π, AdvectiveCFL(Δt = 1)(model) = 6.283185307179586; :65-77: 16^3 on the unit
+    cube, ScalarDiffusivity(ν = 1e-2), DiffusiveCFL(Δt = 0.1)(model) = 0.256 -- the reference's printed values (the advection time scale
+    is the device reduction ocn_model_cell_advection_timescale)"""
+    PPB = (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+    model = ocn.NonhydrostaticModel(grid=ocn.RectilinearGrid(arch, size=(16, 16, 16), extent=(8, 8, 8), topology=PPB), tracers=())
+    u = model.fields()["u"]
+    u.set_parent(np.full(u.shape, np.pi))                     # model.velocities.u .= π (the whole array, like the broadcast)
+    assert ocn.AdvectiveCFL(1.0)(model) == 6.283185307179586
+    model = ocn.NonhydrostaticModel(grid=ocn.RectilinearGrid(arch, size=(16, 16, 16), extent=(1, 1, 1), topology=PPB), tracers=(),
+                                    closure=ocn.ScalarDiffusivity(ν=1e-2))
+    assert float(f"{ocn.DiffusiveCFL(0.1)(model):.15g}") == 0.256
+
+
+def test_default_halo_of_small_grids(ocn, arch):
+    """AbstractOperations/grid_metrics.jl:60-62,109-113 (jldoctests): `RectilinearGrid(size=(2, 2, 3), extent=(1, 2, 3))` prints
+    "with 2×2×3 halo", size (2, 4, 8) "with 2×3×3 halo": the default halo is min(3, size) per direction"""
+    PPB = (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+    assert ocn.RectilinearGrid(arch, size=(2, 2, 3), extent=(1, 2, 3), topology=PPB).halo_size == (2, 2, 3)
+    assert ocn.RectilinearGrid(arch, size=(2, 4, 8), extent=(1, 1, 1), topology=PPB).halo_size == (2, 3, 3)
