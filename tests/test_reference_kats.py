@@ -464,3 +464,15 @@ def test_coriolis_docstring_numbers(ocn_host):
     assert ocn.FPlane(f=1e-4).f == 0.0001
     assert _six(ocn.FPlane(rotation_rate=7.292115e-5, latitude=45).f) == 0.000103126
     assert sind(45) == 0.7071067811865476 == 2 ** 0.5 / 2 and sind(30) == 0.5 and sind(90) == 1.0 and sind(-90) == -1.0 and sind(180) == 0.0
+
+
+def test_field_parent_sizes_of_the_field_docstrings(ocn_host):
+    """Fields/field.jl:141-148: size (2, 3, 4) -> default halo 2 x 3 x 3, a Field{Face, Face, Center} holds 6 x 9 x 10 values (indices
+    -1:4, -2:6, -2:7); docs/src/fields.md: halo (1, 1, 1) on 4 x 5 x 4 -> 6 x 7 x 6; w on a Bounded z has Nz + 1 faces (grid_utils.jl:63-65)"""
+    ocn = ocn_host
+    PPB = (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+    g = ocn.RectilinearGrid(None, size=(2, 3, 4), extent=(1, 1, 1), topology=PPB)
+    assert g.halo_size == (2, 3, 3) and g.total_size((ocn.Face, ocn.Face, ocn.Center)) == (6, 9, 10)
+    assert g.total_size((ocn.Center, ocn.Center, ocn.Face)) == (6, 9, 11) and g.interior_size((ocn.Center, ocn.Center, ocn.Face)) == (2, 3, 5)
+    g = ocn.RectilinearGrid(None, size=(4, 5, 4), halo=(1, 1, 1), x=(0, 1), y=(0, 1), z=[0, 0.1, 0.3, 0.6, 1], topology=PPB)
+    assert g.total_size((ocn.Center,) * 3) == (6, 7, 6)
