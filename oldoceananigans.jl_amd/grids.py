@@ -206,6 +206,9 @@ class RectilinearGrid:
         self.Δxᶜᵃᵃ, self.Lx, self.x0 = _regular_coordinate(x, self.Nx, "x")
         self.Δyᵃᶜᵃ, self.Ly, self.y0 = _regular_coordinate(y, self.Ny, "y")
         self.Δxᶠᵃᵃ, self.Δyᵃᶠᵃ = self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ
+        # node coordinates with halos (grid.xᶠᵃᵃ, xᶜᵃᵃ, yᵃᶠᵃ, yᵃᶜᵃ; array position H holds node 1): Julia ranges, see julia_range
+        self.xᶠᵃᵃ, self.xᶜᵃᵃ = (np.full(1, self.x0),) * 2 if flat[0] else _regular_nodes((self.x0, self.x0 + self.Lx), self.Nx, self.Hx, self.topology[0])
+        self.yᵃᶠᵃ, self.yᵃᶜᵃ = (np.full(1, self.y0),) * 2 if flat[1] else _regular_nodes((self.y0, self.y0 + self.Ly), self.Ny, self.Hy, self.topology[1])
         n = self.Nz + 2 * self.Hz + 1
         if isinstance(z, tuple) and len(z) == 2 and np.isscalar(z[0]):
             dz, self.Lz, self.z0 = _regular_coordinate(z, self.Nz, "z")
@@ -213,6 +216,7 @@ class RectilinearGrid:
             self.Δzᵃᵃᶜ = np.full(n, dz)
             self.Δzᵃᵃᶠ = np.full(n, dz)
             self._dz = dz
+            self.zᵃᵃᶠ, self.zᵃᵃᶜ = (np.full(1, self.z0),) * 2 if flat[2] else _regular_nodes((self.z0, self.z0 + self.Lz), self.Nz, self.Hz, self.topology[2])
         else:
             if self.topology[2] is not Bounded:
                 raise NotImplementedError("a stretched z coordinate requires a Bounded z topology")
@@ -266,8 +270,7 @@ class RectilinearGrid:
                 arr = np.full(m, origin)
             else:
                 H = self.halo_size[d]
-                interval = (self.x0, self.x0 + self.Lx) if d == 0 else ((self.y0, self.y0 + self.Ly) if d == 1 else (self.z0, self.z0 + self.Lz))
-                F, Cn = _regular_nodes(interval, n, H, t)
+                F, Cn = ((self.xᶠᵃᵃ, self.xᶜᵃᵃ), (self.yᵃᶠᵃ, self.yᵃᶜᵃ), (self.zᵃᵃᶠ, self.zᵃᵃᶜ))[d]
                 arr = (F if l is Face else Cn)[H:H + m]
             shape = [1, 1, 1]
             shape[d] = m

@@ -476,3 +476,69 @@ def test_field_parent_sizes_of_the_field_docstrings(ocn_host):
     assert g.total_size((ocn.Center, ocn.Center, ocn.Face)) == (6, 9, 11) and g.interior_size((ocn.Center, ocn.Center, ocn.Face)) == (2, 3, 5)
     g = ocn.RectilinearGrid(None, size=(4, 5, 4), halo=(1, 1, 1), x=(0, 1), y=(0, 1), z=[0, 0.1, 0.3, 0.6, 1], topology=PPB)
     assert g.total_size((ocn.Center,) * 3) == (6, 7, 6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# test/test_grids.jl:18-152,184-241,440-487: the reference's own RectilinearGrid tests on the host mirror (Float64)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_regular_rectilinear_grid_as_the_reference_tests_it(ocn_host):
+    ocn = ocn_host
+    P, B = ocn.Periodic, ocn.Bounded
+    pi = np.pi
+    g = ocn.RectilinearGrid(None, size=(4, 6, 8), extent=(2 * pi, 4 * pi, 9 * pi), topology=(P, P, B))          # correct_size
+    assert g.size == (4, 6, 8) and np.allclose((g.Lx, g.Ly, g.Lz), (2 * pi, 4 * pi, 9 * pi), rtol=1e-15)
+    g = ocn.RectilinearGrid(None, size=(4, 6, 8), x=(1, 2), y=(pi, 3 * pi), z=(0, 4), topology=(P, P, B))       # correct_extent
+    assert np.allclose((g.Lx, g.Ly, g.Lz), (1, 2 * pi, 4), rtol=1e-15)
+    g = ocn.RectilinearGrid(None, size=(2, 3, 4), extent=(1, 1, 1), halo=(1, 1, 1), topology=(P, B, B))         # coordinate_lengths
+    assert (len(g.xᶜᵃᵃ), len(g.yᵃᶜᵃ), len(g.xᶠᵃᵃ), len(g.yᵃᶠᵃ), len(g.zᵃᵃᶜ), len(g.zᵃᵃᶠ)) == (4, 5, 4, 6, 6, 7)
+    g = ocn.RectilinearGrid(None, size=(4, 6, 8), extent=(2 * pi, 4 * pi, 9 * pi), halo=(1, 2, 3), topology=(P, P, B))
+    assert g.halo_size == (1, 2, 3)                                                                              # correct_halo_size
+    N, H, L = 4, 1, 2.0                                                                                           # correct_halo_faces
+    D = L / N
+    g = ocn.RectilinearGrid(None, size=(N, N, N), x=(0, L), y=(0, L), z=(0, L), halo=(H, H, H), topology=(P, B, B))
+    at = lambda a, i: a[i - 1 + H]                                       # noqa: E731  OffsetArray index -> array position
+    assert at(g.xᶠᵃᵃ, 0) == -H * D and at(g.yᵃᶠᵃ, 0) == -H * D and at(g.zᵃᵃᶠ, 0) == -H * D
+    assert at(g.xᶠᵃᵃ, N + 1) == L and at(g.yᵃᶠᵃ, N + 2) == L + H * D and at(g.zᵃᵃᶠ, N + 2) == L + H * D        # + correct_end_faces
+    L = 4.0                                                                                                        # correct_first_cells
+    g = ocn.RectilinearGrid(None, size=(N, N, N), x=(0, L), y=(0, L), z=(0, L), halo=(H, H, H), topology=(P, P, B))
+    assert at(g.xᶜᵃᵃ, 1) == 0.5 and at(g.yᵃᶜᵃ, 1) == 0.5 and at(g.zᵃᵃᶜ, 1) == 0.5
+    g = ocn.RectilinearGrid(None, size=(8, 9, 10), extent=(1, 1, 1), halo=(1, 2, 1), topology=(B, B, B))         # ranges_have_correct_length
+    assert (len(g.xᶜᵃᵃ), len(g.yᵃᶜᵃ), len(g.xᶠᵃᵃ), len(g.yᵃᶠᵃ), len(g.zᵃᵃᶜ), len(g.zᵃᵃᶠ)) == (10, 13, 11, 14, 12, 13)
+    g = ocn.RectilinearGrid(None, size=(1, 1, 64), extent=(1, 1, pi / 2), halo=(1, 1, 1), topology=(P, P, B))    # no_roundoff_error_in_ranges
+    assert (len(g.zᵃᵃᶜ), len(g.zᵃᵃᶠ)) == (66, 67)
+
+
+def test_xnode_ynode_znode_and_spacings_as_the_reference_tests_them(ocn_host):
+    """test_grids.jl:184-241 on the regularly spaced grid and on the grid whose z is given as the same faces (x, y stay regular: the
+    accelerated path takes stretched z only)"""
+    ocn = ocn_host
+    N, pi = 3, np.pi
+    topo = (ocn.Periodic, ocn.Periodic, ocn.Bounded)
+    domain = np.linspace(0, pi, N + 1)
+    for z in ((0, pi), domain):
+        g = ocn.RectilinearGrid(None, size=(N, N, N), x=(0, pi), y=(0, pi), z=z, topology=topo)
+        xc, yc, zc = (a.ravel() for a in g.nodes((ocn.Center,) * 3))
+        xf, yf, zf = (a.ravel() for a in g.nodes((ocn.Face,) * 3))
+        assert np.allclose([xc[1], yc[1], zc[1]], pi / 2, rtol=1e-15) and np.allclose([xf[1], yf[1], zf[1]], pi / 3, rtol=1e-15)
+        dz = np.asarray(g.Δzᵃᵃᶜ[g.Hz:g.Hz + N])
+        assert np.allclose([g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, dz.min()], pi / 3, rtol=1e-15) and np.allclose(dz, pi / N, rtol=1e-15)
+        assert np.allclose(np.asarray(g.Δzᵃᵃᶠ[g.Hz:g.Hz + N + 1]), pi / N, rtol=1e-15) and g.Δxᶠᵃᵃ == g.Δxᶜᵃᵃ and g.Δyᵃᶠᵃ == g.Δyᵃᶜᵃ
+
+
+@pytest.mark.parametrize("N", [16, 17])
+def test_rectilinear_grid_correct_spacings_of_a_stretched_z(ocn_host, N):
+    """test_grids.jl:440-487 (the z part: x = collect(0:N) is regular, the quadratic y is outside the accelerated path): tanh-like faces,
+    S = 3"""
+    ocn = ocn_host
+    S = 3
+
+    def zf(k):
+        return np.tanh(S * (2 * (k - 1) / N - 1)) / np.tanh(S)
+    g = ocn.RectilinearGrid(None, size=(N, N, N), x=(0, N), y=(0, N), z=zf, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    H = g.Hz
+    k = np.arange(1, N + 2)
+    assert g.Δxᶜᵃᵃ == 1 and g.Δxᶠᵃᵃ == 1
+    zc = (zf(k[:-1]) + zf(k[1:])) / 2
+    assert np.allclose(g.zᵃᵃᶠ[H:H + N + 1], zf(k)) and np.allclose(g.zᵃᵃᶜ[H:H + N], zc)
+    assert np.allclose(g.Δzᵃᵃᶜ[H:H + N], zf(k[1:]) - zf(k[:-1]))
+    assert np.allclose(g.Δzᵃᵃᶠ[H + 1:H + N], zc[1:] - zc[:-1])          # Δzᵃᵃᶠ[2:N]; [1] involves a halo point
