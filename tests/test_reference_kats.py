@@ -463,6 +463,8 @@ def test_coriolis_docstring_numbers(ocn_host):
     from oldoceananigans_jl_amd.buoyancy import sind
     assert ocn.FPlane(f=1e-4).f == 0.0001
     assert _six(ocn.FPlane(rotation_rate=7.292115e-5, latitude=45).f) == 0.000103126
+    # test/test_coriolis.jl:18-26: FPlane(f=π).f ≈ π; FPlane(rotation_rate=2, latitude=30).f ≈ 2 (here: exactly, sind(30) = 1/2)
+    assert ocn.FPlane(f=np.pi).f == np.pi and ocn.FPlane(rotation_rate=2, latitude=30).f == 2.0
     assert sind(45) == 0.7071067811865476 == 2 ** 0.5 / 2 and sind(30) == 0.5 and sind(90) == 1.0 and sind(-90) == -1.0 and sind(180) == 0.0
 
 
