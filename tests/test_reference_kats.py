@@ -544,3 +544,16 @@ def test_rectilinear_grid_correct_spacings_of_a_stretched_z(ocn_host, N):
     assert np.allclose(g.zᵃᵃᶠ[H:H + N + 1], zf(k)) and np.allclose(g.zᵃᵃᶜ[H:H + N], zc)
     assert np.allclose(g.Δzᵃᵃᶜ[H:H + N], zf(k[1:]) - zf(k[:-1]))
     assert np.allclose(g.Δzᵃᵃᶠ[H + 1:H + N], zc[1:] - zc[:-1])          # Δzᵃᵃᶠ[2:N]; [1] involves a halo point
+
+
+def test_grid_lengths_areas_and_volumes_of_test_operators(ocn_host, oracle):
+    """test/test_operators.jl:158-224: size (1, 1, 1), extent (π, 2π, 3π): every Δx == π, Δy == 2π, Δz == 3π, Ax == 6π², Ay == 3π²,
+    Az == 2π², V == 6π³ (exact equalities in the reference) -- with the products formed as the metric tables of the kernels form them
+    (Ax = Δy Δz, Ay = Δx Δz, Az = Δx Δy, V = Az Δz: spacings_and_areas_and_volumes.jl:308-378; csrc/ocn_api.hip grid tables)"""
+    ocn = ocn_host
+    pi = np.pi
+    g = ocn.RectilinearGrid(None, size=(1, 1, 1), extent=(pi, 2 * pi, 3 * pi), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    go = oracle.Grid((1, 1, 1), topology=(0, 0, 1), x=(0.0, pi), y=(0.0, 2 * pi), z=(-3 * pi, 0.0), halo=(1, 1, 1))
+    for dx, dy, dz in ((g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, float(g.Δzᵃᵃᶜ[g.Hz])), (go.dc[0][1], go.dc[1][1], go.dc[2][1])):
+        assert (dx, dy, dz) == (pi, 2 * pi, 3 * pi)
+        assert dy * dz == 6 * pi ** 2 and dx * dz == 3 * pi ** 2 and dx * dy == 2 * pi ** 2 and (dx * dy) * dz == 6 * pi ** 3
