@@ -541,3 +541,37 @@ def test_default_halo_of_small_grids(ocn, arch):
     PPB = (ocn.Periodic, ocn.Periodic, ocn.Bounded)
     assert ocn.RectilinearGrid(arch, size=(2, 2, 3), extent=(1, 2, 3), topology=PPB).halo_size == (2, 2, 3)
     assert ocn.RectilinearGrid(arch, size=(2, 4, 8), extent=(1, 1, 1), topology=PPB).halo_size == (2, 3, 3)
+
+
+def test_setting_model_fields(ocn, arch):
+    """test/test_nonhydrostatic_models.jl:114-195 ("Setting model fields", RectilinearGrid part): N = (4, 4, 4), L = (2π, 3π, 5π),
+    (Periodic, Bounded, Bounded), SeawaterBuoyancy, tracers (T, S): set! with an array, with functions evaluated at the nodes of each
+    field's location (v, w compared away from the walls their boundary conditions set), the halos update_state! fills (x-periodicity,
+    free slip at bottom and top), and enforce_incompressibility turning w = 1 between two walls into 0 (|w| < 10 eps)"""
+    N, L = (4, 4, 4), (2 * np.pi, 3 * np.pi, 5 * np.pi)
+    grid = ocn.RectilinearGrid(arch, size=N, extent=L, topology=(ocn.Periodic, ocn.Bounded, ocn.Bounded))
+    model = ocn.NonhydrostaticModel(grid=grid, buoyancy=ocn.SeawaterBuoyancy(), tracers=("T", "S"))
+    F = model.fields()
+    T0 = np.random.default_rng(0).random(N)
+    ocn.set_model(model, enforce_incompressibility=False, T=T0)
+    assert np.array_equal(F["T"].interior(), T0)
+    u0 = lambda x, y, z: 1 + x + y + z                          # noqa: E731
+    v0 = lambda x, y, z: 2 + np.sin(x * y * z)                  # noqa: E731
+    w0 = lambda x, y, z: 3 + y * z + 0 * x                      # noqa: E731
+    T0f = lambda x, y, z: 4 + np.tanh(x + y - z)                # noqa: E731
+    S0 = lambda x, y, z: 5 + 0 * (x + y + z)                    # noqa: E731
+    ocn.set_model(model, enforce_incompressibility=False, u=u0, v=v0, w=w0, T=T0f, S=S0)
+    xC, yC, zC = grid.nodes((ocn.Center,) * 3)
+    xF, yF, zF = grid.nodes((ocn.Face,) * 3)
+    Nx, Ny, Nz = N
+    assert np.allclose(F["u"].interior(), u0(xF, yC, zC), rtol=1e-15)
+    assert np.allclose(F["v"].interior()[:, 1:Ny, :], v0(xC, yF, zC)[:, 1:Ny, :], rtol=1e-15)
+    assert np.allclose(F["w"].interior()[:, :, 1:Nz], w0(xC, yC, zF)[:, :, 1:Nz], rtol=1e-15)
+    assert np.allclose(F["T"].interior(), T0f(xC, yC, zC), rtol=1e-15) and np.all(F["S"].interior() == 5.0)
+    H = 3
+    u = F["u"].parent()
+    assert u[H, H, H] == u[H + Nx, H, H]                                                          # u[1, 1, 1] == u[Nx+1, 1, 1]
+    assert np.array_equal(u[H:H + Nx, H:H + Ny, H], u[H:H + Nx, H:H + Ny, H - 1])                 # free slip at the bottom
+    assert np.array_equal(u[H:H + Nx, H:H + Ny, H + Nz - 1], u[H:H + Nx, H:H + Ny, H + Nz])       # ... and at the top
+    ocn.set_model(model, u=0, v=0, w=1, T=0, S=0)
+    assert np.all(np.abs(F["w"].interior()) < 10 * np.finfo(float).eps)
