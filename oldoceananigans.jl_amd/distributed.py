@@ -274,6 +274,7 @@ class DistributedRectilinearGrid:
         if topology[0] not in (Periodic, Bounded):
             raise ValueError("the partitioned direction is Periodic or Bounded")
         self.global_x_topology = topology[0]
+        self._global_arguments = dict(size=self.global_size, x=x, y=y, z=z, topology=tuple(topology), halo=halo)
         # local_size (distributed_grids.jl:44-58): the remainder of Nx / R goes to the last rank
         self.local_sizes = local_sizes(self.global_size[0], R)
         self.irregular = len(set(self.local_sizes)) > 1
@@ -311,7 +312,20 @@ class DistributedRectilinearGrid:
         else:
             self.local = make_local_grid(self.local_size, xl, y, z, topo, halo)
 
+    def global_nodes(self, loc):
+        """the node coordinates of the GLOBAL grid (reconstruct_global_grid, distributed_grids.jl:192-233) restricted to this rank's
+        interior cells. The local grid's own nodes are ranges over the LOCAL interval (like the reference's) and differ from these by
+        round-off; a state evaluated here is bit for bit the slab of the state a serial model evaluates on the global grid."""
+        if getattr(self, "_global_grid", None) is None:
+            a = self._global_arguments
+            self._global_grid = RectilinearGrid(None, a["size"], x=a["x"], y=a["y"], z=a["z"], topology=a["topology"], halo=a["halo"])
+        X, Y, Z = self._global_grid.nodes(loc)
+        nx, ny, _ = self.local.interior_size(loc)
+        return X[self.i_offset:self.i_offset + nx], Y[:, self.j_offset:self.j_offset + ny], Z
+
     def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
         return getattr(self.local, name)
 
 

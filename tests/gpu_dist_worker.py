@@ -28,7 +28,7 @@ def main():
     grid = dist.DistributedRectilinearGrid(ctx, size=(nx, ny, nz), x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
     flds = model.fields()
-    dist.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()})
+    dist.set_model(model, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in flds.items()})
     dt = 0.1 * grid.local.Δxᶜᵃᵃ / 0.6
     for _ in range(nsteps):
         dist.time_step(model, dt)

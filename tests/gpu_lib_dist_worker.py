@@ -45,7 +45,7 @@ def main():
     model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"))
     for k, v in options.items():
         model.set_option(k, int(v))
-    ocn.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in model.fields().items()})
+    ocn.set_model(model, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in model.fields().items()})
     dt = 0.1 * (2.0 / size[0]) / 0.6
     for _ in range(nsteps):
         ocn.time_step(model, dt)

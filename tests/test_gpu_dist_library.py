@@ -52,7 +52,7 @@ def _library_model(ocn, dist, ctx, size, zkind, xbounded=False, ybounded=False, 
     model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind), closure=_closure(ocn, zkind),
                                          buoyancy=_tracers_and_buoyancy(ocn, zkind)[1],
                                          coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
-    ocn.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in model.fields().items()})
+    ocn.set_model(model, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in model.fields().items()})
     return grid, model
 
 

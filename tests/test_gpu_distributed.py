@@ -66,7 +66,7 @@ def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic"
             model.async_halos = async_halos
             model.thin_halos = thin_halos
             flds = model.fields()
-            vals = {n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()}
+            vals = {n: analytic(n, *grid.global_nodes(f.loc)) for n, f in flds.items()}
             dist.set_model(model, **vals)
             dt = 0.1 * grid.local.Δxᶜᵃᵃ / 0.6
             for _ in range(nsteps):
@@ -314,7 +314,7 @@ def test_self_loop_rank_equals_single_gpu(ocn, arch, size, zkind, substructured)
         model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"), boundary_conditions=_bcs(ocn, zkind),
                                                     coriolis=ocn.FPlane(f=0.5) if zkind == "stretched" else None)
         flds = model.fields()
-        dist.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in flds.items()})
+        dist.set_model(model, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in flds.items()})
         dt = 0.1 * grid.local.Δxᶜᵃᵃ / 0.6
         for _ in range(3):
             dist.time_step(model, dt)
@@ -353,7 +353,7 @@ def test_substructured_solver_layouts(ocn, arch):
             lay = C.c_int()
             _lib.check(_lib.lib().ocn_dist_poisson_layout(model.backend.solver, C.byref(lay)))
             layouts.append(lay.value)
-            dist.set_model(model, **{n: analytic(n, *grid.local.nodes(f.loc)) for n, f in model.fields().items()})
+            dist.set_model(model, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in model.fields().items()})
             for _ in range(2):
                 dist.time_step(model, 0.1 * grid.local.Δxᶜᵃᵃ / 0.6)
             outs.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressure.parent()})

@@ -228,7 +228,7 @@ def _slab_pair(ocn, arch, size, zfaces, physics):
         if partitioned:
             grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo)
             model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"), **physics(ocn))
-            nodes = {n: grid.local.nodes(f.loc) for n, f in model.fields().items()}
+            nodes = {n: grid.global_nodes(f.loc) for n, f in model.fields().items()}
         else:
             grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=topo)
             model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), **physics(ocn))

@@ -486,7 +486,7 @@ def test_fplane_coriolis_matches_oracle(ocn, oracle, arch, topology, size):
     core = tuple(slice(None) if t == "Flat" else slice(3, -3) for t in topology)
     for name, a, b in field_pairs(m_gpu, m_cpu):
         assert rel_err(a[core], b[core]) < 1e-12, (name, rel_err(a[core], b[core]))
-    assert ocn.FPlane(latitude=45).f == 2 * 7.292115e-5 * np.sin(np.pi / 4)
+    assert ocn.FPlane(latitude=45).f == 2 * 7.292115e-5 * 0.7071067811865476          # 2 rotation_rate sind(45) (f_plane.jl:44); sind(45) is one ulp above sin(π / 4)
 
 
 @pytest.mark.parametrize("topology,size", [(("Periodic", "Periodic", "Bounded"), (64, 12, 10)), (("Bounded", "Bounded", "Bounded"), (9, 8, 7))])

@@ -15,7 +15,7 @@ ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
 topo = (ocn.Periodic, ocn.Periodic, ocn.Bounded if bounded else ocn.Periodic)
 grid = dist.DistributedRectilinearGrid(ctx, size=shape, x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(shape[2]) if bounded else (0.0, 1.0), topology=topo)
 model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"))
-vals = smooth_state({n: grid.local.nodes(f.loc) for n, f in model.fields().items()}, 99)
+vals = smooth_state({n: grid.global_nodes(f.loc) for n, f in model.fields().items()}, 99)
 vals["S"] = vals["S"] - 35.0
 ocn.set_model(model, **vals)
 dt = 0.1 / max(shape) / 0.6
