@@ -575,3 +575,38 @@ def test_setting_model_fields(ocn, arch):
     assert np.array_equal(u[H:H + Nx, H:H + Ny, H + Nz - 1], u[H:H + Nx, H:H + Ny, H + Nz])       # ... and at the top
     ocn.set_model(model, u=0, v=0, w=1, T=0, S=0)
     assert np.all(np.abs(F["w"].interior()) < 10 * np.finfo(float).eps)
+
+
+def test_cfl_diagnostics_as_the_reference_tests_them(ocn, arch):
+    """test/test_diagnostics.jl:9-157 (Float64): DiffusiveCFL and AdvectiveCFL on the 3^3 test grids (regular triply periodic; z given as
+    the face range 0:Δx:3Δx), the advective time scale with all three velocity components on the regular and on the stretched grid
+    (z = k^2 faces: w = 0 on the bottom face, the constraint sits at the second face), and the Flat-y grid where v does not count"""
+    P, F, B = ocn.Periodic, ocn.Flat, ocn.Bounded
+    dx0, close = 0.5, lambda a, b: abs(a - b) <= np.sqrt(np.finfo(float).eps) * max(abs(a), abs(b))      # noqa: E731  Julia's ≈
+
+    def regular(nu=1.0):
+        grid = ocn.RectilinearGrid(arch, size=(3, 3, 3), extent=(3 * dx0,) * 3, topology=(P, P, P))
+        return ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=nu, κ=nu), tracers=())
+
+    def stretched(nu=1.0):
+        grid = ocn.RectilinearGrid(arch, size=(3, 3, 3), x=(0, 3 * dx0), y=(0, 3 * dx0), z=np.arange(0, 3 * dx0 + 1e-12, dx0), topology=(P, P, B))
+        return ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=nu, κ=nu), tracers=())
+    dt, nu = 1.3e-6, 1.2
+    assert close(ocn.DiffusiveCFL(dt)(regular(nu)), dt * nu / dx0 ** 2)
+    for make in (regular, stretched):
+        model = make()
+        ocn.set_model(model, u=1.2)
+        assert close(ocn.AdvectiveCFL(dt)(model), dt * 1.2 / model.grid.Δxᶜᵃᵃ)
+    model = regular()
+    g = model.grid
+    ocn.set_model(model, u=1.2, v=-2.5, w=3.9)
+    assert close(ocn.CFL(1.7, ocn.cell_advection_timescale)(model), 1.7 * (1.2 / g.Δxᶜᵃᵃ + 2.5 / g.Δyᵃᶜᵃ + 3.9 / float(g.Δzᵃᵃᶜ[g.Hz])))
+    grid = ocn.RectilinearGrid(arch, size=(4, 4, 8), x=(0, 100), y=(0, 100), z=[float(k * k) for k in range(9)], topology=(P, P, B))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=())
+    ocn.set_model(model, u=1.2, v=-2.5, w=3.9, enforce_incompressibility=False)
+    dz_min = float(grid.Δzᵃᵃᶠ[grid.Hz + 1])                                # Δzᵃᵃᶠ(1, 1, 2, grid)
+    assert close(ocn.CFL(15.5, ocn.cell_advection_timescale)(model), 15.5 * (1.2 / grid.Δxᶜᵃᵃ + 2.5 / grid.Δyᵃᶜᵃ + 3.9 / dz_min))
+    grid = ocn.RectilinearGrid(arch, size=(3, 3), x=(0, 3 * dx0), z=(0, 3 * dx0), topology=(P, F, B))
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=())
+    ocn.set_model(model, v=1)
+    assert ocn.CFL(1.7, ocn.cell_advection_timescale)(model) == 0
