@@ -610,3 +610,72 @@ def test_cfl_diagnostics_as_the_reference_tests_them(ocn, arch):
     model = ocn.NonhydrostaticModel(grid=grid, tracers=())
     ocn.set_model(model, v=1)
     assert ocn.CFL(1.7, ocn.cell_advection_timescale)(model) == 0
+
+
+def _rate(err, N):
+    """test_rate_of_convergence (validation/convergence_tests/src/analysis.jl:65-71): between the last two resolutions"""
+    return np.log10(err[-2] / err[-1]) / np.log10(N[-2] / N[-1])
+
+
+def test_cosine_diffusion_convergence(ocn, arch):
+    """validation/convergence_tests/one_dimensional_cosine_advection_diffusion.jl, the "diffusion only" case (κ = 0.1, U = 0; the two
+    cases with U != 0 expect the second order of the reference's default Centered advection): c = e^{-κt} cos(s) on (0, 2π) in the two
+    transverse velocity components and the tracer, RK3 to t = 0.01 with Δt = 1e-3 h² / κ of the finest grid, Nx = 8 ... 128; rate of
+    convergence -2.0 ± 0.01 in L₁ and L∞ for all nine series, and all series equal (`≈`). One-cell directions are Flat (as above)."""
+    kappa, Ns, stop_time = 1e-1, [8, 16, 32, 64, 128], 0.01
+    h = 2 * np.pi / max(Ns)
+    n_steps = int(round(stop_time / (1e-3 * h ** 2 / kappa)))
+    dt = stop_time / n_steps
+    names = ["u", "v", "w"]
+    series = {}
+    for axis in range(3):
+        for N in Ns:
+            size, topo, coords = [1, 1, 1], [ocn.Flat] * 3, {}
+            size[axis], topo[axis] = N, ocn.Periodic
+            coords["xyz"[axis]] = (0, 2 * np.pi)
+            grid = ocn.RectilinearGrid(arch, size=tuple(size), topology=tuple(topo), **coords)
+            model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=kappa, κ=kappa), tracers=("c",))
+            init = lambda x, y, z: np.cos((x, y, z)[axis]) + 0 * (x + y + z)      # noqa: E731
+            state = {n: init for n in names if n != names[axis]}
+            state.update({names[axis]: 0.0, "c": init})
+            ocn.set_model(model, **state)
+            for _ in range(n_steps):
+                ocn.time_step(model, dt)
+            s = grid.nodes((ocn.Center,) * 3)[axis].ravel()
+            exact = np.exp(-kappa * model.clock.time) * np.cos(s)
+            for n in [q for q in names if q != names[axis]] + ["c"]:
+                err = np.abs(model.fields()[n].interior().ravel() - exact)
+                series.setdefault((n, axis, 0), []).append(err.mean())
+                series.setdefault((n, axis, 1), []).append(err.max())
+            model.close()
+    for norm in (0, 1):
+        ref = np.array(series[("c", 0, norm)])
+        for (n, axis, nm), e in series.items():
+            if nm != norm:
+                continue
+            assert abs(_rate(e, Ns) - (-2.0)) <= 0.01, (n, axis, norm, _rate(e, Ns))
+            assert np.linalg.norm(np.array(e) - ref) <= SQRT_EPS * max(np.linalg.norm(e), np.linalg.norm(ref)), (n, axis, norm)
+
+
+@pytest.mark.parametrize("topology", [("Periodic", "Periodic"), ("Periodic", "Bounded"), ("Bounded", "Bounded")])
+def test_two_dimensional_diffusion_convergence(ocn, arch, topology):
+    """validation/convergence_tests/two_dimensional_diffusion.jl + src/TwoDimensionalDiffusion.jl: c = e^{-2t} cos x cos y, κ = 1, extent
+    2π along Periodic and π along Bounded directions, Nx = Ny = 8 ... 256, RK3 to t = 1e-4 with Δt = 1e-3 min(Δx)² of the finest grid:
+    rate of convergence -2.0 ± 0.01 (L₁), ± 0.06 (L∞). The reference's one-cell Bounded z is Flat here."""
+    Ns, stop_time = [8, 16, 32, 64, 128, 256], 1e-4
+    L = [2 * np.pi if t == "Periodic" else np.pi for t in topology]
+    n_steps = int(round(stop_time / (1e-3 * (2 * np.pi / max(Ns)) ** 2)))         # min_Δx = 2π / maximum(Nx) for every topology (:34-37)
+    dt = stop_time / n_steps
+    L1, Linf = [], []
+    for N in Ns:
+        grid = ocn.RectilinearGrid(arch, size=(N, N), x=(0, L[0]), y=(0, L[1]), topology=tuple(getattr(ocn, t) for t in topology) + (ocn.Flat,))
+        model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(κ=1.0), tracers=("c",))
+        ocn.set_model(model, c=lambda x, y, z: np.cos(x) * np.cos(y) + 0 * z)
+        for _ in range(n_steps):
+            ocn.time_step(model, dt)
+        x, y, _ = grid.nodes((ocn.Center,) * 3)
+        err = np.abs(model.fields()["c"].interior()[:, :, 0] - (np.exp(-2 * model.clock.time) * np.cos(x) * np.cos(y))[:, :, 0])
+        L1.append(err.mean())
+        Linf.append(err.max())
+        model.close()
+    assert abs(_rate(L1, Ns) + 2.0) <= 0.01 and abs(_rate(Linf, Ns) + 2.0) <= 0.06, (_rate(L1, Ns), _rate(Linf, Ns))
