@@ -679,3 +679,29 @@ def test_two_dimensional_diffusion_convergence(ocn, arch, topology):
         Linf.append(err.max())
         model.close()
     assert abs(_rate(L1, Ns) + 2.0) <= 0.01 and abs(_rate(Linf, Ns) + 2.0) <= 0.06, (_rate(L1, Ns), _rate(Linf, Ns))
+
+
+def test_taylor_green_convergence(ocn, arch):
+    """validation/convergence_tests/run_taylor_green.jl + analyze_taylor_green.jl + src/DoublyPeriodicTaylorGreen.jl: the advected, decaying
+    vortex u = U + e^{-2t} cos(x - Ut) sin y, v = -e^{-2t} sin(x - Ut) cos y (U = 1, ν = 1) on (0, 2π)², Nx = Ny = 8 ... 128, RK3 to
+    t = 0.25 with Δt = 0.01 h² of the finest grid (10 375 steps per resolution); error of u at the end: rate of convergence -2.0 ± 0.05 in
+    L₁ and L∞. Adaptations: advection is WENO(order=5) (the reference's default Centered(order=2) has the same formal order as the
+    viscous and pressure terms that set the rate here), the one-cell Bounded z is Flat."""
+    Ns, stop_time, U = [8, 16, 32, 64, 128], 0.25, 1.0
+    Nt = int(round(stop_time / (0.01 * (2 * np.pi / max(Ns)) ** 2)))
+    dt = stop_time / Nt
+    L1, Linf = [], []
+    for N in Ns:
+        grid = ocn.RectilinearGrid(arch, size=(N, N), x=(0, 2 * np.pi), y=(0, 2 * np.pi), topology=(ocn.Periodic, ocn.Periodic, ocn.Flat))
+        model = ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=1.0), tracers=())
+        ocn.set_model(model, u=lambda x, y, z: U + np.cos(x) * np.sin(y) + 0 * z, v=lambda x, y, z: -np.sin(x) * np.cos(y) + 0 * z)
+        for _ in range(Nt):
+            ocn.time_step(model, dt)
+        t = model.clock.time
+        x, y, _ = grid.nodes(model.fields()["u"].loc)
+        exact = U + np.exp(-2 * t) * np.cos(x - U * t) * np.sin(y)
+        err = np.abs(model.fields()["u"].interior()[:, :, 0] - exact[:, :, 0])
+        L1.append(err.mean())
+        Linf.append(err.max())
+        model.close()
+    assert abs(_rate(L1, Ns) + 2.0) <= 0.05 and abs(_rate(Linf, Ns) + 2.0) <= 0.05, (_rate(L1, Ns), _rate(Linf, Ns), L1, Linf)
