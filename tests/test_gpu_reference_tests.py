@@ -705,3 +705,42 @@ def test_taylor_green_convergence(ocn, arch):
         Linf.append(err.max())
         model.close()
     assert abs(_rate(L1, Ns) + 2.0) <= 0.05 and abs(_rate(Linf, Ns) + 2.0) <= 0.05, (_rate(L1, Ns), _rate(Linf, Ns), L1, Linf)
+
+
+def test_field_initialization_and_setting_as_the_reference_tests_them(ocn, arch):
+    """test/test_field.jl:269-300 ("Field initialization": parent sizes of Center / Face fields on four topologies, N = (4, 6, 8),
+    H = (1, 1, 1)) and :375-440 ("Setting fields": numbers of many types, arrays, a function evaluated at each location's nodes) on
+    device fields (Float64; reduced `Nothing` locations and views are outside this library)"""
+    N, L, H = (4, 6, 8), (2 * np.pi, 3 * np.pi, 5 * np.pi), (1, 1, 1)
+    P, B = ocn.Periodic, ocn.Bounded
+    makers = (ocn.CenterField, ocn.XFaceField, ocn.YFaceField, ocn.ZFaceField)
+    T = tuple(n + 2 * h for n, h in zip(N, H))
+    for topo in ((P, P, P), (P, P, B), (P, B, B), (B, B, B)):
+        grid = ocn.RectilinearGrid(arch, size=N, extent=L, halo=H, topology=topo)
+        for d, make in enumerate(makers):
+            want = list(T)
+            if d > 0 and topo[d - 1] is B:
+                want[d - 1] += 1                                   # N + 1 faces along a Bounded direction
+            assert make(grid).parent().shape == tuple(want), (topo, d)
+    grid = ocn.RectilinearGrid(arch, size=N, extent=L, topology=(P, P, B))
+    from fractions import Fraction
+    vals = [0, -1, 2, -3, 4, 6, 7, 8, 9, 10, 0.0, -0.0, 6e-34, float(np.float32(1.0e10)), Fraction(1, 11), Fraction(-23, 7), np.pi]
+    for make in makers:
+        for val in vals:
+            f = make(grid)
+            f.set(float(val))
+            a = f.interior()
+            assert np.all(a == float(val)) and a[0, 0, 0] == float(val)              # correct_field_value_was_set
+        f = make(grid)
+        A = np.random.default_rng(1).random(f.interior().shape)
+        f.set(A)
+        assert f.interior()[0, 0, 0] == A[0, 0, 0] and np.array_equal(f.interior(), A)
+    Nx = 8
+    grid = ocn.RectilinearGrid(arch, size=(Nx, Nx, Nx), x=(-1, 1), y=(0, 2 * np.pi), z=(-1, 1), topology=(B, B, B))
+    fun = lambda x, y, z: np.exp(x) * np.sin(y) * np.tanh(z)                          # noqa: E731
+    for make in makers:
+        f = make(grid)
+        f.set(fun)
+        x, y, z = (a.ravel() for a in grid.nodes(f.loc))
+        got, want = f.interior()[0, 1, 2], fun(x[0], y[1], z[2])                      # ϕ[1, 2, 3] ≈ f(x[1], y[2], z[3])
+        assert abs(got - want) <= SQRT_EPS * max(abs(got), abs(want))
