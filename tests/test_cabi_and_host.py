@@ -156,3 +156,17 @@ def test_distributed_grid_partitions_on_the_host():
     assert g.local.topology[:2] == (ocn.Periodic, ocn.FullyConnected) and g.local_size == (16, 6, 6) and g.j_offset == 6
     with pytest.raises(ValueError):
         dist.DistributedRectilinearGrid(_FakeCtx(4, 0), size=(16, 16, 6), x=(0.0, 1.0), y=(0.0, 1.0), z=(0.0, 1.0), partition=(3, 2))
+    # test_triply_periodic_local_grid_with_411 / 141 / 221_ranks (test_distributed_models.jl:225-275): size (8, 8, 8), extent (1, 2, 3),
+    # the first and the (n + 1)-th face of every direction on every rank, exact equalities
+    at = lambda a, i, H: float(a[i - 1 + H])                          # noqa: E731   OffsetArray index -> array position
+    for partition, world in (((4, 1), 4), ((1, 4), 4), ((2, 2), 4)):
+        for rank in range(world):
+            g = dist.DistributedRectilinearGrid(_FakeCtx(world, rank), size=(8, 8, 8), extent=(1, 2, 3), partition=partition, halo=(2, 2, 2))   # (the
+            # reference validates the default halo 3 against the GLOBAL size; two local cells take halo 2 here)
+            l = g.local
+            nx, ny, nz = l.size
+            ix, iy = rank // partition[1], rank % partition[1]
+            wx, wy = 1.0 / partition[0], 2.0 / partition[1]
+            assert at(l.xᶠᵃᵃ, 1, l.Hx) == wx * ix and at(l.xᶠᵃᵃ, nx + 1, l.Hx) == wx * (ix + 1), (partition, rank)
+            assert at(l.yᵃᶠᵃ, 1, l.Hy) == wy * iy and at(l.yᵃᶠᵃ, ny + 1, l.Hy) == wy * (iy + 1), (partition, rank)
+            assert at(l.zᵃᵃᶠ, 1, l.Hz) == -3 and at(l.zᵃᵃᶠ, nz + 1, l.Hz) == 0
