@@ -744,3 +744,43 @@ def test_field_initialization_and_setting_as_the_reference_tests_them(ocn, arch)
         x, y, z = (a.ravel() for a in grid.nodes(f.loc))
         got, want = f.interior()[0, 1, 2], fun(x[0], y[1], z[2])                      # ϕ[1, 2, 3] ≈ f(x[1], y[2], z[3])
         assert abs(got - want) <= SQRT_EPS * max(abs(got), abs(want))
+
+
+def test_constant_isotropic_diffusivity_fluxdiv(ocn, oracle, arch):
+    """run_constant_isotropic_diffusivity_fluxdiv_tests (test/test_turbulence_closures.jl:36-66): ScalarDiffusivity(ν = 0.3, κ = 0.7) on
+    size (3, 1, 4), extent (3, 1, 4); u, v, w, T = [0, -1/2, 0], [0, -2, 0], [0, -3, 0], [0, -1, 0] along x at every level, halos filled;
+    at cell (2, 1, 3) the reference asserts EXACT equalities: ∇·q_T == -2κ, ∂ⱼτ₁ⱼ == -2ν, ∂ⱼτ₂ⱼ == -4ν, ∂ⱼτ₃ⱼ == -6ν. The library's
+    closure kernel adds -∂ⱼτᵢⱼ / -∇·q to a tendency: from zero tendencies the same cell must hold exactly 2ν, 4ν, 6ν, 2κ -- on the device
+    and in the oracle. (The one-cell Periodic y of the reference's grid is Flat here.)"""
+    nu, kappa = 0.3, 0.7
+    grid = ocn.RectilinearGrid(arch, size=(3, 4), extent=(3, 4), topology=(ocn.Periodic, ocn.Flat, ocn.Bounded))
+    makers = (ocn.XFaceField, ocn.YFaceField, ocn.ZFaceField, ocn.CenterField, ocn.CenterField)
+    amplitude = (-0.5, -2.0, -3.0, -1.0, 0.0)
+    fields, G = [], []
+    for make, a in zip(makers, amplitude):
+        f = make(grid)
+        v = np.zeros(f.interior().shape)
+        v[1, 0, :] = a
+        f.set(v)
+        fields.append(f)
+        G.append(make(grid))
+    ocn.fill_halo_regions(fields)
+    from oldoceananigans_jl_amd.kernels import compute_closure_tendencies
+    compute_closure_tendencies(grid, fields, G, ocn.ScalarDiffusivity(ν=nu, κ={"T": kappa, "S": kappa}), ("T", "S"))
+    got = [g.interior()[1, 0, 2] for g in G[:4]]
+    assert got == [2 * nu, 4 * nu, 6 * nu, 2 * kappa], got
+    # the oracle's restatement of the same operators
+    go = oracle.Grid((3, 1, 4), topology=(0, 3, 1), x=(0.0, 3.0), y=(0.0, 1.0), z=(-4.0, 0.0))
+    arrs = []
+    for loc, a in zip(("u", "v", "w", "c"), amplitude):
+        q = go.zeros(oracle.LOC[loc])
+        go.interior(q, oracle.LOC[loc])[1, 0, :] = a
+        go.fill_halo_regions(q, oracle.LOC[loc])
+        arrs.append(q)
+    import ctypes as C
+    dp = C.POINTER(C.c_double)
+    ptr = lambda q: q.ctypes.data_as(dp)                               # noqa: E731
+    for which, (loc, coef, want) in enumerate((("u", nu, 2 * nu), ("v", nu, 4 * nu), ("w", nu, 6 * nu), ("c", kappa, 2 * kappa))):
+        Gq = go.zeros(oracle.LOC[loc])
+        oracle.lib().oro_add_closure_tendency(go.handle, which, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), coef, ptr(Gq), None)
+        assert go.interior(Gq, oracle.LOC[loc])[1, 0, 2] == want, (loc, go.interior(Gq, oracle.LOC[loc])[1, 0, 2], want)
