@@ -784,3 +784,24 @@ def test_constant_isotropic_diffusivity_fluxdiv(ocn, oracle, arch):
         Gq = go.zeros(oracle.LOC[loc])
         oracle.lib().oro_add_closure_tendency(go.handle, which, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2]), ptr(arrs[3]), coef, ptr(Gq), None)
         assert go.interior(Gq, oracle.LOC[loc])[1, 0, 2] == want, (loc, go.interior(Gq, oracle.LOC[loc])[1, 0, 2], want)
+
+
+def test_stratified_fluid_remains_at_rest(ocn, arch):
+    """stratified_fluid_remains_at_rest_with_tilted_gravity_buoyancy_tracer (test_dynamics.jl:263-306) with θ = 0 -- gravity along -z, the
+    direction this library's buoyancy takes (gravity_unit_vector is outside the accelerated path): (Periodic, Bounded, Bounded), N = 32,
+    L = 2000, b = N² z with Gradient conditions N² at bottom and top, closure = nothing, Δt = 10 minutes for one hour: ∂z b stays N²
+    everywhere (`≈`), ∂y b stays 0, nothing moves. Four cells along x instead of one (one-cell non-Flat directions are refused)."""
+    N, L, N2 = 32, 2000.0, 1e-5
+    grid = ocn.RectilinearGrid(arch, size=(4, N, N), extent=(L, L, L), topology=(ocn.Periodic, ocn.Bounded, ocn.Bounded))
+    G = ocn.GradientBoundaryCondition(N2)
+    model = ocn.NonhydrostaticModel(grid=grid, buoyancy=ocn.BuoyancyTracer(), tracers=("b",),
+                                    boundary_conditions={"b": ocn.FieldBoundaryConditions(bottom=G, top=G)})
+    ocn.set_model(model, b=lambda x, y, z: N2 * z + 0 * (x + y))
+    for _ in range(6):
+        ocn.time_step(model, 600.0)
+    assert model.clock.time == 3600.0
+    b = model.fields()["b"].interior()
+    dz = L / N
+    dbdz, dbdy = np.diff(b, axis=2) / dz, np.diff(b, axis=1) / dz
+    assert np.allclose(dbdz, N2, rtol=SQRT_EPS, atol=0) and abs(dbdz.mean() - N2) <= SQRT_EPS * N2 and np.all(dbdy == 0)
+    assert all(np.all(model.fields()[n].interior() == 0) for n in "uvw")
