@@ -8,7 +8,11 @@
  * no Julia in this container or on the GPU box, and the reference's stored regression data are remote DataDeps
  * (test/data_dependencies.jl:17-38), AB2+Centered only. The restatement is pinned by the reference's data-free
  * tests instead: exact halo tests, Poisson residual tests, tridiagonal-vs-dense, incompressibility,
- * Taylor-Green, WENO order-of-accuracy/symmetry, docstring KATs.
+ * Taylor-Green, WENO order-of-accuracy/symmetry, docstring KATs; and by the numbers the reference itself holds: the stretched-
+ * coordinate spacings printed with 17 digits (docs/src/fields.md), the exact ScalarDiffusivity flux divergences of
+ * test/test_turbulence_closures.jl:36-66, the permutation tables, the grid summaries (tests/test_reference_kats.py,
+ * tests/test_gpu_reference_tests.py). Grid generation, index work and the closure operators are therefore pinned; the WENO-5 /
+ * RK3 field values are not.
  *
  * Conventions: all (i, j, k) are Julia 1-based interior indices, halo cells have indices <= 0 or > N, exactly as the
  * OffsetArrays of the reference (src/Grids/new_data.jl:15-73). Arrays are column-major (x fastest) dense parents.
