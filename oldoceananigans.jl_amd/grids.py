@@ -71,15 +71,48 @@ def _truncbits(x, nb):
     return struct.unpack("<d", struct.pack("<Q", b))[0]
 
 
+def _rat(x):
+    """Base.rat (twiceprecision.jl): a rational approximation n / d of a Float64 with |n|, |d| <= 2^24 by continued fractions; (n, 0)-like
+    failures are reported by d == 0 or by n / d != x at the call site"""
+    import math
+    y = x
+    a = d = 1
+    b = c = 0
+    m = 16777216.0                                   # maxintfloat(Float32)
+    while abs(y) <= m:
+        f = math.trunc(y)
+        y -= f
+        a, c = f * a + c, a
+        b, d = f * b + d, b
+        if max(abs(a), abs(b)) > 16777216:
+            return c, d
+        if b != 0 and a / b == x:
+            break
+        if y == 0:
+            break
+        y = 1.0 / y
+    return a, b
+
+
 def julia_range(start, stop, length):
-    """`range(start, stop, length = length)` for Float64 end points as Julia evaluates it (base/twiceprecision.jl, `_linspace`: a
-    StepRangeLen with twice-precision reference and step; the reference element is the one of smallest magnitude): every element,
-    correctly rounded like `r[i]`. The grids take their node coordinates from such ranges (grid_generation.jl:118-119), so a node is not
-    `c₁ + (i - 1) Δ` in floating point -- e.g. the first x face of `RectilinearGrid(size=(32, 32), extent=(2π, 4π), ...)` is 3.60072e-17
-    (rectilinear_grid.jl:194, reproduced by tests/test_reference_kats.py)."""
+    """`range(start, stop, length = length)` for Float64 end points as Julia evaluates it (base/twiceprecision.jl,
+    `range_start_stop_length`): every element, rounded like `r[i]`. End points that are exact small rationals (0.25, -0.3, 1.2 ...) take
+    the rational path -- the elements are the correctly rounded values of (start_n (len - i) + stop_n (i - 1)) / (den (len - 1)) --, others
+    (multiples of π ...) the floating-point path `_linspace`: a StepRangeLen with twice-precision reference and step whose reference element
+    is the one of smallest magnitude. The grids take their node coordinates from such ranges (grid_generation.jl:118-119), so a node is
+    not `c₁ + (i - 1) Δ` in floating point -- e.g. the first x face of `RectilinearGrid(size=(32, 32), extent=(2π, 4π), ...)` is
+    3.60072e-17 (rectilinear_grid.jl:194, reproduced by tests/test_reference_kats.py)."""
     import math
     if length == 1:
         return np.array([start], dtype=np.float64)
+    sn, sd = _rat(start)
+    en, ed = _rat(stop)
+    if sd != 0 and ed != 0:
+        den = sd * ed // math.gcd(sd, ed)
+        if den != 0 and abs(den * start) <= 2.0 ** 53 and abs(den * stop) <= 2.0 ** 53:
+            start_n, stop_n = int(round(den * start)), int(round(den * stop))
+            if start_n / den == start and stop_n / den == stop:
+                return np.array([float(Fraction(start_n * (length - i) + stop_n * (i - 1), den * (length - 1))) for i in range(1, length + 1)])
     d = stop - start
     imin = int(round(-(start / d) * (length - 1) + 1)) if d != 0 else 1        # round half to even, like round(Int, x)
     if 1 < imin < length:
