@@ -304,6 +304,9 @@ def test_weno_convergence_run_and_directional_symmetry(ocn, arch):
     src/analysis.jl:41-53 (L₁ = mean |error|, L∞ = max |error|).
     Adaptation: the reference's (Nx, 1, 1) triply Periodic grids with halo 6 become grids whose two transverse directions are Flat --
     this library refuses one-cell non-Flat directions (tests/test_gpu_parity.py::test_one_cell_in_a_non_flat_direction_is_refused).
+    (In v0.100.5 the script's own grid, size (Nx, 1, 1) with halo (6, 6, 6), is rejected by validate_halo -- halo must be <= size along
+    x and y, Grids/input_validation.jl:86-92 -- and with the default one-cell halo the Centered(order=4) advecting-velocity interpolation
+    of the other directions reads two cells into it: a one-cell non-Flat direction has no well-defined WENO run in the reference either.)
     Assertions, the reference's: cx ≈ cy ≈ cz, uy ≈ uz, vx ≈ vz, wx ≈ wy in L₁ and L∞ (:108-118, `≈` = rtol sqrt(eps)), and the rate of
     convergence between Nx = 384 and 512 equals 2K - 1 = 5 within the reference's tolerance (atol = 100, :58-59 -- vacuous there; here
     additionally: the error falls monotonically from Nx = 64 on and by more than 2^4 per doubling 128 -> 256 -> 512)."""
