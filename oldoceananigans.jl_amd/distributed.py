@@ -1090,10 +1090,14 @@ class LibraryDistributedModel(_NonhydrostaticModel):
             _lib.check(_lib.lib().ocn_dist_model_create_pencil(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global),
                                                                float(grid.Ly_global), Rx, Ry, sx, sy, 1 if bounded else 0,
                                                                1 if getattr(grid, "global_y_topology", Periodic) is Bounded else 0))
-        elif getattr(grid, "irregular", False) or bounded:
+        elif bounded:
             sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
             _lib.check(_lib.lib().ocn_dist_model_create_partition(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
-                                                                  float(grid.Lx_global), sizes, 1 if bounded else 0))
+                                                                  float(grid.Lx_global), sizes, 1))
+        elif getattr(grid, "irregular", False):          # Periodic x, Nx % R != 0: the remainder on the last rank
+            sizes = (C.c_int * len(grid.local_sizes))(*grid.local_sizes)
+            _lib.check(_lib.lib().ocn_dist_model_create_sizes(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle,
+                                                              float(grid.Lx_global), sizes))
         else:
             _lib.check(_lib.lib().ocn_dist_model_create(C.byref(h), grid.local.handle, ntracers, grid.ctx.handle, float(grid.Lx_global)))
         return h
