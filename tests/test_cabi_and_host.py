@@ -170,3 +170,17 @@ def test_distributed_grid_partitions_on_the_host():
             assert at(l.xᶠᵃᵃ, 1, l.Hx) == wx * ix and at(l.xᶠᵃᵃ, nx + 1, l.Hx) == wx * (ix + 1), (partition, rank)
             assert at(l.yᵃᶠᵃ, 1, l.Hy) == wy * iy and at(l.yᵃᶠᵃ, ny + 1, l.Hy) == wy * (iy + 1), (partition, rank)
             assert at(l.zᵃᵃᶠ, 1, l.Hz) == -3 and at(l.zᵃᵃᶠ, nz + 1, l.Hz) == 0
+
+
+def test_every_header_symbol_is_exercised_somewhere():
+    """every entry point include/ocn_mi355x.h declares is called by the host mirror (which the GPU tests drive) or directly by a test --
+    an unexercised entry point would be an untested part of the drop-in boundary"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "ocn_mi355x.h")).read()
+    symbols = sorted(set(re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", header)))
+    mirror = " ".join(open(f).read() for f in glob.glob(os.path.join(root, "oldoceananigans.jl_amd", "*.py")) if not f.endswith("_lib.py"))
+    tests = " ".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")))
+    missing = [s for s in symbols if s not in mirror and s not in tests]
+    assert len(symbols) >= 110 and not missing, missing
