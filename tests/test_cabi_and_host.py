@@ -184,3 +184,7 @@ def test_every_header_symbol_is_exercised_somewhere():
     tests = " ".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")))
     missing = [s for s in symbols if s not in mirror and s not in tests]
     assert len(symbols) >= 110 and not missing, missing
+    # ... and has its reference-side binding (the ccall signature) in INTEGRATION.md (tools/gen_integration_table.py regenerates the appendix)
+    integration = open(os.path.join(root, "INTEGRATION.md")).read()
+    unbound = [s for s in symbols if f"(:{s}, libocn)" not in integration]
+    assert not unbound, unbound
