@@ -179,11 +179,11 @@ def test_every_header_symbol_is_exercised_somewhere():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     header = open(os.path.join(root, "include", "ocn_mi355x.h")).read()
-    symbols = sorted(set(re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", header)))
+    symbols = sorted(s for s in set(re.findall(r"\b(ocn_[a-z0-9_]+)\s*\(", header)) if not s.endswith("_t"))      # (types in pointer-to-array arguments)
     mirror = " ".join(open(f).read() for f in glob.glob(os.path.join(root, "oldoceananigans.jl_amd", "*.py")) if not f.endswith("_lib.py"))
     tests = " ".join(open(f).read() for f in glob.glob(os.path.join(root, "tests", "*.py")))
     missing = [s for s in symbols if s not in mirror and s not in tests]
-    assert len(symbols) >= 110 and not missing, missing
+    assert len(symbols) >= 109 and not missing, missing
     # ... and has its reference-side binding (the ccall signature) in INTEGRATION.md (tools/gen_integration_table.py regenerates the appendix)
     integration = open(os.path.join(root, "INTEGRATION.md")).read()
     unbound = [s for s in symbols if f"(:{s}, libocn)" not in integration]
