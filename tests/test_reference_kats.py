@@ -557,3 +557,28 @@ def test_grid_lengths_areas_and_volumes_of_test_operators(ocn_host, oracle):
     for dx, dy, dz in ((g.Δxᶜᵃᵃ, g.Δyᵃᶜᵃ, float(g.Δzᵃᵃᶜ[g.Hz])), (go.dc[0][1], go.dc[1][1], go.dc[2][1])):
         assert (dx, dy, dz) == (pi, 2 * pi, 3 * pi)
         assert dy * dz == 6 * pi ** 2 and dx * dz == 3 * pi ** 2 and dx * dy == 2 * pi ** 2 and (dx * dy) * dz == 6 * pi ** 3
+
+
+def test_grid_reconstruction_from_constructor_arguments(ocn_host):
+    """test/test_grid_reconstruction.jl:12-45 (regular RectilinearGrid) and :47-95 with the stretched direction this library takes (z as a
+    function): the grid rebuilt from constructor_arguments(grid) -- what with_halo / on_architecture use (rectilinear_grid.jl:404-449) --
+    has the same size, halo, spacings and face / centre coordinates"""
+    ocn = ocn_host
+    P, B = ocn.Periodic, ocn.Bounded
+    pi = np.pi
+    originals = [ocn.RectilinearGrid(None, size=(4, 6, 8), extent=(2 * pi, 3 * pi, 4 * pi), topology=(P, B, B), halo=(2, 3, 2)),
+                 ocn.RectilinearGrid(None, size=(8, 4, 8), x=(0, 1), y=(0, 1), z=lambda k: -1.0 + (k - 1) / 8, topology=(B, B, B), halo=(1, 1, 1))]
+    for g in originals:
+        r = ocn.with_halo(g.halo_size, g)
+        assert r is not g and r.size == g.size and r.halo_size == g.halo_size and r.topology == g.topology
+        assert (r.Δxᶠᵃᵃ, r.Δyᵃᶠᵃ) == (g.Δxᶠᵃᵃ, g.Δyᵃᶠᵃ) and np.array_equal(r.Δzᵃᵃᶠ, g.Δzᵃᵃᶠ) and np.array_equal(r.Δzᵃᵃᶜ, g.Δzᵃᵃᶜ)
+        import unicodedata
+        for name in ("xᶠᵃᵃ", "xᶜᵃᵃ", "yᵃᶠᵃ", "yᵃᶜᵃ", "zᵃᵃᶠ", "zᵃᵃᶜ"):
+            key = unicodedata.normalize("NFKC", name)             # Python normalises identifiers: the attribute written .xᶠᵃᵃ is stored under this key
+            assert np.array_equal(getattr(r, key), getattr(g, key)), name
+        bigger = ocn.with_halo((4, 4, 4), g)                      # with_halo: the same interior nodes under another halo, to the round-off of
+        # a range that starts elsewhere (the node coordinates are Julia ranges over F- .. F+, which move with the halo)
+        assert bigger.halo_size == (4, 4, 4)
+        for loc in ((ocn.Center,) * 3, (ocn.Face,) * 3):
+            for a, b in zip(bigger.nodes(loc), g.nodes(loc)):
+                assert np.allclose(a, b, rtol=4 * np.finfo(float).eps, atol=4 * np.finfo(float).eps)
