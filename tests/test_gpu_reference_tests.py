@@ -808,3 +808,39 @@ def test_stratified_fluid_remains_at_rest(ocn, arch):
     dbdz, dbdy = np.diff(b, axis=2) / dz, np.diff(b, axis=1) / dz
     assert np.allclose(dbdz, N2, rtol=SQRT_EPS, atol=0) and abs(dbdz.mean() - N2) <= SQRT_EPS * N2 and np.all(dbdy == 0)
     assert all(np.all(model.fields()[n].interior() == 0) for n in "uvw")
+
+
+def test_thermal_bubble_checkpointer(ocn, arch, tmp_path):
+    """test_thermal_bubble_checkpointer_output + run_checkpointer_tests (test/test_checkpointer.jl:60-79,94-130): 16^3 on 100^3,
+    ScalarDiffusivity(ν = κ = 4e-2), SeawaterBuoyancy, a 0.01 K cube in the middle half, Δt = 6: run 5 iterations, checkpoint, run 4 more;
+    `set!(test_model, checkpoint)` gives a model equal to the checkpointed one (clock ==, fields ≈) and, stepped to iteration 9, equal to
+    the uninterrupted run. (The container is this repository's .npz with the reference's addresses, checkpointer.py; the Simulation /
+    pickup plumbing around it is the reference's host code.)"""
+    def make():
+        grid = ocn.RectilinearGrid(arch, size=(16, 16, 16), extent=(100, 100, 100), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        return ocn.NonhydrostaticModel(grid=grid, closure=ocn.ScalarDiffusivity(ν=4e-2, κ=4e-2), buoyancy=ocn.SeawaterBuoyancy(), tracers=("T", "S"))
+    true_model, test_model = make(), make()
+    T = true_model.fields()["T"]
+    a = T.interior()
+    a[3:12, 3:12, 3:12] += 0.01                                   # view(T, i1:i2, j1:j2, k1:k2) .+= 0.01 with i1, i2 = 4, 12
+    T.set(a)
+    ocn.update_state(true_model)
+    dt = 6.0
+    for _ in range(5):
+        ocn.time_step(true_model, dt)
+    path = ocn.write_checkpoint(true_model, str(tmp_path / "checkpoint_iteration5"))
+    at5 = {n: f.parent() for n, f in true_model.fields().items()}
+    clock5 = (true_model.clock.iteration, true_model.clock.time)
+    for _ in range(4):
+        ocn.time_step(true_model, dt)
+    ocn.set_from_checkpoint(test_model, path)
+    assert (test_model.clock.iteration, test_model.clock.time) == clock5 == (5, 30.0)
+    close = lambda x, y: np.all(np.abs(x - y) <= SQRT_EPS * np.maximum(np.abs(x), np.abs(y)))      # noqa: E731  elementwise ≈
+    for n, f in test_model.fields().items():
+        assert np.array_equal(f.parent(), at5[n]), n
+    for _ in range(4):
+        ocn.time_step(test_model, dt)
+    assert (test_model.clock.iteration, test_model.clock.time) == (true_model.clock.iteration, true_model.clock.time) == (9, 54.0)
+    for n, f in test_model.fields().items():
+        assert close(f.interior(), true_model.fields()[n].interior()), n
+    assert np.abs(true_model.fields()["w"].interior()).max() > 0          # the bubble did start to rise
