@@ -322,7 +322,8 @@ int ocn_model_set_option(ocn_model_t model, const char *key, int value);
  * option "fuse_substep" = 1 (default), fused kernel, tendencies cached by pointer swap, no Flux boundary condition) */
 int ocn_model_get_option(ocn_model_t model, const char *key, int *value);
 /* boundary_conditions = (name = FieldBoundaryConditions(side = BoundaryCondition(kind, value)),) of the model
- * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0"..; side 0..5 = west .. top. OCN_EINVAL mirrors
+ * constructor (nonhydrostatic_model.jl:115-244); name "u","v","w","c0".. and, with an LES closure, the diffusivity fields "nu_e",
+ * "kappa_e0".. (Value / Gradient; boundary_conditions = (κₑ = (b = ...,),)); side 0..5 = west .. top. OCN_EINVAL mirrors
  * the reference's validation: Bounded sides only; Flux/Value/Gradient on Center-located, Open on Face-located fields */
 /* buoyancy = nothing (kind 0) | BuoyancyTracer() (kind 1, tracer index) | SeawaterBuoyancy(LinearEquationOfState(α, β), g)
  * (kind 2, tracer indices of T and S). With buoyancy the model carries the hydrostatic pressure anomaly, field name "pHY"

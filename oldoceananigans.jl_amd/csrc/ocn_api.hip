@@ -2153,6 +2153,8 @@ struct ocn_model_s {
     int graph_replays = 0, graph_captures = 0, graph_failures = 0;
     int loc[OCN_MAX_FIELDS][3];
     ocn_bc_t bcs[OCN_MAX_FIELDS][6] = {};   // field boundary conditions (default: field_boundary_conditions.jl:15-25)
+    ocn_bc_t kbcs[OCN_MAX_FIELDS][6] = {};  // ... of the diffusivity fields: [0] = νₑ, [1 + t] = κₑ of tracer t (boundary_conditions = (κₑ = (b = ...,),))
+    bool any_kbc = false;
     bool any_bc = false, any_flux_bc = false;
     struct LinBC { bool on = false; int dep = 0; double a = 0.0, b = 0.0; } lin[OCN_MAX_FIELDS][6];   // linear field-dependent Flux
     bool any_linear_flux = false;
@@ -2438,7 +2440,7 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
         K[0] = m->nu_e;
         for (int t = 0; t < m->ntr; ++t) K[1 + t] = m->kappa_e[t];
         for (int q = 0; q < 1 + m->ntr; ++q) memcpy(kl[q], LOC_C, sizeof(int) * 3);
-        if ((rc = fill_halo_regions(m->grid, K, kl, 1 + m->ntr, true))) return rc;
+        if ((rc = fill_halo_regions(m->grid, K, kl, 1 + m->ntr, true, m->any_kbc ? m->kbcs : nullptr))) return rc;
     }
     // compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69)
     if (m->buoyancy_kind &&
@@ -2634,6 +2636,23 @@ extern "C" int ocn_model_set_amd(ocn_model_t m, double Cnu, const double *Ckappa
 static int model_set_bc(ocn_model_t m, const char *name, int side, int kind, double value, const double *array) {
     if (m) m->epoch += 1;
     if (!m || !name) return fail(OCN_EINVAL, "NULL argument");
+    // the diffusivity fields of an LES closure carry boundary conditions too (anisotropic_minimum_dissipation.jl:339-352: νₑ, κₑ are
+    // CenterFields built with the conditions the user passes as boundary_conditions = (νₑ = ..., κₑ = (b = ...,))); their halos are
+    // filled with them after compute_diffusivities!
+    if (!strcmp(name, "nu_e") || (!strncmp(name, "kappa_e", 7) && name[7] >= '0' && name[7] <= '9' && !name[8])) {
+        const int q = name[0] == 'n' ? 0 : 1 + (name[7] - '0');
+        if (q > m->ntr) return fail(OCN_EINVAL, "no tracer %d", q - 1);
+        if (kind == OCN_BC_FLUX || kind == OCN_BC_OPEN) return fail(OCN_EINVAL, "a diffusivity field takes Value or Gradient conditions");
+        int rcq = validate_bc(m->grid->d, LOC_C, side, kind);
+        if (rcq) return rcq;
+        m->kbcs[q][side].kind = kind;
+        m->kbcs[q][side].value = value;
+        m->kbcs[q][side].array = array;
+        m->any_kbc = false;
+        for (int a = 0; a <= m->ntr; ++a)
+            for (int sd = 0; sd < 6; ++sd) m->any_kbc = m->any_kbc || m->kbcs[a][sd].kind != OCN_BC_DEFAULT;
+        return OCN_OK;
+    }
     int f = -1;
     if (!strcmp(name, "u")) f = 0;
     else if (!strcmp(name, "v")) f = 1;

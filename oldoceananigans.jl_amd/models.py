@@ -118,22 +118,40 @@ class NonhydrostaticModel:
         # 163-190): constant Flux / Value / Gradient / Open conditions on Bounded sides
         self.boundary_conditions = dict(boundary_conditions or {})
         from .boundary_conditions import KINDS, SIDES
+        import unicodedata
+        targets = []                                     # (library field name, FieldBoundaryConditions)
         for name, fbcs in self.boundary_conditions.items():
+            key = unicodedata.normalize("NFKC", name)
+            if key in ("νe", "nu_e", "κe", "kappa_e"):
+                # boundary_conditions = (νₑ = FieldBoundaryConditions(...), κₑ = (b = FieldBoundaryConditions(...),)): the diffusivity
+                # fields of an LES closure (anisotropic_minimum_dissipation.jl:339-352)
+                if self.diffusivity_fields is None:
+                    raise ValueError(f"boundary conditions given for {name}, but the closure has no diffusivity fields")
+                if key in ("νe", "nu_e"):
+                    targets.append(("nu_e", fbcs))
+                else:
+                    for tracer, tb in dict(fbcs).items():
+                        if tracer not in self.tracer_names:
+                            raise ValueError(f"κₑ boundary conditions given for {tracer}, which is not a tracer of the model")
+                        targets.append(("kappa_e%d" % self.tracer_names.index(tracer), tb))
+                continue
             if name not in ("u", "v", "w") + self.tracer_names:
                 raise ValueError(f"boundary conditions given for {name}, which is not a velocity or tracer of the model")
+            targets.append((self._cname(name), fbcs))
+        for cname, fbcs in targets:
             for side, bc in fbcs.sides.items():
                 if bc.linear is not None:
                     a, b, dep = bc.linear
-                    _lib.check(_lib.lib().ocn_model_set_linear_flux_bc(self.handle, self._cname(name).encode(), SIDES.index(side), a, b,
+                    _lib.check(_lib.lib().ocn_model_set_linear_flux_bc(self.handle, cname.encode(), SIDES.index(side), a, b,
                                                                        self._cname(dep).encode()))
                     continue
                 if bc.array is not None:
                     from .boundary_conditions import _tangential_shape
                     dev = bc.device_array(_tangential_shape(self.grid, SIDES.index(side)))      # borrowed by the library: `bc` is kept
-                    _lib.check(_lib.lib().ocn_model_set_boundary_condition_array(self.handle, self._cname(name).encode(), SIDES.index(side),
+                    _lib.check(_lib.lib().ocn_model_set_boundary_condition_array(self.handle, cname.encode(), SIDES.index(side),
                                                                                  KINDS[bc.classification], dev))
                     continue
-                _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, self._cname(name).encode(), SIDES.index(side),
+                _lib.check(_lib.lib().ocn_model_set_boundary_condition(self.handle, cname.encode(), SIDES.index(side),
                                                                        KINDS[bc.classification], bc.condition))
 
     def _create_handle(self, grid, ntracers):

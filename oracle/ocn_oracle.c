@@ -1272,6 +1272,7 @@ struct oro_model {
     double *Gm[3 + ORO_MAXTR];
     int loc[3 + ORO_MAXTR][3];
     oro_bc bcs[3 + ORO_MAXTR][6];
+    oro_bc kbcs[1 + ORO_MAXTR][6];   /* conditions of the diffusivity fields: [0] = nu_e, [1 + t] = kappa_e of tracer t */
     int any_flux_bc;
     struct { int on, dep; double a, b; } lin[3 + ORO_MAXTR][6];   /* linear field-dependent Flux conditions */
     int has_closure;
@@ -1373,6 +1374,14 @@ int oro_model_set_bc_array(oro_model *m, const char *name, int side, int kind, c
     return array ? model_set_bc(m, name, side, kind, 0.0, array) : -1;
 }
 static int model_set_bc(oro_model *m, const char *name, int side, int kind, double value, const double *array) {
+    if (!strcmp(name, "nu_e") || (!strncmp(name, "kappa_e", 7) && name[7] >= '0' && name[7] <= '9' && !name[8])) {
+        /* diffusivity fields are CenterFields with user conditions (anisotropic_minimum_dissipation.jl:339-352) */
+        const int q = name[0] == 'n' ? 0 : 1 + (name[7] - '0');
+        if (q > m->ntr || side < 0 || side > 5 || m->g->topo[side / 2] != ORO_BOUNDED) return -1;
+        if (kind != ORO_BC_DEFAULT && kind != ORO_BC_VALUE && kind != ORO_BC_GRADIENT) return -1;
+        m->kbcs[q][side].kind = kind; m->kbcs[q][side].value = value; m->kbcs[q][side].array = array;
+        return 0;
+    }
     char k;
     int f = field_index(m, name, &k);
     if (f < 0 || k != 'U' || side < 0 || side > 5) return -1;
@@ -1437,8 +1446,8 @@ void oro_model_update_state(oro_model *m, int compute_tendencies) {
     if (m->has_amd) {
         oro_compute_amd_diffusivities(g, m->Cnu, m->Ckappa, m->U[0], m->U[1], m->U[2], (const double *const *)(m->U + 3), m->ntr,
                                       m->nu_e, m->kappa_e);
-        oro_fill_halo_regions(g, m->nu_e, LOC_C, 1);
-        for (int t = 0; t < m->ntr; ++t) oro_fill_halo_regions(g, m->kappa_e[t], LOC_C, 1);
+        oro_fill_halo_regions_bcs(g, m->nu_e, LOC_C, m->kbcs[0], 1);
+        for (int t = 0; t < m->ntr; ++t) oro_fill_halo_regions_bcs(g, m->kappa_e[t], LOC_C, m->kbcs[1 + t], 1);
     }
     if (m->buoyancy_kind == 1)
         oro_update_hydrostatic_pressure(g, 1, m->U[3 + m->b_index], NULL, 0, 0, 0, m->pHY);

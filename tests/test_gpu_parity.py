@@ -1175,3 +1175,46 @@ def test_mid_size_parity_with_the_oracle(ocn, oracle, arch, size, topology):
             continue
         assert rel_err(ia, ib) < 1e-12, (name, size, rel_err(ia, ib))
     assert ocn.max_abs_divergence(m_gpu) < 5e-8
+
+
+def test_boundary_conditions_on_the_diffusivity_fields_match_oracle(ocn, oracle, arch):
+    """boundary_conditions = (νₑ = ..., κₑ = (T = ...,)) of an AnisotropicMinimumDissipation model (anisotropic_minimum_dissipation.jl:
+    339-352: the diffusivity fields are CenterFields built with the user's conditions, filled after compute_diffusivities!): Value and
+    Gradient conditions at bottom / top; diffusivity fields with their halos and the tendencies bit-identical to the oracle, 5 steps 1e-12.
+    The reference's own test of this feature runs in tests/test_gpu_reference_tests.py (fluxes_with_diffusivity_boundary_conditions)."""
+    size = (12, 10, 8)
+    z = tanh_faces(size[2])
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    g_cpu = oracle.Grid(size, topology=(0, 0, 1), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    F = ocn.FieldBoundaryConditions
+    bcs = {"νₑ": F(bottom=ocn.ValueBoundaryCondition(2e-3)), "κₑ": {"T": F(bottom=ocn.ValueBoundaryCondition(5e-3), top=ocn.GradientBoundaryCondition(-1e-2))},
+           "T": F(bottom=ocn.GradientBoundaryCondition(0.4))}
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T", "S"), closure=ocn.AnisotropicMinimumDissipation(), boundary_conditions=bcs)
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_amd(C=1 / 3, Ckappa=[1 / 3, 1 / 3])
+    m_cpu.set_bc("nu_e", "bottom", "value", 2e-3)
+    m_cpu.set_bc("kappa_e0", "bottom", "value", 5e-3)
+    m_cpu.set_bc("kappa_e0", "top", "gradient", -1e-2)
+    m_cpu.set_bc("c0", "bottom", "gradient", 0.4)
+    set_both(ocn, m_gpu, m_cpu, seed=8, enforce_incompressibility=False)
+    for fused in (1, 0):
+        m_gpu.set_option("fused_epilogue", fused)
+        ocn.update_state(m_gpu, True)
+        m_cpu.update_state(True)
+        D = m_gpu.diffusivity_fields
+        assert np.array_equal(D[0].parent(), m_cpu.field("nu_e")) and np.array_equal(D[1][0].parent(), m_cpu.field("kappa_e0"))
+        assert np.array_equal(D[1][1].parent(), m_cpu.field("kappa_e1"))
+        nu = D[0].parent()
+        assert np.allclose(0.5 * (nu[3:-3, 3:-3, 2] + nu[3:-3, 3:-3, 3]), 2e-3, rtol=1e-14)        # the Value condition sits on the bottom face
+        for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (n, fused)
+    m_gpu.set_option("fused_epilogue", 1)
+    set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+    dt = 0.05 * min(g_gpu.Δxᶜᵃᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))) / 0.6
+    for _ in range(5):
+        ocn.time_step(m_gpu, dt)
+        m_cpu.time_step(dt)
+    for name, a, b in field_pairs(m_gpu, m_cpu):
+        assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, name
+    with pytest.raises(ocn.OcnError):
+        ocn.NonhydrostaticModel(grid=g_gpu, closure=ocn.AnisotropicMinimumDissipation(), boundary_conditions={"νₑ": F(bottom=ocn.FluxBoundaryCondition(1.0))})

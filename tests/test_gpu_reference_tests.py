@@ -844,3 +844,45 @@ def test_thermal_bubble_checkpointer(ocn, arch, tmp_path):
     for n, f in test_model.fields().items():
         assert close(f.interior(), true_model.fields()[n].interior()), n
     assert np.abs(true_model.fields()["w"].interior()).max() > 0          # the bubble did start to rise
+
+
+def test_fluxes_with_diffusivity_boundary_conditions_are_correct(ocn, arch):
+    """fluxes_with_diffusivity_boundary_conditions_are_correct (test_boundary_conditions_integration.jl:54-103): 16^3 on the unit cube,
+    QuasiAdamsBashforth2 (Euler first step), BuoyancyTracer, AnisotropicMinimumDissipation; b = π z with a Gradient condition π at the
+    bottom and a VALUE condition κ₀ = e^{-3} at the bottom of the eddy diffusivity field κₑ.b (boundary_conditions = (b = ..., κₑ = (b =
+    ...,))): nothing moves, κₑ = 0 inside, the only flux is -κ₀ π through the bottom, so <b> - <b>₀ = flux t / Lz (atol 1e-6 in the
+    reference). The reference's comment also records its own Float64 run: mean_b₀ = -1.5707963267949192, mean(b) - mean_b₀ =
+    -3.141592656086267e-5 against flux t / Lz = -3.141592653589793e-5 -- numbers of an actual reference run of this path."""
+    Lz, kappa0, bz = 1.0, float(np.exp(-3)), float(np.pi)
+    flux = -kappa0 * bz
+    grid = ocn.RectilinearGrid(arch, size=(16, 16, 16), extent=(1, 1, Lz), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    F = ocn.FieldBoundaryConditions
+    bcs = {"b": F(bottom=ocn.GradientBoundaryCondition(bz)), "κₑ": {"b": F(bottom=ocn.ValueBoundaryCondition(kappa0))}}
+    model = ocn.NonhydrostaticModel(grid=grid, timestepper="QuasiAdamsBashforth2", tracers=("b",), buoyancy=ocn.BuoyancyTracer(),
+                                    closure=ocn.AnisotropicMinimumDissipation(), boundary_conditions=bcs)
+    ocn.set_model(model, b=lambda x, y, z: z * bz + 0 * (x + y))
+    b = model.fields()["b"]
+
+    def julia_mean(a):
+        """mean(::Field) as the reference evaluates it: a sequential left fold over the interior in column-major order (it reproduces the
+        recorded mean_b₀ to the last digit; numpy's pairwise mean gives -1.5707963267948968)"""
+        total = 0.0
+        for v in np.asarray(a).ravel(order="F"):
+            total += float(v)
+        return total / a.size
+    mean0 = julia_mean(b.interior())
+    dt = 1e-6 * (Lz ** 2 / kappa0)
+    for n in range(10):
+        ocn.time_step(model, dt, euler=(n == 0))
+    mean1 = julia_mean(b.interior())
+    change = mean1 - mean0
+    expected = flux * model.clock.time / Lz
+    assert abs(change - expected) <= 1e-6                                                   # the reference's assertion
+    # ... and the reference's own recorded Float64 run (comment at :88-93)
+    # mean_b₀ to the last digit (the sixteen level values π z_k are bit for bit the reference's: Julia-range z nodes), the exact budget,
+    # and the recorded final mean / change to within the round-off of that 4096-term sequential sum (its error is -2.3e-14 on the initial
+    # field and depends on the last bits of every addend: the recorded change is itself 2.5e-14 off the exact budget)
+    assert mean0 == -1.5707963267949192 and expected == -3.141592653589793e-5
+    assert abs(mean1 - (-1.57082774272148)) < 1e-13 and abs(change - (-3.141592656086267e-5)) < 5e-14, (repr(mean1), repr(change))
+    assert abs(float(np.mean(b.interior())) - (-np.pi / 2 + expected)) < 1e-15          # pairwise mean: the budget to round-off
+    assert all(np.all(model.fields()[n].interior() == 0) for n in "uvw")
