@@ -479,3 +479,26 @@ def test_reference_distributed_fourier_tridiagonal_solver_cases(ocn, arch):
     _own_stream()
     for size, partition in _REF_TRI_CASES:
         _reference_distributed_poisson_case(ocn, arch, size, partition, ("Bounded", "Bounded", "Bounded"), True)
+
+
+def test_library_partition_with_conditions_on_the_diffusivity_fields(ocn, arch, monkeypatch):
+    """the configs[4] physics with Value conditions on νₑ and κₑ.T at the bottom (boundary_conditions = (νₑ = ..., κₑ = (T = ...,))) on
+    four x-slabs: the diffusivity fields are filled with their conditions on every rank (z sides) while their x halos are evaluated from
+    the exchanged fields -- against the single-GPU model"""
+    import test_gpu_dist_library as me
+    base = me._bcs
+
+    def with_kbcs(ocn_, zkind):
+        b = dict(base(ocn_, zkind))
+        F = ocn_.FieldBoundaryConditions
+        b["νₑ"] = F(bottom=ocn_.ValueBoundaryCondition(1e-3))
+        b["κₑ"] = {"T": F(bottom=ocn_.ValueBoundaryCondition(2e-3))}
+        return b
+    monkeypatch.setattr(me, "_bcs", with_kbcs)
+    _own_stream()
+    R, size, nsteps = 4, (32, 12, 10), 3
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, "amd", {})
+    ref, time, _ = _single_gpu(ocn, arch, size, "amd", nsteps)
+    for r, (out, div, t, _off) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, size[0] // R, size)
