@@ -601,6 +601,10 @@ class DistributedNonhydrostaticModel:
             self.backend.set_buoyancy(buoyancy, self.tracer_names)
         if boundary_conditions:
             names = ["u", "v", "w"] + list(self.tracer_names)
+            unknown = [n for n in boundary_conditions if n not in names]
+            if unknown:          # e.g. conditions on the diffusivity fields (νₑ, κₑ): the library-resident model carries them
+                raise NotImplementedError(f"boundary conditions for {unknown}: use LibraryDistributedModel (the host-orchestrated model "
+                                          "takes conditions on velocities and tracers only)")
             self.backend.set_boundary_conditions({names.index(n): fb for n, fb in boundary_conditions.items()})
 
     @property
