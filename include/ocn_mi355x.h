@@ -349,7 +349,12 @@ int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, 
  *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform);
  *   fused tendency kernel: "fused_ty" (tile rows 3 | 7), "fused_kchunk" (levels per workgroup, 0 = automatic), "fused_minw",
  *     "fused_zwin" (register z-windows), "fused_lds" (LDS-tile variant), "fused_xcd" (XCD-aware tile order; measured: no effect);
- *   halo fills: "fused_halo" (one launch per periodic fill).
+ *   halo fills: "fused_halo" (one launch per periodic fill);
+ *   "arithmetic": 0 (default) the reference's IEEE operation sequence in every kernel -- results bit-identical to a faithful CPU
+ *     evaluation of weno_interpolants.jl; 1 the opt-in CONTRACTED WENO-5 flux of the flux-sharing tendency kernel (fma-contracted
+ *     sub-stencil polynomials and alpha weights, one normalisation of the weighted sum, reciprocal without the IEEE divide's fix-up,
+ *     advecting transport multiplied by the area after its interpolation): fewer FP64 instructions, fields within 1e-12 of mode 0
+ *     on O(1) data but not bit-identical.
  * Model options (ocn_model_set_option): "tendency_impl" (1 fused, 0 per-field kernels), "swap_tendencies", "fuse_substep",
  * "fused_epilogue", "use_graph" (hipGraph replay of the RK3 step; measured: no gain, default 0), "profile". */
 int ocn_set_option(const char *key, int value);
@@ -405,6 +410,10 @@ typedef struct {
 int ocn_dist_create_transport(ocn_dist_t *dist, const ocn_transport_t *transport, int world, int rank);
 int ocn_dist_destroy(ocn_dist_t dist);
 int ocn_dist_info(ocn_dist_t dist, int *world, int *rank, int *west, int *east);
+/* what the TRANSPORT reports: kind 0 = the library's RCCL communicator (comm_ranks / comm_rank / device from ncclCommCount /
+ * ncclCommUserRank / ncclCommCuDevice -- the ranks RCCL really connected, MPI.Comm_size / Comm_rank of the reference's communicator,
+ * distributed_architectures.jl:262-263), 1 = caller-supplied collectives (the numbers given at creation) */
+int ocn_dist_comm_info(ocn_dist_t dist, int *kind, int *comm_ranks, int *comm_rank, int *device);
 /* MEASUREMENT / TEST ONLY: a communicator of ONE rank treats x as partitioned with itself as both neighbours, so the complete
  * N > 1 code path runs (and can be timed) on a one-GPU box; results equal the one-rank Periodic run. Set before model creation. */
 int ocn_dist_set_self_loop(ocn_dist_t dist, int enabled);

@@ -54,6 +54,7 @@ SYMBOLS = {
     "ocn_dist_create_transport": (C.c_int, [_pp, C.POINTER(Transport), C.c_int, C.c_int]),
     "ocn_dist_destroy": (C.c_int, [_vp]),
     "ocn_dist_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "ocn_dist_comm_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "ocn_dist_set_self_loop": (C.c_int, [_vp, C.c_int]),
     "ocn_dist_exchange_start": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_size_t]),
     "ocn_dist_exchange_wait": (C.c_int, [_vp]),

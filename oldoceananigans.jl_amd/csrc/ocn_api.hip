@@ -2297,6 +2297,9 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "tendency_impl")) { if (value < 0 || value > 2) return fail(OCN_EINVAL, "tendency_impl is 0, 1 or 2"); g_tendency_impl = value; return OCN_OK; }
     if (!strcmp(key, "fused_ty")) { g_fused_ty = value; return OCN_OK; }
     if (!strcmp(key, "role_ldspad")) { g_role_ldspad = value; return OCN_OK; }
+    // 0: the reference's IEEE operation sequence (default); 1: the contracted WENO flux of the role kernel (ocn_device.h) -- opt-in,
+    // within north_star's 1e-12 of the default but not bit-identical to it; other tendency kernels ignore it
+    if (!strcmp(key, "arithmetic")) { if (value < 0 || value > 1) return fail(OCN_EINVAL, "arithmetic is 0 (reference sequence) or 1 (contracted)"); g_arithmetic = value; return OCN_OK; }
     if (!strcmp(key, "role_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "role_kchunk must be >= 0 (0 = automatic)"); g_role_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
@@ -2414,6 +2417,7 @@ extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) 
     if (!strcmp(key, "graph_failures")) { *value = m->graph_failures; return OCN_OK; }
     if (!strcmp(key, "fuse_substep")) { *value = m->fuse_substep; return OCN_OK; }
     if (!strcmp(key, "fuse_substep_active")) { *value = can_fuse_substep(m) ? 1 : 0; return OCN_OK; }
+    if (!strcmp(key, "arithmetic")) { *value = g_arithmetic; return OCN_OK; }
     if (!strcmp(key, "fused_tendency_active")) { *value = fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl) ? 1 : 0; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown model option '%s'", key);
 }

@@ -107,7 +107,26 @@ __device__ __forceinline__ double beta2(double p0, double p1, double C1, double 
     return __builtin_fma(p1 * p1, C3, p0 * in1);
 }
 
+// ---- arithmetic modes of the flux-sharing kernels (template parameter ARITH; option "arithmetic") ----
+// 0 (default, every parity test): the reference's operation sequence -- bit-identical to the oracle.
+// 1 (opt-in, "contracted"): the same formulas with the roundings north_star's 1e-12 tolerance leaves free removed from the
+//   instruction stream of WENO{3} -- (i) the sub-stencil polynomials `sum(coeff .* psi)` (weno_interpolants.jl:136-137) as fma chains,
+//   (ii) alpha = C (1 + r^2) (:290-297) as C * fma(r, r, 1), (iii) ONE normalisation: (sum alpha_r p_r) / (sum alpha_r) instead of
+//   three weights alpha_r * (1 / sum) (:336-337,500), (iv) that quotient through v_rcp_f64 + two Newton steps without the IEEE divide's
+//   residual fix-up, (v) the advecting transport of the momentum fluxes interpolated before it is multiplied by the (uniform) area.
+//   Smoothness indicators, tau, the Float32-reciprocal ratio with its Newton step and the upwind selection are untouched. Every change
+//   is a relative perturbation of a few 2^-53 of the flux; what it does to the fields is measured, not assumed
+//   (tests/test_gpu_arithmetic_mode.py).
+__device__ __forceinline__ double rcp_newton2_f64(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 // biased_interpolate for WENO{3} (weno_interpolants.jl:504-516); s0..s5 = psi[f-3 .. f+2]
+template <int ARITH = 0>
 __device__ __forceinline__ double weno5_biased(double s0, double s1, double s2, double s3, double s4, double s5, bool left) {
     // S₀₃, S₁₃, S₂₃ (:435-437): the right-biased stencils are the mirrored left-biased ones
     double a0 = left ? s2 : s3, a1 = left ? s3 : s2, a2 = left ? s4 : s1;   // stencil 0
@@ -120,6 +139,16 @@ __device__ __forceinline__ double weno5_biased(double s0, double s1, double s2, 
     double r0 = newton_div_f32(tau, be0 + OCN_WENO_EPS);
     double r1 = newton_div_f32(tau, be1 + OCN_WENO_EPS);
     double r2 = newton_div_f32(tau, be2 + OCN_WENO_EPS);
+    if (ARITH == 1) {
+        const double al0 = OCN_W3C0 * __builtin_fma(r0, r0, 1.0);
+        const double al1 = OCN_W3C1 * __builtin_fma(r1, r1, 1.0);
+        const double al2 = OCN_W3C2 * __builtin_fma(r2, r2, 1.0);
+        const double q0 = __builtin_fma(OCN_W3P02, a2, __builtin_fma(OCN_W3P01, a1, OCN_W3P00 * a0));
+        const double q1 = __builtin_fma(OCN_W3P12, b2, __builtin_fma(OCN_W3P11, b1, OCN_W3P10 * b0));
+        const double q2 = __builtin_fma(OCN_W3P22, c2, __builtin_fma(OCN_W3P21, c1, OCN_W3P20 * c0));
+        const double num = __builtin_fma(al2, q2, __builtin_fma(al1, q1, al0 * q0));
+        return num * rcp_newton2_f64((al0 + al1) + al2);
+    }
     double al0 = OCN_W3C0 * (1.0 + r0 * r0);
     double al1 = OCN_W3C1 * (1.0 + r1 * r1);
     double al2 = OCN_W3C2 * (1.0 + r2 * r2);
@@ -176,9 +205,10 @@ __device__ __forceinline__ double symmetric_interp(double q0, double q1, double 
 }
 
 // _biased_interpolate (WENO{3} -> WENO{2} -> UpwindBiased{1}); s0..s5 = psi[f-3 .. f+2]
+template <int ARITH = 0>
 __device__ __forceinline__ double biased_interp(double s0, double s1, double s2, double s3, double s4, double s5,
                                                 bool left, bool bounded, int i, bool center, int N, bool lo = true, bool hi = true) {
-    if (!bounded || outside_biased_halo(i, center, N, 3, lo, hi)) return weno5_biased(s0, s1, s2, s3, s4, s5, left);
+    if (!bounded || outside_biased_halo(i, center, N, 3, lo, hi)) return weno5_biased<ARITH>(s0, s1, s2, s3, s4, s5, left);
     if (outside_biased_halo(i, center, N, 2, lo, hi)) return weno3_biased(s1, s2, s3, s4, left);
     return left ? 1.0 * s2 : 1.0 * s3;
 }

@@ -29,6 +29,9 @@ struct RcclApi {
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;         // optional (ocn_dist_comm_info): what the communicator itself reports
+    int (*CommUserRank)(void *, int *) = nullptr;
+    int (*CommCuDevice)(void *, int *) = nullptr;
 };
 static RcclApi g_rccl;
 enum { OCN_NCCL_FLOAT64 = 8, OCN_NCCL_MAX = 2 };      // ncclDouble, ncclMax (rccl.h)
@@ -53,6 +56,9 @@ static int rccl_load() {
     OCN_RCCL_SYM(AllReduce, "ncclAllReduce");
     OCN_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef OCN_RCCL_SYM
+    *(void **)(&g_rccl.CommCount) = dlsym(h, "ncclCommCount");
+    *(void **)(&g_rccl.CommUserRank) = dlsym(h, "ncclCommUserRank");
+    *(void **)(&g_rccl.CommCuDevice) = dlsym(h, "ncclCommCuDevice");
     g_rccl.handle = h;
     return OCN_OK;
 }
@@ -60,6 +66,16 @@ static int rccl_load() {
     do {                                                                                                         \
         int _r = (call);                                                                                         \
         if (_r != 0) return fail(1000 + _r, "%s: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?"); \
+    } while (0)
+// inside ncclGroupStart / ncclGroupEnd: a failing call must not leave the group open (the communicator would swallow every later call
+// into it): close the group, then report the FIRST error
+#define NCCL_TRY_IN_GROUP(call)                                                                                  \
+    do {                                                                                                         \
+        int _r = (call);                                                                                         \
+        if (_r != 0) {                                                                                           \
+            g_rccl.GroupEnd();                                                                                   \
+            return fail(1000 + _r, "%s: %s", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(_r) : "?");    \
+        }                                                                                                        \
     } while (0)
 
 struct ocn_dist_s {
@@ -152,6 +168,25 @@ extern "C" int ocn_dist_set_self_loop(ocn_dist_t d, int enabled) {
     return OCN_OK;
 }
 
+// What the TRANSPORT itself reports (bench.py prints it next to n_gpus): kind 0 = the library's RCCL communicator -- comm_ranks /
+// comm_rank / device from ncclCommCount / ncclCommUserRank / ncclCommCuDevice, i.e. the ranks RCCL really connected, not the numbers the
+// caller passed in; kind 1 = caller-supplied collectives (world / rank as given, device = the library's current device).
+extern "C" int ocn_dist_comm_info(ocn_dist_t d, int *kind, int *comm_ranks, int *comm_rank, int *device) {
+    if (!d) return fail(OCN_EINVAL, "NULL argument");
+    int n = d->world, r = d->rank, dev = -1;
+    hipGetDevice(&dev);
+    if (d->kind == 0 && d->comm) {
+        if (g_rccl.CommCount) NCCL_TRY(g_rccl.CommCount(d->comm, &n));
+        if (g_rccl.CommUserRank) NCCL_TRY(g_rccl.CommUserRank(d->comm, &r));
+        if (g_rccl.CommCuDevice) NCCL_TRY(g_rccl.CommCuDevice(d->comm, &dev));
+    }
+    if (kind) *kind = d->kind;
+    if (comm_ranks) *comm_ranks = n;
+    if (comm_rank) *comm_rank = r;
+    if (device) *device = dev;
+    return OCN_OK;
+}
+
 extern "C" int ocn_dist_info(ocn_dist_t d, int *world, int *rank, int *west, int *east) {
     if (!d) return fail(OCN_EINVAL, "NULL argument");
     if (world) *world = d->world;
@@ -184,10 +219,10 @@ static int dist_exchange_pair(ocn_dist_t d, int peer_lo, int peer_hi, const doub
         return rc ? fail(rc, "transport exchange_peers failed") : OCN_OK;
     }
     NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.Send(lo_send, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
-    NCCL_TRY(g_rccl.Recv(hi_recv, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
-    NCCL_TRY(g_rccl.Send(hi_send, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
-    NCCL_TRY(g_rccl.Recv(lo_recv, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Send(lo_send, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(hi_recv, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Send(hi_send, count, OCN_NCCL_FLOAT64, peer_hi, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(lo_recv, count, OCN_NCCL_FLOAT64, peer_lo, d->comm, g_stream));
     NCCL_TRY(g_rccl.GroupEnd());
     return OCN_OK;
 }
@@ -210,10 +245,10 @@ extern "C" int ocn_dist_exchange_start(ocn_dist_t d, const double *west_send, co
     // one group: the pairing is unambiguous even when both neighbours are the same rank (R = 2) or this rank itself (R = 1) --
     // what leaves through the west side arrives in the west neighbour's EAST halo
     NCCL_TRY(g_rccl.GroupStart());
-    NCCL_TRY(g_rccl.Send(west_send, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
-    NCCL_TRY(g_rccl.Recv(east_recv, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
-    NCCL_TRY(g_rccl.Send(east_send, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
-    NCCL_TRY(g_rccl.Recv(west_recv, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Send(west_send, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(east_recv, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Send(east_send, count, OCN_NCCL_FLOAT64, d->east, d->comm, d->comm_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(west_recv, count, OCN_NCCL_FLOAT64, d->west, d->comm, d->comm_stream));
     NCCL_TRY(g_rccl.GroupEnd());
     HIP_TRY(hipEventRecord(d->done, d->comm_stream));
     d->in_flight = true;
@@ -244,8 +279,8 @@ extern "C" int ocn_dist_all_to_all(ocn_dist_t d, const double *send, double *rec
     }
     NCCL_TRY(g_rccl.GroupStart());
     for (int r = 0; r < d->world; ++r) {
-        NCCL_TRY(g_rccl.Send(send + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
-        NCCL_TRY(g_rccl.Recv(recv + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
+        NCCL_TRY_IN_GROUP(g_rccl.Send(send + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
+        NCCL_TRY_IN_GROUP(g_rccl.Recv(recv + (size_t)r * count_per_rank, count_per_rank, OCN_NCCL_FLOAT64, r, d->comm, g_stream));
     }
     NCCL_TRY(g_rccl.GroupEnd());
     return OCN_OK;

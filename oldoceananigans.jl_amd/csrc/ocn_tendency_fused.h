@@ -63,15 +63,19 @@ __device__ __forceinline__ Win6 load_win(const double *base, unsigned o, unsigne
     return w;
 }
 
+template <int ARITH = 0>
 __device__ __forceinline__ double sym4(const Win6 &q, double a, bool bounded, int idx, bool center, int N) {
+    // ARITH 1 (ocn_device.h): one multiplication by the uniform area after the interpolation instead of four before it
+    if (ARITH == 1) return a * symmetric_interp(q.s[1], q.s[2], q.s[3], q.s[4], bounded, idx, center, N);
     return symmetric_interp(a * q.s[1], a * q.s[2], a * q.s[3], a * q.s[4], bounded, idx, center, N);
 }
 // symmetric interpolation along z: per-level area factors a[k-2 .. k+1]
 __device__ __forceinline__ double sym4z(const Win6 &q, const double *a, bool bounded, int idx, bool center, int N) {
     return symmetric_interp(a[0] * q.s[1], a[1] * q.s[2], a[2] * q.s[3], a[3] * q.s[4], bounded, idx, center, N);
 }
+template <int ARITH = 0>
 __device__ __forceinline__ double bias6(const Win6 &s, bool left, bool bounded, int idx, bool center, int N) {
-    return biased_interp(s.s[0], s.s[1], s.s[2], s.s[3], s.s[4], s.s[5], left, bounded, idx, center, N);
+    return biased_interp<ARITH>(s.s[0], s.s[1], s.s[2], s.s[3], s.s[4], s.s[5], left, bounded, idx, center, N);
 }
 
 // The low-side fluxes of cell (i, j, k) (reference: upwind_biased_advective_fluxes.jl:23-121):

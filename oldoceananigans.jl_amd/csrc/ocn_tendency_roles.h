@@ -141,22 +141,22 @@ template <int ROLE> __device__ __forceinline__ Win6 load_zin(const PlaneCtx &p, 
     if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.w, o.c, so);
     return w;
 }
-template <int ROLE>
+template <int ROLE, int ARITH>
 __device__ __forceinline__ double z_flux(const DGrid &g, const Win6 &zin, int i, int j, int k, const Win6 &qz) {
     const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
     const double az = g.az;
     if (ROLE == ROLE_U) {
-        const double wt = sym4(zin, az, bx, i, false, g.Nx);                         // advective_momentum_flux_Wu :39-45
-        return wt * bias6(qz, wt > 0, bz, k, false, g.Nz);
+        const double wt = sym4<ARITH>(zin, az, bx, i, false, g.Nx);                         // advective_momentum_flux_Wu :39-45
+        return wt * bias6<ARITH>(qz, wt > 0, bz, k, false, g.Nz);
     } else if (ROLE == ROLE_V) {
-        const double wt = sym4(zin, az, by, j, false, g.Ny);                         // Wv :63-69
-        return wt * bias6(qz, wt > 0, bz, k, false, g.Nz);
+        const double wt = sym4<ARITH>(zin, az, by, j, false, g.Ny);                         // Wv :63-69
+        return wt * bias6<ARITH>(qz, wt > 0, bz, k, false, g.Nz);
     } else if (ROLE == ROLE_W) {
-        const double wt = sym4(qz, az, bz, k - 1, true, g.Nz);                       // Ww :87-93
-        return wt * bias6(qz, wt > 0, bz, k - 1, true, g.Nz);
+        const double wt = sym4<ARITH>(qz, az, bz, k - 1, true, g.Nz);                       // Ww :87-93
+        return wt * bias6<ARITH>(qz, wt > 0, bz, k - 1, true, g.Nz);
     } else {
         const double w0 = zin.s[3];                                                  // advective_tracer_flux_z :115-121
-        return az * w0 * bias6(qz, w0 > 0, bz, k, false, g.Nz);
+        return az * w0 * bias6<ARITH>(qz, w0 > 0, bz, k, false, g.Nz);
     }
 }
 // x-flux: own field along x (qx) + the advecting u: along y (role v, indices 1 .. 4), along z (role w), at the face (tracers)
@@ -168,21 +168,21 @@ template <int ROLE> __device__ __forceinline__ Win6 load_xaux(const PlaneCtx &p,
     if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.u, o.c, p.so);
     return w;
 }
-template <int ROLE>
+template <int ROLE, int ARITH>
 __device__ __forceinline__ double x_flux(const DGrid &g, const PlaneCtx &p, const Win6 &qx, const Win6 &aux, int i, int j, int k) {
     const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
     if (ROLE == ROLE_U) {
-        const double ut = sym4(qx, p.axk, bx, i - 1, true, g.Nx);                    // advective_momentum_flux_Uu :23-29
-        return ut * bias6(qx, ut > 0, bx, i - 1, true, g.Nx);
+        const double ut = sym4<ARITH>(qx, p.axk, bx, i - 1, true, g.Nx);                    // advective_momentum_flux_Uu :23-29
+        return ut * bias6<ARITH>(qx, ut > 0, bx, i - 1, true, g.Nx);
     } else if (ROLE == ROLE_V) {
-        const double ut = sym4(aux, p.axk, by, j, false, g.Ny);                      // Uv :47-53
-        return ut * bias6(qx, ut > 0, bx, i, false, g.Nx);
+        const double ut = sym4<ARITH>(aux, p.axk, by, j, false, g.Ny);                      // Uv :47-53
+        return ut * bias6<ARITH>(qx, ut > 0, bx, i, false, g.Nx);
     } else if (ROLE == ROLE_W) {
         const double ut = sym4z(aux, p.axz, bz, k, false, g.Nz);                     // Uw :71-77
-        return ut * bias6(qx, ut > 0, bx, i, false, g.Nx);
+        return ut * bias6<ARITH>(qx, ut > 0, bx, i, false, g.Nx);
     } else {
         const double u0 = aux.s[3];                                                  // advective_tracer_flux_x :99-105
-        return p.axk * u0 * bias6(qx, u0 > 0, bx, i, false, g.Nx);
+        return p.axk * u0 * bias6<ARITH>(qx, u0 > 0, bx, i, false, g.Nx);
     }
 }
 // y-flux: own field along y (qy) + the advecting v: along x (role u), along z (role w), at the face (tracers)
@@ -194,21 +194,21 @@ template <int ROLE> __device__ __forceinline__ Win6 load_yaux(const PlaneCtx &p,
     if (ROLE == ROLE_C) w.s[3] = ldb<24>(p.v, o.c, p.so);
     return w;
 }
-template <int ROLE>
+template <int ROLE, int ARITH>
 __device__ __forceinline__ double y_flux(const DGrid &g, const PlaneCtx &p, const Win6 &qy, const Win6 &aux, int i, int j, int k) {
     const bool bx = g.tx != 0, by = g.ty != 0, bz = g.tz != 0;
     if (ROLE == ROLE_U) {
-        const double vt = sym4(aux, p.ayk, bx, i, false, g.Nx);                      // advective_momentum_flux_Vu :31-37
-        return vt * bias6(qy, vt > 0, by, j, false, g.Ny);
+        const double vt = sym4<ARITH>(aux, p.ayk, bx, i, false, g.Nx);                      // advective_momentum_flux_Vu :31-37
+        return vt * bias6<ARITH>(qy, vt > 0, by, j, false, g.Ny);
     } else if (ROLE == ROLE_V) {
-        const double vt = sym4(qy, p.ayk, by, j - 1, true, g.Ny);                    // Vv :55-61
-        return vt * bias6(qy, vt > 0, by, j - 1, true, g.Ny);
+        const double vt = sym4<ARITH>(qy, p.ayk, by, j - 1, true, g.Ny);                    // Vv :55-61
+        return vt * bias6<ARITH>(qy, vt > 0, by, j - 1, true, g.Ny);
     } else if (ROLE == ROLE_W) {
         const double vt = sym4z(aux, p.ayz, bz, k, false, g.Nz);                     // Vw :79-85
-        return vt * bias6(qy, vt > 0, by, j, false, g.Ny);
+        return vt * bias6<ARITH>(qy, vt > 0, by, j, false, g.Ny);
     } else {
         const double v0 = aux.s[3];                                                  // advective_tracer_flux_y :107-113
-        return p.ayk * v0 * bias6(qy, v0 > 0, by, j, false, g.Ny);
+        return p.ayk * v0 * bias6<ARITH>(qy, v0 > 0, by, j, false, g.Ny);
     }
 }
 
@@ -230,7 +230,7 @@ __device__ __forceinline__ void role_barrier() {
 // operations of the plane, right behind the loads of the y-window, so that no wait of this plane includes them: they have the
 // arithmetic of the y-flux, the barrier and the first loads of the next plane to complete. The new element of the z-window
 // arrives one plane ahead of its use (qn), the previous tendency of the cell closed in the next plane likewise (gmn).
-template <int ROLE, int TY, bool SUB, bool BZ, typename Args>
+template <int ROLE, int TY, bool SUB, bool BZ, int ARITH, typename Args>
 __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const int fidx, const int i0, const int j0, const int kc0,
                                            const int kc1, double (*FX)[TY][66], double (*FY)[TY + 1][64]) {
     // Bounded z: only the planes within reach of a wall need the fallback logic of the scheme (every z-stencil test of
@@ -296,13 +296,13 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
                 if (edge_y && !(OCN_ROLE_ABLATE & 32)) {
                     const Win6 qy = ywin6<false>(p.q, p.so, o, 0.0);
                     const Win6 aux = ROLE == ROLE_W ? zwin4(p.v, p.so, o, s2) : load_yaux<ROLE>(p, o);
-                    FY[buf][TY][lane] = y_flux<ROLE>(gg, p, qy, aux, i, j, k);
+                    FY[buf][TY][lane] = y_flux<ROLE, ARITH>(gg, p, qy, aux, i, j, k);
                 }
                 if (edge_x && !(OCN_ROLE_ABLATE & 32)) {
                     asm volatile("" : "+v"(e.c));
                     const Win6 qxe = xwin6<false>(p.q, p.so, e, 0.0);
                     const Win6 aux = ROLE == ROLE_W ? zwin4(p.u, p.so, e, s2) : load_xaux<ROLE>(p, e);
-                    FX[buf][lane][64] = x_flux<ROLE>(gg, p, qxe, aux, ie, je, k);
+                    FX[buf][lane][64] = x_flux<ROLE, ARITH>(gg, p, qxe, aux, ie, je, k);
                 }
             };
             if (ROLE == ROLE_W && near_wall(k)) edge_plane(gB); else edge_plane(gP);     // only role w interpolates along z here
@@ -338,7 +338,7 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
         zin = load_zin<ROLE>(p, p.so, o);
     };
     auto z_compute = [&](const DGrid &gg, const int k, const int buf, const long pk) {
-        const double fz = z_flux<ROLE>(gg, zin, i, j, k, qz);
+        const double fz = z_flux<ROLE, ARITH>(gg, zin, i, j, k, qz);
         const int pb = buf ^ 1;
         const long pkm = pk - 1;
         const double vinv = ROLE == ROLE_W ? ktab(g.vinv_f)[pkm] : ktab(g.vinv_c)[pkm];
@@ -397,12 +397,12 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
             x_loads();
             stores();
             __builtin_amdgcn_sched_barrier(0);
-            FX[buf][row0][lane] = x_flux<ROLE>(gg, p, qx, xaux, i, j, k);
+            FX[buf][row0][lane] = x_flux<ROLE, ARITH>(gg, p, qx, xaux, i, j, k);
             __builtin_amdgcn_sched_barrier(0);
             y_loads();
             prefetches();
             __builtin_amdgcn_sched_barrier(0);
-            FY[buf][row0][lane] = y_flux<ROLE>(gg, p, qy, yaux, i, j, k);
+            FY[buf][row0][lane] = y_flux<ROLE, ARITH>(gg, p, qy, yaux, i, j, k);
         };
         if (near_wall(k)) plane(gB); else plane(gP);
         p.so += s2;
@@ -417,7 +417,7 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     }
 }
 
-template <int NTR, int TY, bool BZ, bool SUB>
+template <int NTR, int TY, bool BZ, bool SUB, int ARITH = 0>
 __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_kernel(DGrid gin, RoleArgs<3 + NTR> a) {
     constexpr int NF = 3 + NTR;
     __shared__ double FX[2][TY][66];                // low-side x-fluxes of columns 0..64 (65 used, padded)
@@ -436,10 +436,10 @@ __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_k
     const int i0 = a.r.i0 + (int)(tile % (unsigned)a.ntile_x) * 64, j0 = a.r.j0 + (int)(tile / (unsigned)a.ntile_x) * TY;
     const int kc0 = a.r.k0 + (int)chunk * a.kchunk;
     const int kc1 = min(kc0 + a.kchunk - 1, a.r.k1);
-    if (role == 0) role_march<ROLE_U, TY, SUB, BZ>(g, a, 0, i0, j0, kc0, kc1, FX, FY);
-    else if (role == 1) role_march<ROLE_V, TY, SUB, BZ>(g, a, 1, i0, j0, kc0, kc1, FX, FY);
-    else if (role == 2) role_march<ROLE_W, TY, SUB, BZ>(g, a, 2, i0, j0, kc0, kc1, FX, FY);
-    else role_march<ROLE_C, TY, SUB, BZ>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
+    if (role == 0) role_march<ROLE_U, TY, SUB, BZ, ARITH>(g, a, 0, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 1) role_march<ROLE_V, TY, SUB, BZ, ARITH>(g, a, 1, i0, j0, kc0, kc1, FX, FY);
+    else if (role == 2) role_march<ROLE_W, TY, SUB, BZ, ARITH>(g, a, 2, i0, j0, kc0, kc1, FX, FY);
+    else role_march<ROLE_C, TY, SUB, BZ, ARITH>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
 }
 
 // The role kernel addresses a parent array with a 31-bit byte offset (bit 31 is the out-of-range flag of its buffer descriptor, whose
@@ -450,6 +450,7 @@ static inline bool role_tendency_supported(const DGrid &g) {
     return plane * (g.Nz + 2.0 * g.Hz + 1.0 + 4.0) < 2147483648.0;
 }
 
+static int g_arithmetic = 0;       // 0: the reference's operation sequence (bit-identical to the oracle); 1: contracted WENO flux (ocn_device.h)
 static int g_role_kchunk = 0;      // 0: automatic
 static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgroup (bytes) to limit the workgroups per CU
 
@@ -484,9 +485,14 @@ static int launch_roles_t(const DGrid &g, hipStream_t stream, RoleArgs<3 + NTR> 
     a.band = (a.npair + 7) / 8;
     const unsigned nblocks = (unsigned)a.band * 8u * NF;
     const dim3 blk(64 * (TY + 1));
-#define OCN_LAUNCH_ROLES(BZV, SUBV) hipLaunchKernelGGL((role_tendency_kernel<NTR, TY, BZV, SUBV>), dim3(nblocks), blk, (size_t)g_role_ldspad, stream, g, a)
-    if (g.tz != 0) { if (sub) OCN_LAUNCH_ROLES(true, true); else OCN_LAUNCH_ROLES(true, false); }
-    else           { if (sub) OCN_LAUNCH_ROLES(false, true); else OCN_LAUNCH_ROLES(false, false); }
+#define OCN_LAUNCH_ROLES(BZV, SUBV, AR) hipLaunchKernelGGL((role_tendency_kernel<NTR, TY, BZV, SUBV, AR>), dim3(nblocks), blk, (size_t)g_role_ldspad, stream, g, a)
+    if (g_arithmetic == 1) {          // the opt-in contracted arithmetic of the WENO flux (ocn_device.h; option "arithmetic")
+        if (g.tz != 0) { if (sub) OCN_LAUNCH_ROLES(true, true, 1); else OCN_LAUNCH_ROLES(true, false, 1); }
+        else           { if (sub) OCN_LAUNCH_ROLES(false, true, 1); else OCN_LAUNCH_ROLES(false, false, 1); }
+    } else {
+        if (g.tz != 0) { if (sub) OCN_LAUNCH_ROLES(true, true, 0); else OCN_LAUNCH_ROLES(true, false, 0); }
+        else           { if (sub) OCN_LAUNCH_ROLES(false, true, 0); else OCN_LAUNCH_ROLES(false, false, 0); }
+    }
 #undef OCN_LAUNCH_ROLES
     return 0;
 }

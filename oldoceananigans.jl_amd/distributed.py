@@ -922,6 +922,17 @@ class Distributed:
     def barrier(self):
         _lib.check(_lib.lib().ocn_dist_barrier(self.handle))
 
+    def info(self):
+        """what the communicator itself reports (ocn_dist_info + ocn_dist_comm_info): for the RCCL transport the number of ranks and
+        this rank's index come from ncclCommCount / ncclCommUserRank -- the ranks RCCL really connected"""
+        w, r, we, ea = (C.c_int() for _ in range(4))
+        _lib.check(_lib.lib().ocn_dist_info(self.handle, C.byref(w), C.byref(r), C.byref(we), C.byref(ea)))
+        k, n, cr, dev = (C.c_int() for _ in range(4))
+        _lib.check(_lib.lib().ocn_dist_comm_info(self.handle, C.byref(k), C.byref(n), C.byref(cr), C.byref(dev)))
+        return {"world": w.value, "rank": r.value, "west": we.value, "east": ea.value,
+                "transport": "rccl" if k.value == 0 else "caller-supplied collectives (ocn_transport_t)",
+                "comm_ranks": n.value, "comm_rank": cr.value, "device": dev.value, "self_loop": self.self_loop}
+
     def close(self):
         if getattr(self, "handle", None) is not None:
             _lib.lib().ocn_dist_destroy(self.handle)
