@@ -405,6 +405,9 @@ def main():
     arithmetic = int(os.environ.get("OCN_ARITHMETIC", str(args.arithmetic)))
     if arithmetic:
         model.set_option("arithmetic", arithmetic)
+    for kv in filter(None, os.environ.get("OCN_MODEL_OPTIONS", "").split(",")):      # A/B experiments: "early_exchange=0,fused_step=0"
+        k, v = kv.split("=")
+        model.set_option(k.strip(), int(v))
     phase("model")
     dt = 0.1 * (1.0 / (args.global_size or N)) / 0.6                                # Δt = 0.1 Δx / max|u|
 

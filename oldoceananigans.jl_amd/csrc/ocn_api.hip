@@ -918,6 +918,29 @@ static inline void launch_strided_line_fft(double2 *data, const double2 *tw, lon
     if (zl == 4) hipLaunchKernelGGL(strided_line_fft_kernel<4>, grd, dim3(256), lds, g_stream, data, tw, C, N, logn, inverse, scale, plane_stride);
     else         hipLaunchKernelGGL(strided_line_fft_kernel<8>, grd, dim3(256), lds, g_stream, data, tw, C, N, logn, inverse, scale, plane_stride);
 }
+static inline void launch_paired_zline(bool forward, const double2 *in, double2 *out, const double2 *tw, long C, int N, int logn, double scale) {
+    const int zl = line_zl(N);
+    const dim3 grd((unsigned)((C + zl - 1) / zl));
+    const size_t lds = (size_t)N * zl * sizeof(double2);
+    if (forward) {
+        if (zl == 4) hipLaunchKernelGGL(paired_zline_r2c_kernel<4>, grd, dim3(256), lds, g_stream, in, out, tw, C, N, logn);
+        else         hipLaunchKernelGGL(paired_zline_r2c_kernel<8>, grd, dim3(256), lds, g_stream, in, out, tw, C, N, logn);
+    } else {
+        if (zl == 4) hipLaunchKernelGGL(paired_zline_c2r_kernel<4>, grd, dim3(256), lds, g_stream, in, out, tw, C, N, logn, scale);
+        else         hipLaunchKernelGGL(paired_zline_c2r_kernel<8>, grd, dim3(256), lds, g_stream, in, out, tw, C, N, logn, scale);
+    }
+}
+template <bool SOLVE>
+static inline void launch_xline_thomas(int E, double2 *S, const double *rden, long M, int N, double a, double2 *payload, const double2 *iface, double scale) {
+    const dim3 grd((unsigned)((M + 3) / 4)), blk(256);
+    switch (E) {
+        case 1: hipLaunchKernelGGL((xline_thomas_kernel<1, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
+        case 2: hipLaunchKernelGGL((xline_thomas_kernel<2, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
+        case 4: hipLaunchKernelGGL((xline_thomas_kernel<4, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
+        case 8: hipLaunchKernelGGL((xline_thomas_kernel<8, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
+        default: hipLaunchKernelGGL((xline_thomas_kernel<16, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
+    }
+}
 static inline void launch_zline_solve(double2 *hc, const double2 *tw, const double *lx, const double *ly, const double *lz, int Nxs, int Ny, int Nz,
                                       int logn, double scale, int pitch = 0) {
     const int zl = line_zl(Nz);
@@ -930,6 +953,8 @@ static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
+static int g_dist_xfast = 1;           // substructured x solve in the fields' own x-fastest layout (paired z transform in LDS, one-wave-per-line Thomas scans) when sizes allow
+static int g_dist_fused_step = 1;      // partitioned model, (connected, Periodic, Periodic) slabs: the pressure step without fills / copies between its stages (ocn_dist.h)
 static int g_dist_yline = 1;           // z Bounded: local y transform by strided_line_fft_kernel (Ny = 2^m <= 1024) instead of rocFFT's 1-D strided plan
 static int g_dist_zfirst = 1;          // substructured solve on the z-fastest layout (R2C along z); 0: paired-column layout
 
@@ -1622,6 +1647,12 @@ struct ocn_dist_poisson_s {
     double2 *ytw = nullptr;
     bool zf_2d = false;
     bool has_zf = false;
+    // x-fastest variant of the substructured solve (ocn_kernels.h, "xfast"): dense real array rx (Nx, Ny, Nz), spectrum xs (Nx, Ny, Nz/2 + 1),
+    // Thomas factors rden_x in the spectrum's layout, first / last entry of s = T⁻¹e₀ per mode
+    bool xfast = false;
+    int xE = 0, logn_z = 0;
+    double *rx = nullptr, *rden_x = nullptr, *s_first = nullptr, *s_last = nullptr;
+    double2 *xs = nullptr, *ztw = nullptr;
 };
 
 extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
@@ -1634,6 +1665,7 @@ extern "C" int ocn_dist_poisson_destroy(ocn_dist_poisson_t s) {
     for (int d = 0; d < 3; ++d) hipFree(s->lam[d]);
     if (s->has_zf) { hipfftDestroy(s->plan_zr2c); hipfftDestroy(s->plan_zc2r); if (!s->zf_2d) hipfftDestroy(s->plan_y); }
     hipFree(s->rreal); hipFree(s->spec); hipFree(s->ytw);
+    hipFree(s->rx); hipFree(s->rden_x); hipFree(s->s_first); hipFree(s->s_last); hipFree(s->xs); hipFree(s->ztw);
     delete s;
     return OCN_OK;
 }
@@ -1713,7 +1745,62 @@ extern "C" int ocn_dist_poisson_create(ocn_dist_poisson_t *solver, ocn_grid_t lo
         }
         if (r != HIPFFT_SUCCESS) { rc = fail(1000 + (int)r, "hipfftPlanMany(local y/z) failed (%d)", (int)r); goto bad; }
         s->has_loc = true;
-        if (zmode == 0 && g_dist_substructured && g_dist_zfirst) {
+        auto pow2_line = [](int n) { return n >= 8 && n <= OCN_LINE_MAX && (n & (n - 1)) == 0; };
+        if (zmode == 0 && g_dist_substructured && g_dist_xfast && (s->Nxl % 2) == 0 && s->Nxl <= 1024 && pow2_line(s->Ny) && pow2_line(s->Nz)) {
+            // ---- x-fastest variant (ocn_kernels.h "xfast") ----
+            s->sub = true; s->xfast = true;
+            s->Nzh = s->Nz / 2 + 1;
+            s->M = (long)s->Ny * s->Nzh;                                     // mode m = ky + Ny kz
+            while ((1 << s->logn_y) < s->Ny) ++s->logn_y;
+            while ((1 << s->logn_z) < s->Nz) ++s->logn_z;
+            s->xE = 1;
+            while (s->xE * 64 < s->Nxl) s->xE *= 2;
+            const size_t nreal = (size_t)s->Nxl * s->Ny * s->Nz, nspec = (size_t)s->Nxl * s->M;
+            TRY_OR_FREE(dev_alloc((void **)&s->rx, nreal * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->xs, nspec * sizeof(double2)));
+            TRY_OR_FREE(dev_alloc((void **)&s->rden_x, nspec * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->s_first, (size_t)s->M * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->s_last, (size_t)s->M * sizeof(double)));
+            TRY_OR_FREE(dev_alloc((void **)&s->iface, (2 * (size_t)s->M + 2) * sizeof(double2)));
+            auto twiddles = [&](int n, double2 **dst) -> hipError_t {
+                std::vector<double2> tw(n / 2);
+                for (int q = 0; q < n / 2; ++q) {
+                    const double ang = -2.0 * M_PI * (double)q / (double)n;
+                    tw[q] = make_double2(cos(ang), sin(ang));
+                }
+                hipError_t e_ = dev_alloc((void **)dst, tw.size() * sizeof(double2));
+                return e_ != hipSuccess ? e_ : hipMemcpy(*dst, tw.data(), tw.size() * sizeof(double2), hipMemcpyHostToDevice);
+            };
+            TRY_OR_FREE(twiddles(s->Ny, &s->ytw));
+            TRY_OR_FREE(twiddles(s->Nz, &s->ztw));
+            const double a = 1.0 / (g.dx * g.dx);
+            // mode m = ky + Ny kz: first eigenvalue array indexed with m % Ny, second with m / Ny; the spectrum buffer is the scratch of s
+            hipLaunchKernelGGL(sub_setup_xfast_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Ny, s->Nxl, a, s->lam[1],
+                               s->lam[2], s->rden_x, s->s_first, s->s_last, (double *)(s->iface + 2 * s->M + 1), (double *)s->xs);
+            TRY_OR_FREE(hipGetLastError());
+            // known-answer check of the paired z transform (a round trip cannot tell a mis-read layout from the right one): column 2c
+            // carries cos(2 pi k / N), column 2c + 1 carries sin(2 pi 3 k / N): X_even[1] = N/2, X_odd[3] = -i N/2, everything else 0;
+            // then the way back reproduces the input
+            {
+                const long C = (long)s->Nxl * s->Ny / 2;
+                double *bm = nullptr;
+                TRY_OR_FREE(dev_alloc((void **)&bm, 2 * sizeof(double)));
+                hipLaunchKernelGGL(xfast_kat_fill_kernel, dim3((unsigned)((nreal / 2 + 255) / 256)), dim3(256), 0, g_stream, (double2 *)s->rx, C, s->Nz);
+                launch_paired_zline(true, (const double2 *)s->rx, s->xs, s->ztw, C, s->Nz, s->logn_z, 1.0);
+                hipLaunchKernelGGL(xfast_kat_check_kernel, dim3(1), dim3(256), 0, g_stream, (const double2 *)s->xs, C, s->Nz, bm);
+                launch_paired_zline(false, s->xs, (double2 *)s->rx, s->ztw, C, s->Nz, s->logn_z, 1.0 / (double)s->Nz);
+                hipLaunchKernelGGL(xfast_kat_check_real_kernel, dim3(1), dim3(256), 0, g_stream, (const double2 *)s->rx, C, s->Nz, bm + 1);
+                double err[2] = {1.0, 1.0};
+                hipError_t e_ = hipMemcpyAsync(err, bm, sizeof(err), hipMemcpyDeviceToHost, g_stream);
+                if (e_ == hipSuccess) e_ = hipStreamSynchronize(g_stream);
+                hipFree(bm);
+                if (e_ != hipSuccess) { rc = fail((int)e_, "x-fastest solver self-check: %s", hipGetErrorString(e_)); goto bad; }
+                if (!(err[0] < 1e-10 * s->Nz) || !(err[1] < 1e-12 * s->Nz)) {
+                    rc = fail(OCN_EFFT, "the paired z line transform failed its known-answer check (spectrum %.3g, round trip %.3g)", err[0], err[1]);
+                    goto bad;
+                }
+            }
+        } else if (zmode == 0 && g_dist_substructured && g_dist_zfirst) {
             s->sub = true; s->zfirst = true;
             s->Nzh = s->Nz / 2 + 1;
             s->Nzp = (s->Nzh + 7) & ~7;
@@ -1922,10 +2009,11 @@ extern "C" int ocn_dist_poisson_buffer_size(ocn_dist_poisson_t s, size_t *comple
     return OCN_OK;
 }
 
-// 0: paired-column layout; 1: z-fastest layout with 1-D plans; 2: z-fastest layout with the 2-D (y, z) real plans; -1 transposing solver
+// 0: paired-column layout; 1: z-fastest layout with 1-D plans; 2: z-fastest layout with the 2-D (y, z) real plans; 3: z-fastest with the LDS
+// y-line kernel; 4: x-fastest layout (paired z transform in LDS, Thomas scans); -1 transposing solver
 extern "C" int ocn_dist_poisson_layout(ocn_dist_poisson_t s, int *layout) {
     if (!s || !layout) return fail(OCN_EINVAL, "NULL argument");
-    *layout = !s->sub ? -1 : (!s->zfirst ? 0 : (s->yline ? 3 : (s->zf_2d ? 2 : 1)));
+    *layout = !s->sub ? -1 : (s->xfast ? 4 : (!s->zfirst ? 0 : (s->yline ? 3 : (s->zf_2d ? 2 : 1))));
     return OCN_OK;
 }
 
@@ -1950,6 +2038,14 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
     if (!s || !s->sub || !s->payload) return fail(OCN_EINVAL, "substructured solver / gather buffers not set");
     int rc;
     const double a = 1.0 / (s->grid->d.dx * s->grid->d.dx);
+    if (s->xfast) {
+        const long C = (long)s->Nxl * s->Ny / 2, P = (long)s->Nxl * s->Ny;
+        launch_paired_zline(true, (const double2 *)s->rx, s->xs, s->ztw, C, s->Nz, s->logn_z, 1.0);
+        launch_strided_line_fft(s->xs, s->ytw, (long)s->Nxl, (long)s->Nxl, (unsigned)s->Nzh, s->Ny, s->logn_y, 0, 1.0, P);
+        launch_xline_thomas<false>(s->xE, s->xs, s->rden_x, s->M, s->Nxl, a, s->payload, nullptr, 1.0);      // reads only: the payload
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     if (s->zfirst) {
         if ((rc = plan_set_stream(s->plan_zr2c))) return rc;
         FFT_TRY(hipfftExecD2Z(s->plan_zr2c, s->rreal, (hipfftDoubleComplex *)s->spec));
@@ -1977,14 +2073,33 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
 
 // substructured mode, stage 2: interface unknowns from the gathered payloads, slab correction, rebuild the paired spectrum,
 // inverse local transform, copy into the haloed pressure
+static int dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi, bool keep_zfast);
 extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi) {
     NEED_INIT();
     if (!s || !s->sub || !s->gathered || !phi) return fail(OCN_EINVAL, "substructured solver / gather buffers not set");
+    return dist_poisson_backward_local(s, phi, false);
+}
+// keep_zfast (z-fastest layout only): leave the solution in the solver's dense z-fastest real array (s->rreal) instead of copying it
+// into a haloed field -- the partitioned model's pressure correction reads it there (pressure_correction_zfast_kernel)
+static int dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi, bool keep_zfast) {
     const DGrid &g = s->grid->d;
     const double a = 1.0 / (g.dx * g.dx);
-    hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Nyh, s->Nxl, s->R, s->rank,
-                       a, s->lam[1], s->lam[2], s->svec, (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
     const double scale = 1.0 / ((double)s->Ny * (double)s->Nz);
+    if (s->xfast) {
+        // interface unknowns, then the SAME line solve on the right-hand side that carries them in its two end entries: the final solution
+        hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Ny, s->Nxl, s->R, s->rank,
+                           a, s->lam[1], s->lam[2], s->s_first, s->s_last, (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
+        launch_xline_thomas<true>(s->xE, s->xs, s->rden_x, s->M, s->Nxl, a, nullptr, s->iface, scale);
+        const long C = (long)s->Nxl * s->Ny / 2, P = (long)s->Nxl * s->Ny;
+        launch_strided_line_fft(s->xs, s->ytw, (long)s->Nxl, (long)s->Nxl, (unsigned)s->Nzh, s->Ny, s->logn_y, 1, 1.0, P);
+        launch_paired_zline(false, s->xs, (double2 *)s->rx, s->ztw, C, s->Nz, s->logn_z, 1.0);
+        if (!keep_zfast)           // (here: keep the dense x-fastest solution in s->rx)
+            hipLaunchKernelGGL(copy_dense_to_field_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C), (const double *)s->rx);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
+    hipLaunchKernelGGL(sub_interface_kernel, dim3((unsigned)((s->M + 255) / 256)), dim3(256), 0, g_stream, s->M, s->Nyh, s->Nxl, s->R, s->rank,
+                       a, s->lam[1], s->lam[2], s->svec, s->svec + s->M * (long)(s->Nxl - 1), (const double *)(s->iface + 2 * s->M + 1), s->gathered, s->iface);
     if (s->zfirst) {
         const long total = (long)s->Nzp * s->Nxl * s->Ny;
         hipLaunchKernelGGL(sub_correct_zfast_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, s->spec, s->svec, s->iface,
@@ -1999,8 +2114,9 @@ extern "C" int ocn_dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi
         }
         if ((rcz = plan_set_stream(s->plan_zc2r))) return rcz;
         FFT_TRY(hipfftExecZ2D(s->plan_zc2r, (hipfftDoubleComplex *)s->spec, s->rreal));
-        hipLaunchKernelGGL(copy_real_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
-                           make_view(g, phi, LOC_C), s->rreal);
+        if (!keep_zfast)
+            hipLaunchKernelGGL(copy_real_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
+                               make_view(g, phi, LOC_C), s->rreal);
         KERNEL_CHECK();
         return OCN_OK;
     }
@@ -2027,6 +2143,7 @@ extern "C" int ocn_dist_poisson_set_buffers(ocn_dist_poisson_t s, double *send_c
 extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *u, const double *v, const double *w) {
     NEED_INIT();
     if (!s || !u || !v || !w) return fail(OCN_EINVAL, "NULL argument");
+    if (s->xfast) return source_term(s->grid->d, u, v, w, s->rx, false, true);
     if (s->zfirst) {
         const DGrid &g = s->grid->d;
         hipLaunchKernelGGL(source_term_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
@@ -2035,6 +2152,22 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
         return OCN_OK;
     }
     return source_term(s->grid->d, u, v, w, s->zfield, s->zmode == 1, true, (long)s->Nxe * s->Nz, (long)s->Nxe, s->Nxe != s->Nxl);
+}
+
+// the partitioned model's form (z-fastest layout): no halo is read -- y / z neighbours at wrapped interior indices, u[Nx+1] from `u_east`, the
+// (Ny, Nz) column received by the one-column exchange
+static int dist_poisson_source_term_wrapped(ocn_dist_poisson_t s, const double *u, const double *v, const double *w, const double *u_east) {
+    const DGrid &g = s->grid->d;
+    if (s->xfast) {
+        hipLaunchKernelGGL(source_term_dense_wrapped_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U), make_view(g, v, LOC_V),
+                           make_view(g, w, LOC_W), u_east, s->rx);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
+    hipLaunchKernelGGL(source_term_zfast_wrapped_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
+                       make_view(g, u, LOC_U), make_view(g, v, LOC_V), make_view(g, w, LOC_W), u_east, s->rreal);
+    KERNEL_CHECK();
+    return OCN_OK;
 }
 
 static int transpose_stage(ocn_dist_poisson_s *s, int dir, const double2 *src, double2 *dst) {
@@ -2310,12 +2443,15 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_substructured")) { g_dist_substructured = value; return OCN_OK; }
     if (!strcmp(key, "dist_zfirst")) { g_dist_zfirst = value; return OCN_OK; }
     if (!strcmp(key, "dist_yline")) { g_dist_yline = value; return OCN_OK; }
+    if (!strcmp(key, "dist_fused_step")) { g_dist_fused_step = value; return OCN_OK; }
+    if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }
 
 static int dist_model_set_option(ocn_model_s *m, const char *key, int value);
+static int dist_model_get_option(const ocn_model_s *m, const char *key, int *value);
 extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
     m->epoch += 1;
@@ -2418,6 +2554,7 @@ extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) 
     if (!strcmp(key, "fuse_substep")) { *value = m->fuse_substep; return OCN_OK; }
     if (!strcmp(key, "fuse_substep_active")) { *value = can_fuse_substep(m) ? 1 : 0; return OCN_OK; }
     if (!strcmp(key, "arithmetic")) { *value = g_arithmetic; return OCN_OK; }
+    if (dist_model_get_option(m, key, value) == OCN_OK) return OCN_OK;
     if (!strcmp(key, "fused_tendency_active")) { *value = fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl) ? 1 : 0; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown model option '%s'", key);
 }

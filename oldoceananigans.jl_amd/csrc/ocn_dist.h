@@ -269,6 +269,25 @@ extern "C" int ocn_dist_exchange_wait(ocn_dist_t d) {
     return OCN_OK;
 }
 
+// the same exchange for data the very next kernel reads (the one-column exchanges of the pressure step): nothing could overlap it, so it
+// runs on the COMPUTE stream itself -- no event hop to the communication stream and back (two cross-queue dependencies, ~15 us each)
+static int dist_exchange_inline(ocn_dist_t d, const double *west_send, const double *east_send, double *west_recv, double *east_recv, size_t count) {
+    if (d->in_flight) return fail(OCN_ESTATE, "an exchange is already in flight");
+    if (d->kind == 1) {
+        int rc = d->tr.exchange_start(d->tr.user, west_send, east_send, west_recv, east_recv, count, (void *)g_stream);
+        if (rc) return fail(rc, "transport exchange_start failed");
+        rc = d->tr.exchange_wait(d->tr.user, (void *)g_stream);
+        return rc ? fail(rc, "transport exchange_wait failed") : OCN_OK;
+    }
+    NCCL_TRY(g_rccl.GroupStart());
+    NCCL_TRY_IN_GROUP(g_rccl.Send(west_send, count, OCN_NCCL_FLOAT64, d->west, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(east_recv, count, OCN_NCCL_FLOAT64, d->east, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Send(east_send, count, OCN_NCCL_FLOAT64, d->east, d->comm, g_stream));
+    NCCL_TRY_IN_GROUP(g_rccl.Recv(west_recv, count, OCN_NCCL_FLOAT64, d->west, d->comm, g_stream));
+    NCCL_TRY(g_rccl.GroupEnd());
+    return OCN_OK;
+}
+
 // MPI.Alltoallv! with equal counts (distributed_transpose.jl:185-191): piece r of `send` (count doubles) goes to rank r
 extern "C" int ocn_dist_all_to_all(ocn_dist_t d, const double *send, double *recv, size_t count_per_rank) {
     NEED_INIT();
@@ -349,6 +368,12 @@ struct DistModel {
     bool pencil = false;        // Partition(Rx, Ry) with Ry > 1: a second hop along y per fill (corners ride along)
     double *ss = nullptr, *ns = nullptr, *sr = nullptr, *nr = nullptr;     // y-halo buffers: Hy rows of every prognostic field per side
     bool plain_y = true;        // the non-partitioned y direction is Periodic (what the partitioned solvers transform); Bounded / Flat y: gathered solve
+    // Round 3 -- the pressure step of (connected, Periodic, Periodic) x-slabs without the passes between its stages (ocn_kernels.h,
+    // "Round 3"): one-column exchanges of u and p through dense (Ny, Nz) buffers that the source-term / correction kernels read directly,
+    // the solution left z-fastest, the early exchange packed from wrapped interior indices
+    bool fused_step = false;
+    double *cws = nullptr, *ces = nullptr, *cwr = nullptr, *cer = nullptr;   // column buffers: Ny * Nz doubles each
+    bool fused() const { return fused_step && thin_halos != 0 && partitioned(); }
     bool general() const { return bounded_x || pencil || !plain_y; }                    // no overlap / thin exchanges on such partitions
     bool partitioned() const { return dist->world > 1 || dist->self_loop; }
 };
@@ -364,6 +389,7 @@ static void dist_model_free(DistModel *dm) {
     }
     hipFree(dm->ws); hipFree(dm->es); hipFree(dm->wr); hipFree(dm->er); hipFree(dm->p2); hipFree(dm->buf_a);
     hipFree(dm->ss); hipFree(dm->ns); hipFree(dm->sr); hipFree(dm->nr);
+    hipFree(dm->cws); hipFree(dm->ces); hipFree(dm->cwr); hipFree(dm->cer);
     if (dm->buf_b != dm->buf_a) hipFree(dm->buf_b);
     delete dm;
 }
@@ -399,6 +425,27 @@ static int y_halo_buffers(const DGrid &g, double *const *fields, const int (*loc
     if (pack) hipLaunchKernelGGL(y_halo_buffer_kernel<true>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north, true, true);
     else      hipLaunchKernelGGL(y_halo_buffer_kernel<false>, dim3(nb), dim3(256), 0, g_stream, fl, rl, g.Ny, g.Hy, g.Hy, south, north,
                                  !wall_lo(g.ty), !wall_hi(g.ty));
+    KERNEL_CHECK();
+    return OCN_OK;
+}
+
+// fill_send_buffers! (communication_buffers.jl:281-289) reading the y / z halo rows at their wrapped interior source: what a local fill
+// followed by x_halo_buffers(pack) would put into the buffers, without the fill. y, z Periodic only.
+static int x_halo_pack_wrapped(const DGrid &g, double *const *fields, const int (*locs)[3], int n, double *west, double *east) {
+    if (n > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
+    FieldList fl;
+    SlabList sl;
+    fl.n = n;
+    const long rows = (long)(g.Ny + 2 * g.Hy) * (g.Nz + 2 * g.Hz);
+    for (int f = 0; f < n; ++f) {
+        int P[3];
+        parent_size(g, locs[f], P);
+        if ((long)P[1] * P[2] != rows) return fail(OCN_ESTATE, "x_halo_pack_wrapped: fields of different parent shapes");
+        fl.p[f] = fields[f]; sl.p0[f] = P[0]; sl.rows[f] = rows; sl.off[f] = (long)f * g.Hx * rows;
+    }
+    const long threads = (long)g.Hx * rows;
+    hipLaunchKernelGGL(x_halo_pack_wrapped_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, g_stream, fl, sl, g.Nx, g.Hx, g.Hx, g.Ny, g.Hy,
+                       g.Nz, g.Hz, west, east);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -484,8 +531,36 @@ static int dist_solve_for_pressure(ocn_model_s *m) {
 // compute_pressure_correction! (pressure_correction.jl:8-20). Of the x halos only ONE column is read before update_state! fills
 // everything again: u[Nx+1] by the divergence, p[0] by the correction. The reference's generic fills move Hx columns of u, v, w and of
 // p here; `thin_halos` exchanges the one column of u and of p -- identical results in every cell that is read.
+static int dist_compute_pressure_correction_fused(ocn_model_s *m) {
+    // fill_halo_regions!(velocities) reduces to ONE column of u going west (the divergence at i = Nx reads u[Nx+1]; y / z neighbours are
+    // read at wrapped interior indices); solve; fill_halo_regions!(pNHS) reduces to ONE column of p dt going east (the correction at
+    // i = 1 reads p[0]). Both columns travel as dense (Ny, Nz) buffers the consumer kernels read directly.
+    DistModel *dm = m->dm;
+    const DGrid &g = m->grid->d;
+    ocn_dist_poisson_s *s = dm->solver;
+    const size_t col = (size_t)g.Ny * g.Nz;
+    int rc;
+    hipLaunchKernelGGL(column_pack_kernel, dim3((g.Ny + 255) / 256, g.Nz), dim3(256), 0, g_stream, g, make_view(g, m->U[0], LOC_U), 1, g.Nx,
+                       dm->cws, dm->ces);
+    KERNEL_CHECK();
+    if ((rc = dist_exchange_inline(dm->dist, dm->cws, dm->ces, dm->cwr, dm->cer, col))) return rc;
+    if ((rc = dist_poisson_source_term_wrapped(s, m->U[0], m->U[1], m->U[2], dm->cer))) return rc;     // from the east neighbour: its u[1]
+    if ((rc = ocn_dist_poisson_forward_local(s))) return rc;
+    if ((rc = ocn_dist_all_gather(dm->dist, dm->buf_a, dm->buf_b, 2 * dm->payload))) return rc;
+    if ((rc = dist_poisson_backward_local(s, nullptr, /*keep_zfast=*/true))) return rc;
+    if (s->xfast)
+        hipLaunchKernelGGL(column_pack_dense_kernel, dim3((g.Ny + 255) / 256, g.Nz), dim3(256), 0, g_stream, g.Nx, g.Ny, g.Nz, (const double *)s->rx,
+                           dm->cws, dm->ces);
+    else
+        hipLaunchKernelGGL(column_pack_zfast_kernel, dim3((g.Nz + 255) / 256, g.Ny), dim3(256), 0, g_stream, g.Nx, g.Ny, g.Nz, (const double *)s->rreal,
+                           dm->cws, dm->ces);
+    KERNEL_CHECK();
+    return dist_exchange_inline(dm->dist, dm->cws, dm->ces, dm->cwr, dm->cer, col);                      // cwr: the west neighbour's p[Nx] = our p[0]
+}
+
 static int dist_compute_pressure_correction(ocn_model_s *m) {
     DistModel *dm = m->dm;
+    if (dm->fused()) return dist_compute_pressure_correction_fused(m);
     const bool thin = dm->thin_halos != 0 && !dm->pencil;
     int rc = dist_fill_halo_regions(m, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr, thin ? 1 : 3, thin ? 1 : 0);
     if (rc) return rc;
@@ -504,10 +579,35 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     const DGrid &g = m->grid->d;
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     int rc;
-    auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], dm->p2, range, m->p, dtp); };
-    if (!(start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx) || dm->general()) {
-        return pc(nullptr);
+    const bool early = start_halo_exchange && dm->partitioned() && dm->early_exchange && dm->async_halos != 0 && g.Nx > 2 * g.Hx && !dm->general();
+    if (dm->fused()) {
+        // corrections straight from the z-fastest solution (p[0] from the received column): both strips in one launch, pack from wrapped
+        // interior indices (no local fill of the strips), start the exchange, then the interior
+        const bool xf = dm->solver->xfast;
+        const double *pd = (const double *)(xf ? dm->solver->rx : dm->solver->rreal), *pw = (const double *)dm->cwr;
+        const FView vu = make_view(g, m->U[0], LOC_U), vv = make_view(g, m->U[1], LOC_V), vw = make_view(g, m->U[2], LOC_W), vp = make_view(g, m->p, LOC_C);
+        auto pcz = [&](int ia, int ib) {
+            if (xf)          // the solution is dense and x-fastest: the single-GPU path's dense correction on a column range
+                hipLaunchKernelGGL(pressure_correction_dense_slab_kernel, grid3(ib - ia + 1, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib);
+            else
+                hipLaunchKernelGGL(pressure_correction_zfast_kernel, dim3((ib - ia + 32) / 32, (g.Nz + 31) / 32, (g.Ny + OCN_ZC_JB - 1) / OCN_ZC_JB), dim3(32, 8), 0,
+                                   g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib);
+            hipError_t e = hipGetLastError();
+            return e == hipSuccess ? OCN_OK : fail((int)e, "pressure correction (partitioned slab): %s", hipGetErrorString(e));
+        };
+        if (!early) return pcz(1, g.Nx);
+        if (xf)
+            hipLaunchKernelGGL(pressure_correction_dense_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx);
+        else
+            hipLaunchKernelGGL(pressure_correction_zfast_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx);
+        KERNEL_CHECK();
+        if ((rc = x_halo_pack_wrapped(g, m->U, m->loc, m->nf, dm->ws, dm->es))) return rc;
+        if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, dm->slab_total))) return rc;
+        dm->halos_in_flight = true;
+        return pcz(g.Hx + 1, g.Nx - g.Hx);
     }
+    auto pc = [&](const int *range) { return pressure_correction(g, m->U[0], m->U[1], m->U[2], dm->p2, range, m->p, dtp); };
+    if (!early) return pc(nullptr);
     const int west[6] = {1, g.Hx, 1, g.Ny, 1, g.Nz}, east[6] = {g.Nx - g.Hx + 1, g.Nx, 1, g.Ny, 1, g.Nz};
     const int mid[6] = {g.Hx + 1, g.Nx - g.Hx, 1, g.Ny, 1, g.Nz};
     if ((rc = pc(west)) || (rc = pc(east))) return rc;
@@ -738,6 +838,18 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
         hipMemsetAsync(dm->buf_a, 0, 2 * n * sizeof(double), g_stream);
         hipMemsetAsync(dm->buf_b, 0, 2 * n * sizeof(double) * (size_t)dist->world, g_stream);
         if ((rc = ocn_dist_poisson_set_gather_buffers(dm->solver, dm->buf_a, dm->buf_b))) return bail(rc);
+        // the pressure step without fills / copies between its stages: z-fastest substructured solver on a partitioned slab whose y and
+        // z directions are Periodic (every field then shares one parent shape, which the wrapped pack relies on)
+        if (g_dist_fused_step && part && (dm->solver->zfirst || dm->solver->xfast) && g.ty == OCN_PERIODIC && g.tz == OCN_PERIODIC && g.Nx >= 2) {
+            const size_t col = (size_t)g.Ny * g.Nz * sizeof(double);
+            double **cb[4] = {&dm->cws, &dm->ces, &dm->cwr, &dm->cer};
+            for (auto b : cb) {
+                e = dev_alloc((void **)b, col);
+                if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(column buffers): %s", hipGetErrorString(e)));
+                hipMemsetAsync(*b, 0, col, g_stream);
+            }
+            dm->fused_step = true;
+        }
     } else {
         ocn_dist_poisson_buffer_size(dm->solver, &n);
         dm->nbuf = n;
@@ -760,6 +872,24 @@ static int dist_model_set_option(ocn_model_s *m, const char *key, int value) {
     if (!strcmp(key, "thin_halos")) { dm->thin_halos = value; return OCN_OK; }
     if (!strcmp(key, "early_exchange")) { dm->early_exchange = value; return OCN_OK; }
     if (!strcmp(key, "strip_width")) { dm->strip_width = value; return OCN_OK; }
+    if (!strcmp(key, "fused_step")) {
+        if (value && !dm->cws) return fail(OCN_ENOTSUP, "fused_step needs a (connected, Periodic, Periodic) slab with the z-fastest substructured solver");
+        dm->fused_step = value != 0;
+        return OCN_OK;
+    }
+    return -1;
+}
+
+static int dist_model_get_option(const ocn_model_s *m, const char *key, int *value) {
+    const DistModel *dm = m->dm;
+    if (!dm) return -1;
+    // which distributed pressure solver the model runs: ocn_dist_poisson_layout's code (4 x-fastest, 1..3 z-fastest, 0 paired columns,
+    // -1 transposing), -2 = the gathered solve on the global grid
+    if (!strcmp(key, "dist_poisson_layout")) { *value = dm->gs ? -2 : -1; return dm->solver ? ocn_dist_poisson_layout(dm->solver, value) : OCN_OK; }
+    if (!strcmp(key, "fused_step")) { *value = dm->fused() ? 1 : 0; return OCN_OK; }
+    if (!strcmp(key, "async_halos")) { *value = dm->async_halos; return OCN_OK; }
+    if (!strcmp(key, "thin_halos")) { *value = dm->thin_halos; return OCN_OK; }
+    if (!strcmp(key, "early_exchange")) { *value = dm->early_exchange; return OCN_OK; }
     return -1;
 }
 

@@ -1583,12 +1583,12 @@ __global__ void __launch_bounds__(64) sub_thomas_kernel(long M, int N, double a,
 // interface unknowns from the gathered payloads (R ranks x (2M + 1)): per mode an R-point DFT over the rank index, 2x2 solves, and
 // the two values this rank needs: gL = l[rank-1], gR = f[rank+1]. out[m] = gL, out[M+m] = gR, out[2M] = mean of mode 0
 __global__ void __launch_bounds__(256) sub_interface_kernel(long M, int Nyh, int N, int R, int rank, double a, const double *ly,
-                                                            const double *lz, const double *svec, const double *ssum0,
+                                                            const double *lz, const double *s_first, const double *s_last, const double *ssum0,
                                                             const double2 *gathered, double2 *out) {
     const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     const long stride = 2 * M + 1;
-    const double alpha = a * svec[m], beta = a * svec[m + M * (N - 1)];
+    const double alpha = a * s_first[m], beta = a * s_last[m];          // s = T⁻¹e₀: its first and its last entry
     const bool null_mode = m == 0 && (ly[0] + lz[0]) == 0.0;
     double2 gl = make_double2(0.0, 0.0), gr = gl;
     double2 mean = gl;
@@ -1748,6 +1748,509 @@ __global__ void __launch_bounds__(256) copy_real_zfast_kernel(DGrid g, FView p, 
         const int i = i0 + tx, k = k0 + kk;
         if (i <= g.Nx && k <= g.Nz) p.at(i, j, k) = tile[tx][kk];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the x-slab pressure step without the passes between its stages (z Periodic, substructured x solve, z-fastest layout).
+//   * the source term reads its periodic neighbours at wrapped interior indices and u[Nx+1] from the receive buffer of the one-column
+//     exchange: no local fill, no unpack before it;
+//   * the pressure correction reads the z-fastest real solution the inverse transform leaves (tiles transposed through LDS, the row
+//     j - 1 kept from the previous iteration of a short march along y) and p[0] from the receive buffer: no copy_real pass, no haloed
+//     copy of p dt, no fill / unpack of it; it writes u, v, w and p / dt like pressure_correction_kernel (same expressions);
+//   * the pack of the early exchange reads wrapped interior rows / levels: no local fill of the strips before it.
+// ---------------------------------------------------------------------------------------------------------------------
+// one interior column of a haloed field -> dense (Ny, Nz) buffers: west[j-1 + Ny (k-1)] = f[iw, j, k], east[...] = f[ie, j, k]
+__global__ void __launch_bounds__(256) column_pack_kernel(DGrid g, FView f, int iw, int ie, double *west, double *east) {
+    const int j = 1 + blockIdx.x * blockDim.x + threadIdx.x, k = 1 + blockIdx.y;
+    if (j > g.Ny || k > g.Nz) return;
+    const long b = (long)(j - 1) + (long)g.Ny * (k - 1);
+    west[b] = f.at(iw, j, k);
+    east[b] = f.at(ie, j, k);
+}
+// the same from the z-fastest dense real array r[(k-1) + Nz ((i-1) + Nx (j-1))]: buffers laid out [k-1 + Nz (j-1)]
+__global__ void __launch_bounds__(256) column_pack_zfast_kernel(int Nx, int Ny, int Nz, const double *r, double *west, double *east) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (k >= Nz || j >= Ny) return;
+    const long b = (long)k + (long)Nz * j;
+    west[b] = r[(long)k + (long)Nz * (0 + (long)Nx * j)];
+    east[b] = r[(long)k + (long)Nz * ((Nx - 1) + (long)Nx * j)];
+}
+
+// source_term_zfast_kernel without halos: y / z neighbours at wrapped interior indices, u[Nx+1, j, k] = ue[j-1 + Ny (k-1)] (the east
+// neighbour's first column, received by the one-column exchange). x connected, y and z Periodic.
+__global__ void __launch_bounds__(256) source_term_zfast_wrapped_kernel(DGrid g, FView u, FView v, FView w, const double *ue, double *r) {
+    __shared__ double tile[32][33];
+    const int i0 = 1 + blockIdx.x * 32, k0 = 1 + blockIdx.y * 32, j = 1 + blockIdx.z;
+    const int tx = threadIdx.x, ty = threadIdx.y;          // block (32, 8)
+    const int jp = j == g.Ny ? 1 : j + 1;
+    for (int kk = ty; kk < 32; kk += 8) {
+        const int i = i0 + tx, k = k0 + kk;
+        if (i <= g.Nx && k <= g.Nz) {
+            const int kq = k - 1 + g.Hz, kp = k == g.Nz ? 1 : k + 1;
+            const double ax = g.ax[kq], ay = g.ay[kq], az = g.az;
+            const double up = i == g.Nx ? ue[(long)(j - 1) + (long)g.Ny * (k - 1)] : u.at(i + 1, j, k);
+            const double dx = ax * up - ax * u.at(i, j, k);
+            const double dy = ay * v.at(i, jp, k) - ay * v.at(i, j, k);
+            const double dz = az * w.at(i, j, kp) - az * w.at(i, j, k);
+            const double div = g.vinv_c[kq] * ((dx + dy) + dz);
+            tile[kk][tx] = 1.0 * div;
+        }
+    }
+    __syncthreads();
+    for (int ii = ty; ii < 32; ii += 8) {
+        const int k = k0 + tx, i = i0 + ii;
+        if (i <= g.Nx && k <= g.Nz) r[(long)(k - 1) + (long)g.Nz * ((i - 1) + (long)g.Nx * (j - 1))] = tile[tx][ii];
+    }
+}
+
+// _make_pressure_correction! + `pNHS ./= Δt⁺` (pressure_correction.jl:31-50) from the z-fastest dense solution pd[(k-1) + Nz ((i-1) +
+// Nx (j-1))] = p Δt, columns ia .. ib. A block owns a 32 (x) x 32 (z) tile and marches over JB rows of y: the tile of row j (with one
+// more column on its low x side and one more level on its low z side) is transposed through LDS, the tile of row j - 1 is the previous
+// iteration's. x: p[0, j, k] = pw[k-1 + Nz (j-1)] (the west neighbour's last column, received); y, z Periodic: wrapped.
+// Same expressions as pressure_correction_kernel.
+#define OCN_ZC_JB 8
+__global__ void __launch_bounds__(256) pressure_correction_zfast_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
+                                                                        FView p, double divisor, int ia, int ib) {
+    __shared__ double T[2][33][33];                   // [buffer][x: i0-1 .. i0+31][z: k0-1 .. k0+31]; odd pitch: no bank conflicts either way
+    const int i0 = ia + blockIdx.x * 32, k0 = 1 + blockIdx.y * 32, jfirst = 1 + blockIdx.z * OCN_ZC_JB;
+    const int tx = threadIdx.x, ty = threadIdx.y;     // block (32, 8)
+    const long sNz = g.Nz, sNx = g.Nx;
+    const int ni = min(min(ib, g.Nx), i0 + 31) - (i0 - 1) + 1;      // columns i0 - 1 .. min(ib, Nx, i0 + 31) of the tile
+    auto load = [&](int buf, int j) {                 // threads along z (the fast index of pd)
+        const int jw = j < 1 ? g.Ny : j;
+        for (int ii = ty; ii < ni; ii += 8) {
+            const int i = i0 - 1 + ii;
+            for (int kk = tx; kk < 33; kk += 32) {
+                int k = k0 - 1 + kk;
+                if (k > g.Nz) continue;
+                if (k < 1) k = g.Nz;
+                T[buf][ii][kk] = i < 1 ? pw[(long)(k - 1) + sNz * (jw - 1)] : pd[(long)(k - 1) + sNz * ((i - 1) + sNx * (jw - 1))];
+            }
+        }
+    };
+    load(0, jfirst - 1);
+    int cur = 1;
+    for (int j = jfirst; j < jfirst + OCN_ZC_JB && j <= g.Ny; ++j, cur ^= 1) {
+        __syncthreads();                              // the previous iteration's readers of T[cur] are done
+        load(cur, j);
+        __syncthreads();
+        const int i = i0 + tx;
+        if (i <= ib && i <= g.Nx) {
+            // the three fields may alias as far as the compiler knows: load the four levels of u, v, w first, then store
+            double uo[4], vo[4], wo[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = min(k0 + ty + 8 * q, g.Nz);
+                uo[q] = u.at(i, j, k); vo[q] = v.at(i, j, k); wo[q] = w.at(i, j, k);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int kk = ty + 8 * q, k = k0 + kk;
+                if (k > g.Nz) continue;
+                const double pc = T[cur][tx + 1][kk + 1];
+                p.at(i, j, k) = pc / divisor;
+                u.at(i, j, k) = uo[q] - (pc - T[cur][tx][kk + 1]) * g.rdx;
+                v.at(i, j, k) = vo[q] - (pc - T[cur ^ 1][tx + 1][kk + 1]) * g.rdy;
+                w.at(i, j, k) = wo[q] - (pc - T[cur][tx + 1][kk]) * g.rdzf[k - 1 + g.Hz];
+            }
+        }
+    }
+}
+
+// the same for the two Hx-wide boundary strips (columns 1 .. H and Nx - H + 1 .. Nx) in one launch: a tile kernel would leave 29 of 32
+// lanes idle, so here a thread owns one cell and reads its four pressure values from the z-fastest array directly -- threads along
+// (column, y) like pressure_correction_kernel on a strip range; the lines of pd are shared by 16 consecutive levels (L2)
+__global__ void __launch_bounds__(256) pressure_correction_zfast_strips_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
+                                                                               FView p, double divisor, int H) {
+    const int c = threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (c >= 2 * H || j > g.Ny || k > g.Nz) return;
+    const int i = c < H ? 1 + c : g.Nx - 2 * H + 1 + c;
+    const long sNz = g.Nz, sNx = g.Nx;
+    const int jm = j == 1 ? g.Ny : j - 1, km = k == 1 ? g.Nz : k - 1;
+    const double pc = pd[(long)(k - 1) + sNz * ((i - 1) + sNx * (j - 1))];
+    const double pim = i == 1 ? pw[(long)(k - 1) + sNz * (j - 1)] : pd[(long)(k - 1) + sNz * ((i - 2) + sNx * (j - 1))];
+    const double pjm = pd[(long)(k - 1) + sNz * ((i - 1) + sNx * (jm - 1))];
+    const double pkm = pd[(long)(km - 1) + sNz * ((i - 1) + sNx * (j - 1))];
+    p.at(i, j, k) = pc / divisor;
+    u.at(i, j, k) -= (pc - pim) * g.rdx;
+    v.at(i, j, k) -= (pc - pjm) * g.rdy;
+    w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the substructured x solve in the FIELDS' OWN layout (x fastest) -- "xfast". The z-fastest variant above pays for its layout
+// twice: the source term and the solution are transposed through LDS (the solution a second time when the pressure correction reads it),
+// and the Thomas sweeps along x touch the spectrum twice in each direction. Here nothing is transposed:
+//   real rhs / solution  r[(i-1) + Nx ((j-1) + Ny (k-1))]           (what source_term_kernel<real> writes, what the dense correction reads)
+//   spectrum             S[i + Nx (ky + Ny kz)],  kz = 0 .. Nz/2      (x lines contiguous: 4 KB at Nx = 256)
+// * z: the real-to-complex transform of TWO neighbouring x columns at once -- (r[2i'], r[2i'+1]) read as one complex number, a complex
+//   radix-4 line FFT along z in LDS (the machinery of strided_line_fft_kernel: ZL pairs = ZL x 16 B rows per workgroup), and the two
+//   columns' half spectra separated with the Hermitian symmetry WHILE THE LINE IS IN LDS (paired_zline_r2c_kernel / _c2r_kernel);
+// * y: strided_line_fft_kernel, as on the single-GPU path;
+// * x: one WAVE per line. A lane holds E consecutive elements; the two Thomas recurrences f_i = (r_i - a f_{i-1}) d_i and
+//   y_i = f_i - a d_i y_{i+1} are affine maps, composed across the 64 lanes by a shuffle scan (6 steps), then re-evaluated inside the lane
+//   with the carried-in value -- the whole solve on ONE read of the line. The payload pass (first / last value per mode) reads only; the
+//   solve pass after the all-gather runs the same kernel on the right-hand side with the interface values in its two end entries
+//   (T p = r - a gL e_0 - a gR e_{N-1}) and writes the final solution: no correction pass, no s = T^-1 e_0 array.
+// Same solution as the z-fastest variant to round-off (the scan re-associates the recurrences); validated at creation and by the
+// partitioned-vs-single-GPU tests at 1e-12.
+// ---------------------------------------------------------------------------------------------------------------------
+#define OCN_FFT_CMUL(ar, ai, w) make_double2((ar) * (w).x - (ai) * (w).y, (ar) * (w).y + (ai) * (w).x)
+#define OCN_FFT_CMULC(v, w) make_double2((v).x * (w).x + (v).y * (w).y, (v).y * (w).x - (v).x * (w).y)
+// forward radix-4 DIF of the ZL lines in zbuf[N][ZL] (natural order in, frequency f at position bitreverse(f) out)
+template <int ZL> __device__ __forceinline__ void lds_fft_forward(double2 *zbuf, const double2 *tw, int N, int logn, int il, int kq) {
+    const int half = N >> 1, quarter = N >> 2, KQ = 256 / ZL;
+#define ZB(n) zbuf[(n) * ZL + il]
+    int h = half, st = 1;
+    if (logn & 1) {
+        for (int q = kq; q < half; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), xb = ZB(b), w = tw[jj * st];
+            ZB(a) = make_double2(xa.x + xb.x, xa.y + xb.y);
+            ZB(b) = OCN_FFT_CMUL(xa.x - xb.x, xa.y - xb.y, w);
+        }
+        __syncthreads();
+        h >>= 1; st <<= 1;
+    }
+    for (; h >= 2; h >>= 2, st <<= 2) {
+        const int h2 = h >> 1;
+        for (int q = kq; q < quarter; q += KQ) {
+            const int jj = q & (h2 - 1), a = ((q - jj) << 2) + jj;
+            const double2 x0 = ZB(a), x1 = ZB(a + h2), x2 = ZB(a + h), x3 = ZB(a + h + h2);
+            const double2 wa = tw[jj * st], wb = tw[(jj + h2) * st], wc = tw[jj * 2 * st];
+            const double2 y0 = make_double2(x0.x + x2.x, x0.y + x2.y), y2 = OCN_FFT_CMUL(x0.x - x2.x, x0.y - x2.y, wa);
+            const double2 y1 = make_double2(x1.x + x3.x, x1.y + x3.y), y3 = OCN_FFT_CMUL(x1.x - x3.x, x1.y - x3.y, wb);
+            ZB(a) = make_double2(y0.x + y1.x, y0.y + y1.y);
+            ZB(a + h2) = OCN_FFT_CMUL(y0.x - y1.x, y0.y - y1.y, wc);
+            ZB(a + h) = make_double2(y2.x + y3.x, y2.y + y3.y);
+            ZB(a + h + h2) = OCN_FFT_CMUL(y2.x - y3.x, y2.y - y3.y, wc);
+        }
+        __syncthreads();
+    }
+#undef ZB
+}
+// inverse radix-4 DIT (frequency f at position bitreverse(f) in, natural order out, unnormalised)
+template <int ZL> __device__ __forceinline__ void lds_fft_inverse(double2 *zbuf, const double2 *tw, int N, int il, int kq) {
+    const int half = N >> 1, quarter = N >> 2, KQ = 256 / ZL;
+#define ZB(n) zbuf[(n) * ZL + il]
+    int h = 1, st = half;
+    for (; (h << 1) <= half; h <<= 2, st >>= 2) {
+        for (int q = kq; q < quarter; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 2) + jj;
+            const double2 x0 = ZB(a), x1 = ZB(a + h), x2 = ZB(a + 2 * h), x3 = ZB(a + 3 * h);
+            const double2 wa = tw[jj * st], wb = tw[jj * (st >> 1)], wc = tw[(jj + h) * (st >> 1)];
+            const double2 t1 = OCN_FFT_CMULC(x1, wa), t3 = OCN_FFT_CMULC(x3, wa);
+            const double2 y0 = make_double2(x0.x + t1.x, x0.y + t1.y), y1 = make_double2(x0.x - t1.x, x0.y - t1.y);
+            const double2 y2 = make_double2(x2.x + t3.x, x2.y + t3.y), y3 = make_double2(x2.x - t3.x, x2.y - t3.y);
+            const double2 u2 = OCN_FFT_CMULC(y2, wb), u3 = OCN_FFT_CMULC(y3, wc);
+            ZB(a) = make_double2(y0.x + u2.x, y0.y + u2.y);
+            ZB(a + 2 * h) = make_double2(y0.x - u2.x, y0.y - u2.y);
+            ZB(a + h) = make_double2(y1.x + u3.x, y1.y + u3.y);
+            ZB(a + 3 * h) = make_double2(y1.x - u3.x, y1.y - u3.y);
+        }
+        __syncthreads();
+    }
+    if (h <= half) {
+        for (int q = kq; q < half; q += KQ) {
+            const int jj = q & (h - 1), a = ((q - jj) << 1) + jj, b = a + h;
+            const double2 xa = ZB(a), t = OCN_FFT_CMULC(ZB(b), tw[jj * st]);
+            ZB(a) = make_double2(xa.x + t.x, xa.y + t.y);
+            ZB(b) = make_double2(xa.x - t.x, xa.y - t.y);
+        }
+        __syncthreads();
+    }
+#undef ZB
+}
+
+// real-to-complex along z of the column PAIRS of a dense x-fastest real array: rp[c + C k] = (r[2c], r[2c+1]) at level k, c = pair index
+// over (x, y) (C = Nx Ny / 2 pairs per level); out: spec[2c + 2C kz], spec[2c + 1 + 2C kz], kz = 0 .. N/2 -- the half spectra of the two
+// columns. With Z = FFT(r_even + i r_odd): X_even[k] = (Z[k] + conj Z[N-k]) / 2, X_odd[k] = (Z[k] - conj Z[N-k]) / (2i).
+template <int ZL>
+__global__ void __launch_bounds__(256) paired_zline_r2c_kernel(const double2 *rp, double2 *spec, const double2 *tw, long C, int N, int logn) {
+    extern __shared__ double2 zbuf[];                 // [N][ZL]
+    const int il = threadIdx.x % ZL, kq = threadIdx.x / ZL, KQ = 256 / ZL;
+    const long c = (long)blockIdx.x * ZL + il;
+    const bool live = c < C;
+    for (int k = kq; k < N; k += KQ) zbuf[k * ZL + il] = live ? rp[c + C * k] : make_double2(0.0, 0.0);
+    __syncthreads();
+    lds_fft_forward<ZL>(zbuf, tw, N, logn, il, kq);
+    if (!live) return;
+    for (int kz = kq; kz <= (N >> 1); kz += KQ) {
+        const int pa = (int)(__brev((unsigned)kz) >> (32 - logn)), pb = (int)(__brev((unsigned)((N - kz) & (N - 1))) >> (32 - logn));
+        const double2 a = zbuf[pa * ZL + il], b = zbuf[pb * ZL + il];
+        double2 *o = spec + 2 * c + 2 * C * (long)kz;
+        o[0] = make_double2(0.5 * (a.x + b.x), 0.5 * (a.y - b.y));
+        o[1] = make_double2(0.5 * (a.y + b.y), -0.5 * (a.x - b.x));
+    }
+}
+// the way back: Z[k] = X_even[k] + i X_odd[k], Z[N-k] = conj X_even[k] + i conj X_odd[k]; the imaginary parts of the k = 0 and k = N/2
+// entries are ignored like a complex-to-real transform ignores them; rp = Re / Im of the inverse transform, times `scale`
+template <int ZL>
+__global__ void __launch_bounds__(256) paired_zline_c2r_kernel(const double2 *spec, double2 *rp, const double2 *tw, long C, int N, int logn, double scale) {
+    extern __shared__ double2 zbuf[];
+    const int il = threadIdx.x % ZL, kq = threadIdx.x / ZL, KQ = 256 / ZL;
+    const long c = (long)blockIdx.x * ZL + il;
+    const bool live = c < C;
+    for (int kz = kq; kz <= (N >> 1); kz += KQ) {
+        const double2 *in = spec + 2 * c + 2 * C * (long)kz;
+        const double2 E = live ? in[0] : make_double2(0.0, 0.0), O = live ? in[1] : make_double2(0.0, 0.0);
+        const int pa = (int)(__brev((unsigned)kz) >> (32 - logn));
+        if (kz == 0 || kz == (N >> 1)) zbuf[pa * ZL + il] = make_double2(E.x, O.x);
+        else {
+            const int pb = (int)(__brev((unsigned)(N - kz)) >> (32 - logn));
+            zbuf[pa * ZL + il] = make_double2(E.x - O.y, E.y + O.x);
+            zbuf[pb * ZL + il] = make_double2(E.x + O.y, O.x - E.y);
+        }
+    }
+    __syncthreads();
+    lds_fft_inverse<ZL>(zbuf, tw, N, il, kq);
+    if (!live) return;
+    for (int k = kq; k < N; k += KQ) {
+        const double2 v = zbuf[k * ZL + il];
+        rp[c + C * k] = make_double2(v.x * scale, v.y * scale);
+    }
+}
+
+// Thomas factors of every mode in the x-fastest layout: rden[i + N m] = 1 / (b_m - a cp[i-1]), cp = a rden (the recurrences of
+// sub_setup_kernel), and of s = T^-1 e_0 only what the interface system needs: its first and last entry (and its sum for the null mode).
+// `scratch` (N M doubles) holds s while it is back-substituted. One thread per mode; runs once.
+__global__ void __launch_bounds__(256) sub_setup_xfast_kernel(long M, int n0, int N, double a, const double *l0, const double *l1, double *rden,
+                                                              double *s_first, double *s_last, double *ssum0, double *scratch) {
+    const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const double b = -2.0 * a - (l0[m % n0] + l1[m / n0]);
+    double *rd = rden + (long)N * m, *sv = scratch + (long)N * m;
+    double c = 0.0;
+    for (int i = 0; i < N; ++i) {
+        const double r = 1.0 / (b - a * c);
+        c = a * r;
+        rd[i] = r;
+    }
+    double y = rd[0];
+    sv[0] = y;
+    for (int i = 1; i < N; ++i) { y = (-a * y) * rd[i]; sv[i] = y; }
+    for (int i = N - 2; i >= 0; --i) sv[i] -= (a * rd[i]) * sv[i + 1];
+    s_first[m] = sv[0];
+    s_last[m] = sv[N - 1];
+    if (m == 0) {
+        double t = 0.0;
+        for (int i = 0; i < N; ++i) t += sv[i];
+        *ssum0 = t;
+    }
+}
+
+// One wave per x line (mode m): the Dirichlet solve y = T^-1 r by Thomas, both recurrences as shuffle scans of affine maps (see the
+// section comment). SOLVE = false: reads only, payload[m] = y[0], payload[M + m] = y[N-1], payload[2M] = sum_i y[i] of mode 0.
+// SOLVE = true: r_0 -= a gL, r_{N-1} -= a gR (iface[m], iface[M + m]) first, writes (y - mean[mode 0]) * scale in place.
+template <int E, bool SOLVE>
+__global__ void __launch_bounds__(256) xline_thomas_kernel(double2 *S, const double *__restrict__ rden, long M, int N, double a, double2 *payload,
+                                                           const double2 *__restrict__ iface, double scale) {
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;                                // whole waves leave together
+    const int lane = threadIdx.x & 63, i0 = lane * E;
+    double2 *line = S + (long)N * m;
+    const double *dl = rden + (long)N * m;
+    double2 r[E], f[E];
+    double d[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool in = i0 + e < N;
+        r[e] = in ? line[i0 + e] : make_double2(0.0, 0.0);
+        d[e] = in ? dl[i0 + e] : 0.0;                  // beyond the line: both maps are the zero map
+    }
+    if (SOLVE) {
+        const double2 gl = iface[m], gr = iface[M + m];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (i0 + e == 0) { r[e].x -= a * gl.x; r[e].y -= a * gl.y; }
+            if (i0 + e == N - 1) { r[e].x -= a * gr.x; r[e].y -= a * gr.y; }
+        }
+    }
+    // forward: f_i = A_i f_{i-1} + B_i, A_i = -a d_i, B_i = r_i d_i
+    double A = 1.0, Bx = 0.0, By = 0.0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const double Ae = -a * d[e];
+        Bx = Ae * Bx + r[e].x * d[e]; By = Ae * By + r[e].y * d[e];
+        A = Ae * A;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double Ap = __shfl_up(A, off, 64), Bpx = __shfl_up(Bx, off, 64), Bpy = __shfl_up(By, off, 64);
+        if (lane >= off) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
+    }
+    double2 prev = make_double2(__shfl_up(Bx, 1, 64), __shfl_up(By, 1, 64));
+    if (lane == 0) prev = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        f[e] = make_double2((r[e].x - a * prev.x) * d[e], (r[e].y - a * prev.y) * d[e]);
+        prev = f[e];
+    }
+    // backward: y_i = f_i - (a d_i) y_{i+1}
+    A = 1.0; Bx = 0.0; By = 0.0;
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        const double Ae = -(a * d[e]);
+        Bx = Ae * Bx + f[e].x; By = Ae * By + f[e].y;
+        A = Ae * A;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double Ap = __shfl_down(A, off, 64), Bpx = __shfl_down(Bx, off, 64), Bpy = __shfl_down(By, off, 64);
+        if (lane + off < 64) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
+    }
+    prev = make_double2(__shfl_down(Bx, 1, 64), __shfl_down(By, 1, 64));
+    if (lane == 63) prev = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int e = E - 1; e >= 0; --e) {
+        const double c = a * d[e];
+        f[e] = make_double2(f[e].x - c * prev.x, f[e].y - c * prev.y);       // f now holds y
+        prev = f[e];
+    }
+    if (SOLVE) {
+        const double2 mu = m == 0 ? iface[2 * M] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            if (i0 + e < N) line[i0 + e] = make_double2((f[e].x - mu.x) * scale, (f[e].y - mu.y) * scale);
+    } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (i0 + e == 0) payload[m] = f[e];
+            if (i0 + e == N - 1) payload[M + m] = f[e];
+        }
+        if (m == 0) {
+            double sx = 0.0, sy = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) { sx += f[e].x; sy += f[e].y; }        // entries beyond the line are zero
+            for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
+            if (lane == 0) payload[2 * M] = make_double2(sx, sy);
+        }
+    }
+}
+
+// known-answer check of the paired z transform at solver creation: pair c, level k holds (cos(2 pi k / N), sin(2 pi 3 k / N)) scaled by
+// a pair-dependent amplitude; expected: X_even[1] = amp N/2, X_odd[3] = -i amp N/2, zero elsewhere (N >= 8; sampled on 256 pairs)
+__device__ __forceinline__ double xfast_kat_amp(long c) { return 1.0 + 0.25 * (double)(c % 7); }
+__global__ void __launch_bounds__(256) xfast_kat_fill_kernel(double2 *rp, long C, int N) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * N) return;
+    const long c = t % C;
+    const int k = (int)(t / C);
+    double s3, c3, s5, c5;
+    sincospi(2.0 * 1.0 * (double)k / (double)N, &s3, &c3);
+    sincospi(2.0 * 3.0 * (double)k / (double)N, &s5, &c5);
+    (void)s3; (void)c5;
+    rp[t] = make_double2(xfast_kat_amp(c) * c3, xfast_kat_amp(c) * s5);
+}
+__global__ void __launch_bounds__(256) xfast_kat_check_kernel(const double2 *spec, long C, int N, double *out) {
+    __shared__ double sm[256];
+    const long c = (C - 1) * (long)threadIdx.x / 255;               // 256 pairs spread over the array
+    double worst = 0.0;
+    for (int kz = 0; kz <= N / 2; ++kz) {
+        const double2 E = spec[2 * c + 2 * C * (long)kz], O = spec[2 * c + 1 + 2 * C * (long)kz];
+        const double amp = xfast_kat_amp(c);
+        const double2 eE = kz == 1 ? make_double2(amp * N / 2.0, 0.0) : make_double2(0.0, 0.0);
+        const double2 eO = kz == 3 ? make_double2(0.0, -amp * N / 2.0) : make_double2(0.0, 0.0);
+        worst = fmax(worst, fmax(fmax(fabs(E.x - eE.x), fabs(E.y - eE.y)), fmax(fabs(O.x - eO.x), fabs(O.y - eO.y))));
+    }
+    sm[threadIdx.x] = worst;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+__global__ void __launch_bounds__(256) xfast_kat_check_real_kernel(const double2 *rp, long C, int N, double *out) {
+    __shared__ double sm[256];
+    const long c = (C - 1) * (long)threadIdx.x / 255;
+    double worst = 0.0;
+    for (int k = 0; k < N; ++k) {
+        double s3, c3, s5, c5;
+        sincospi(2.0 * 1.0 * (double)k / (double)N, &s3, &c3);
+        sincospi(2.0 * 3.0 * (double)k / (double)N, &s5, &c5);
+        (void)s3; (void)c5;
+        const double2 v = rp[c + C * (long)k];
+        worst = fmax(worst, fmax(fabs(v.x - xfast_kat_amp(c) * c3), fabs(v.y - xfast_kat_amp(c) * s5)));
+    }
+    sm[threadIdx.x] = worst;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sm[threadIdx.x] = fmax(sm[threadIdx.x], sm[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sm[0];
+}
+// dense x-fastest real array -> interior of the haloed (Center, Center, Center) field
+__global__ void __launch_bounds__(256) copy_dense_to_field_kernel(DGrid g, FView phi, const double *r) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    phi.at(i, j, k) = r[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))];
+}
+
+// compute_source_term! into the dense x-fastest real array with NO halo read: y / z neighbours at wrapped interior indices, u[Nx+1, j, k]
+// from `ue` (the east neighbour's first column, dense (Ny, Nz)); expression of source_value (weight_by_dz = false)
+__global__ void __launch_bounds__(256) source_term_dense_wrapped_kernel(DGrid g, FView u, FView v, FView w, const double *ue, double *r) {
+    const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > g.Nx || j > g.Ny || k > g.Nz) return;
+    const int kq = k - 1 + g.Hz, jp = j == g.Ny ? 1 : j + 1, kp = k == g.Nz ? 1 : k + 1;
+    const double ax = g.ax[kq], ay = g.ay[kq], az = g.az;
+    const double up = i == g.Nx ? ue[(long)(j - 1) + (long)g.Ny * (k - 1)] : u.at(i + 1, j, k);
+    const double dx = ax * up - ax * u.at(i, j, k);
+    const double dy = ay * v.at(i, jp, k) - ay * v.at(i, j, k);
+    const double dz = az * w.at(i, j, kp) - az * w.at(i, j, k);
+    const double div = g.vinv_c[kq] * ((dx + dy) + dz);
+    r[(long)(i - 1) + (long)g.Nx * ((j - 1) + (long)g.Ny * (k - 1))] = 1.0 * div;
+}
+
+// first / last column of the dense x-fastest array -> dense (Ny, Nz) buffers [j-1 + Ny (k-1)]
+__global__ void __launch_bounds__(256) column_pack_dense_kernel(int Nx, int Ny, int Nz, const double *r, double *west, double *east) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (j >= Ny || k >= Nz) return;
+    const long row = (long)Nx * (j + (long)Ny * k), b = (long)j + (long)Ny * k;
+    west[b] = r[row];
+    east[b] = r[row + Nx - 1];
+}
+
+// pressure_correction_dense_kernel on the columns ia .. ib of a partitioned slab: p[0, j, k] = pw[j-1 + Ny (k-1)] (the west neighbour's
+// last column, received) instead of the periodic wrap; y and z Periodic. Same expressions.
+__global__ void __launch_bounds__(256) pressure_correction_dense_slab_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
+                                                                             FView p, double divisor, int ia, int ib) {
+    const int i = ia + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = 1 + blockIdx.z;
+    if (i > ib || j > g.Ny || k > g.Nz) return;
+    const long sx = g.Nx, sxy = (long)g.Nx * g.Ny;
+    const long q = (long)(i - 1) + sx * (j - 1) + sxy * (k - 1);
+    const double pc = pd[q];
+    const double pim = i == 1 ? pw[(long)(j - 1) + (long)g.Ny * (k - 1)] : pd[q - 1];
+    const double pjm = pd[j == 1 ? q + sx * (g.Ny - 1) : q - sx];
+    const double pkm = pd[k == 1 ? q + sxy * (g.Nz - 1) : q - sxy];
+    u.at(i, j, k) -= (pc - pim) * g.rdx;
+    v.at(i, j, k) -= (pc - pjm) * g.rdy;
+    w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
+    p.at(i, j, k) = pc / divisor;
+}
+// ... and on the two Hx-wide boundary strips in one launch (threads along (column, y))
+__global__ void __launch_bounds__(256) pressure_correction_dense_strips_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
+                                                                               FView p, double divisor, int H) {
+    const int c = threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
+    if (c >= 2 * H || j > g.Ny || k > g.Nz) return;
+    const int i = c < H ? 1 + c : g.Nx - 2 * H + 1 + c;
+    const long sx = g.Nx, sxy = (long)g.Nx * g.Ny;
+    const long q = (long)(i - 1) + sx * (j - 1) + sxy * (k - 1);
+    const double pc = pd[q];
+    const double pim = i == 1 ? pw[(long)(j - 1) + (long)g.Ny * (k - 1)] : pd[q - 1];
+    const double pjm = pd[j == 1 ? q + sx * (g.Ny - 1) : q - sx];
+    const double pkm = pd[k == 1 ? q + sxy * (g.Nz - 1) : q - sxy];
+    u.at(i, j, k) -= (pc - pim) * g.rdx;
+    v.at(i, j, k) -= (pc - pjm) * g.rdy;
+    w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
+    p.at(i, j, k) = pc / divisor;
 }
 
 // per-block max |a - b| (plan cross-checks)
@@ -1922,6 +2425,26 @@ __global__ void __launch_bounds__(256) x_halo_buffer_kernel(FieldList fl, SlabLi
             if (do_west) p[row + HX - H + h] = west[b];
             if (do_east) p[row + N + HX + h] = east[b];
         }
+    }
+}
+
+// fill_send_buffers! of x_halo_buffer_kernel<true> with the y / z halo rows read at their WRAPPED interior source (y, z Periodic, every
+// field with parent extents (Px, Ny + 2Hy, Nz + 2Hz)): what the buffers would hold after a local fill of the packed columns
+__global__ void __launch_bounds__(256) x_halo_pack_wrapped_kernel(FieldList fl, SlabList sl, int N, int HX, int H, int Ny, int Hy, int Nz, int Hz,
+                                                                  double *west, double *east) {
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int h = t % H;
+    const long r = t / H;                      // j + P1 * k over the parent extents
+    const int P1 = Ny + 2 * Hy;
+    const int jp = (int)(r % P1), kp = (int)(r / P1);
+    if (kp >= Nz + 2 * Hz) return;
+    const int js = Hy + ((jp - Hy) % Ny + Ny) % Ny, ks = Hz + ((kp - Hz) % Nz + Nz) % Nz;
+    for (int f = 0; f < fl.n; ++f) {
+        const double *p = fl.p[f];
+        const long row = ((long)js + (long)P1 * ks) * sl.p0[f];
+        const long b = sl.off[f] + t;
+        west[b] = p[row + HX + h];
+        east[b] = p[row + HX + N - H + h];
     }
 }
 

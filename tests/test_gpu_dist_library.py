@@ -99,6 +99,41 @@ def test_library_self_loop_over_rccl_equals_single_gpu(ocn, arch, size, zkind, s
         assert np.array_equal(out[name][:3, 3:-3, 3:-3], out[name][-6:-3, 3:-3, 3:-3]), name
 
 
+@pytest.mark.parametrize("size,R", [((32, 16, 8), 1), ((64, 16, 16), 2), ((384, 8, 8), 2), ((1536, 8, 8), 2)])
+def test_library_x_solve_layouts_agree(ocn, arch, size, R):
+    """the x-fastest substructured solve (paired z transform in LDS + one-wave-per-line Thomas scans, with 1, 4, 8 and 16 elements of a
+    line per lane: local Nx = 32, 32, 192, 768) against the z-fastest one (option dist_xfast = 0) and, with and without the pressure step
+    that skips the fills / copies between its stages (fused_step), against the single-GPU model: three RK3 steps, 1e-12"""
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _own_stream()
+    ref, time, dt = _single_gpu(ocn, arch, size, "periodic", 3)
+    nxl = size[0] // R
+    for xfast, fused in ((1, 1), (1, 0), (0, 1), (0, 0)):
+        ocn.set_option("dist_xfast", xfast)
+        try:
+            if R == 1:
+                uid = C.create_string_buffer(128)
+                _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+                ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
+                grid, model = _library_model(ocn, dist, ctx, size, "periodic")
+                assert model.get_option("dist_poisson_layout") in ((4,) if xfast else (1, 2, 3))
+                model.set_option("fused_step", fused)
+                assert model.get_option("fused_step") == fused
+                for _ in range(3):
+                    ocn.time_step(model, dt)
+                results = [({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent()}, ocn.max_abs_divergence(model),
+                            model.clock.time, None)]
+                model.close()
+                ctx.close()
+            else:
+                results = _run_library_ranks(ocn, arch, R, size, 3, "periodic", {"fused_step": fused})
+        finally:
+            ocn.set_option("dist_xfast", 1)
+        for r, (out, div, t, _off) in enumerate(results):
+            assert div < 5e-8 and t == time, (xfast, fused)
+            _compare(out, ref, r, nxl, size)
+
+
 def test_library_collectives_over_rccl_world_1(ocn, arch):
     """the raw collectives of the boundary with a one-rank RCCL communicator: an exchange swaps the sides (what leaves through the
     west side arrives in the east halo), all-to-all / all-gather are copies, the reduction returns its argument"""

@@ -15,6 +15,8 @@ model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
 flds = model.fields()
 ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in flds.items()}, 1234))
 model.set_option("tendency_impl", 2)
+arith = int(os.environ.get("OCN_ARITHMETIC", "0"))      # 1: the opt-in contracted WENO flux
+ocn.set_option("arithmetic", arith)
 model.set_option("role_kchunk", kc)
 for _ in range(5): ocn.update_state(model, True)
 ocn.synchronize()
@@ -32,5 +34,5 @@ for rep in range(6):
     for _ in range(6): ocn.time_step(model, dt)
     ms, n = model.profile_read(); model.set_option("profile", 0)
     avg.append(ms / n)
-print("role kernel %s kchunk %d: plain min %.3f median %.3f | in time_step (2 of 3 with substep) min %.3f median %.3f ms" %
-      ("x".join(map(str, shape)), kc, min(res), sorted(res)[len(res) // 2], min(avg), sorted(avg)[len(avg) // 2]), flush=True)
+print("arithmetic %d role kernel %s kchunk %d: plain min %.3f median %.3f | in time_step (2 of 3 with substep) min %.3f median %.3f ms" %
+      (arith, "x".join(map(str, shape)), kc, min(res), sorted(res)[len(res) // 2], min(avg), sorted(avg)[len(avg) // 2]), flush=True)
