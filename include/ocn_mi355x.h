@@ -348,7 +348,7 @@ int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, 
  *   x-slab solve: "dist_substructured" (1: gathered interface solve, 0: the reference's two transposes), "dist_zfirst" (z-fastest
  *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform);
  *   fused tendency kernel: "fused_ty" (tile rows 3 | 7), "fused_kchunk" (levels per workgroup, 0 = automatic), "fused_minw",
- *     "fused_zwin" (register z-windows), "fused_lds" (LDS-tile variant), "fused_xcd" (XCD-aware tile order; measured: no effect);
+ *     "fused_zwin" (register z-windows), "fused_xcd" (XCD-aware tile order; measured: no effect);
  *   halo fills: "fused_halo" (one launch per periodic fill);
  *   "arithmetic": 0 (default) the reference's IEEE operation sequence in every kernel -- results bit-identical to a faithful CPU
  *     evaluation of weno_interpolants.jl; 1 the opt-in CONTRACTED WENO-5 flux of the flux-sharing tendency kernel (fma-contracted

@@ -5,7 +5,6 @@
 #include "ocn_kernels.h"
 #include "ocn_tendency_fused.h"
 #include "ocn_tendency_roles.h"
-#include "ocn_tendency_lds.h"
 #include <hipfft/hipfft.h>
 #include <cmath>
 #include <cstdarg>
@@ -311,7 +310,7 @@ static int check_range(const DGrid &g, const int *range, Range6 *out, const int 
 static int g_fused_halo = 1;     // triply periodic grids: the three directional periodic fills as one launch
 
 static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n, const int loc[3], bool fill_open,
-                           const ocn_bc_t (*bcs)[6]) {
+                           const ocn_bc_t (*bcs)[6], bool extend_x = false) {
     if (n <= 0) return OCN_OK;
     const DGrid &g = grid->d;
     FieldList fl;
@@ -337,7 +336,8 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         const int H0 = T[0] == OCN_CONNECTED ? 0 : H[0], N0 = T[0] == OCN_CONNECTED ? P[0] : N[0];
         const long total = (zfill ? (long)P[0] * P[1] * 2 : 0) + ((long)P[0] * (2 * H[1]) + (long)(2 * H0) * N[1]) * (P[2] - (zfill ? 2 : 0));
         hipLaunchKernelGGL(fill_periodic_xy_bounded_z_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, g_stream, fl, bc, P[0], P[1],
-                           P[2], N0, N[1], N[2], H0, H[1], H[2], face, zfill, T[0] == OCN_CONNECTED ? H[0] : 0, N[0]);
+                           P[2], N0, N[1], N[2], H0, H[1], H[2], face, zfill, T[0] == OCN_CONNECTED ? H[0] : 0, N[0],
+                           extend_x && T[0] == OCN_CONNECTED ? 1 : 0);
         KERNEL_CHECK();
         return OCN_OK;
     }
@@ -363,7 +363,13 @@ static int fill_halo_group(const ocn_grid_s *grid, double *const *fields, int n,
         const int nb = (int)((total + 255) / 256);
         if (d == 0) hipLaunchKernelGGL(fill_bounded_kernel<0>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[0], face, fill_open, do_lo, do_hi);
         if (d == 1) hipLaunchKernelGGL(fill_bounded_kernel<1>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[1], face, fill_open, do_lo, do_hi);
-        if (d == 2) hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nb), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open);
+        if (d == 2) {
+            // connected x sides of an x-slab rank's diffusivity fields: the first halo column takes the z fill too (see fill_bounded_kernel)
+            const int el = extend_x && (T[0] == OCN_CONNECTED || T[0] == OCN_LEFT_CONNECTED) ? 1 : 0;
+            const int eh = extend_x && (T[0] == OCN_CONNECTED || T[0] == OCN_RIGHT_CONNECTED) ? 1 : 0;
+            const int nbe = (int)(((long)(Na + el + eh) * Nb + 255) / 256);
+            hipLaunchKernelGGL(fill_bounded_kernel<2>, dim3(nbe), dim3(256), 0, g_stream, fl, bc, view, Na, Nb, N[2], face, fill_open, true, true, el, eh);
+        }
     }
     // triply periodic with N >= H everywhere: one launch writes every halo cell from its wrapped interior source
     if (g_fused_halo && T[0] == OCN_PERIODIC && T[1] == OCN_PERIODIC && T[2] == OCN_PERIODIC && N[0] >= H[0] && N[1] >= H[1] && N[2] >= H[2]) {
@@ -412,7 +418,7 @@ static int validate_bc(const DGrid &g, const int loc[3], int side, int kind) {
 
 // groups fields by identical location (identical parent shape) -> one set of launches per group
 static int fill_halo_regions(const ocn_grid_s *grid, double *const *fields, const int (*locs)[3], int nfields, bool fill_open,
-                             const ocn_bc_t (*bcs)[6] = nullptr) {
+                             const ocn_bc_t (*bcs)[6] = nullptr, bool extend_x = false) {
     const DGrid &g = grid->d;
     if (nfields > OCN_MAX_FIELDS) return fail(OCN_EINVAL, "at most %d fields per call", OCN_MAX_FIELDS);
     bool done[OCN_MAX_FIELDS] = {false};
@@ -437,7 +443,7 @@ static int fill_halo_regions(const ocn_grid_s *grid, double *const *fields, cons
                 done[h] = true;
             }
         }
-        int rc = fill_halo_group(grid, grp, n, locs[f], fill_open, bcs ? gbc : nullptr);
+        int rc = fill_halo_group(grid, grp, n, locs[f], fill_open, bcs ? gbc : nullptr, extend_x);
         if (rc) return rc;
     }
     return OCN_OK;
@@ -2436,7 +2442,6 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "role_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "role_kchunk must be >= 0 (0 = automatic)"); g_role_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "fused_minw")) { g_fused_minw = value; return OCN_OK; }
     if (!strcmp(key, "fused_zwin")) { g_fused_zwin = value; return OCN_OK; }
-    if (!strcmp(key, "fused_lds")) { g_fused_lds = value; return OCN_OK; }
     if (!strcmp(key, "fused_xcd")) { g_fused_xcd = value; return OCN_OK; }
     if (!strcmp(key, "fused_zfft")) { g_fused_zfft = value; return OCN_OK; }
     if (!strcmp(key, "fused_halo")) { g_fused_halo = value; return OCN_OK; }
@@ -2581,7 +2586,9 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
         K[0] = m->nu_e;
         for (int t = 0; t < m->ntr; ++t) K[1 + t] = m->kappa_e[t];
         for (int q = 0; q < 1 + m->ntr; ++q) memcpy(kl[q], LOC_C, sizeof(int) * 3);
-        if ((rc = fill_halo_regions(m->grid, K, kl, 1 + m->ntr, true, m->any_kbc ? m->kbcs : nullptr))) return rc;
+        // (on an x-slab rank amd_range includes i = 0 and Nx + 1: their z halo cell is filled too, the value a serial run's periodic x
+        // fill copies there -- the reference's only_local_halos fill leaves it unwritten on a partitioned grid, halo_communication.jl:87-110)
+        if ((rc = fill_halo_regions(m->grid, K, kl, 1 + m->ntr, true, m->any_kbc ? m->kbcs : nullptr, amd_range != nullptr))) return rc;
     }
     // compute_auxiliaries!: update_hydrostatic_pressure! (update_nonhydrostatic_model_state.jl:58-69)
     if (m->buoyancy_kind &&

@@ -665,17 +665,21 @@ struct BcSides {
     }
 };
 
+// ea_lo / ea_hi (z fill of an x-slab rank's DIFFUSIVITY fields only): also fill the first halo column on a connected x side -- the rank
+// evaluates the eddy diffusivities at i = 0 / Nx + 1 itself, and a serial Periodic run's x fill copies the z-filled value into those
+// cells (the closure's corner interpolations at the rank edge read them); an array-valued condition is read at the nearest interior point
 template <int D>
 __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides bc, FView view, int Na, int Nb, int N, bool face,
-                                                           bool fill_open, bool do_lo = true, bool do_hi = true) {   // one-sided: Left / RightConnected x
+                                                           bool fill_open, bool do_lo = true, bool do_hi = true, int ea_lo = 0, int ea_hi = 0) {   // one-sided: Left / RightConnected x
     long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)Na * Nb) return;
-    int a = 1 + t % Na, b = 1 + t / Na;
+    const int Nae = Na + ea_lo + ea_hi;
+    if (t >= (long)Nae * Nb) return;
+    int a = 1 - ea_lo + t % Nae, b = 1 + t / Nae;
     long lo, ilo, hi, ihi;
     if (D == 0) { lo = view.lin(face ? 1 : 0, a, b); ilo = view.lin(1, a, b); hi = view.lin(N + 1, a, b); ihi = view.lin(N, a, b); }
     else if (D == 1) { lo = view.lin(a, face ? 1 : 0, b); ilo = view.lin(a, 1, b); hi = view.lin(a, N + 1, b); ihi = view.lin(a, N, b); }
     else { lo = view.lin(a, b, face ? 1 : 0); ilo = view.lin(a, b, 1); hi = view.lin(a, b, N + 1); ihi = view.lin(a, b, N); }
-    const long ab = (long)(a - 1) + (long)Na * (b - 1);
+    const long ab = (long)(min(max(a, 1), Na) - 1) + (long)Na * (b - 1);
     for (int f = 0; f < fl.n; ++f) {
         double *p = fl.p[f];
         if (!face) {
@@ -705,9 +709,10 @@ __global__ void __launch_bounds__(256) fill_bounded_kernel(FieldList fl, BcSides
 // Each such cell is written here directly from those sources: same bits, a third of the launches. `zfill`: the z fill runs (Center
 // fields always; Face fields when fill_open_bcs). An x-slab rank (x halos owned by the neighbours) passes H0 = 0, N0 = P0 and XC = Hx:
 // its XC outermost columns are left to the exchange -- in the z-boundary planes they only take part in the periodic y copy.
+// XZ (diffusivity fields of an x-slab rank, see fill_bounded_kernel): the innermost XZ of the XC neighbour columns take the z formula too.
 __global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldList fl, BcSides bc, int P0, int P1, int P2, int N0, int N1,
                                                                          int N2, int H0, int H1, int H2, bool face, bool zfill, int XC,
-                                                                         int NA) {
+                                                                         int NA, int XZ = 0) {
     const int klo = face ? H2 : H2 - 1, khi = N2 + H2;                       // 0-based parent planes of the z fill
     const long nA = zfill ? (long)P0 * P1 * 2 : 0;
     const int nplanes = P2 - (zfill ? 2 : 0);
@@ -719,13 +724,13 @@ __global__ void __launch_bounds__(256) fill_periodic_xy_bounded_z_kernel(FieldLi
         const int sj = j < H1 ? j + N1 : (j >= H1 + N1 ? j - N1 : j);
         const long col = si + (long)P0 * sj, plane = (long)P0 * P1;
         const long od = i + (long)P0 * j + plane * (side ? khi : klo);
-        if (i < XC || i >= P0 - XC) {                                       // a neighbour's column: periodic y copy only
+        if (i < XC - XZ || i >= P0 - XC + XZ) {                             // a neighbour's column: periodic y copy only
             if (sj == j) return;
             const long os = col + plane * (side ? khi : klo);
             for (int f = 0; f < fl.n; ++f) fl.p[f][od] = fl.p[f][os];
             return;
         }
-        const long ab = (long)(si - H0 - XC) + (long)NA * (sj - H1);        // tangential interior point (i, j) of the source column
+        const long ab = (long)min(max(si - H0 - XC, 0), NA - 1) + (long)NA * (sj - H1);      // tangential interior point (i, j) of the source column
         for (int f = 0; f < fl.n; ++f) {
             double *p = fl.p[f];
             double val;

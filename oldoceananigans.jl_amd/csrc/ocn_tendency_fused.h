@@ -341,7 +341,6 @@ static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
 // kchunk = 0: levels per workgroup chosen per launch so that the grid fills whole rounds of the chip (see pick_kchunk)
 static int g_fused_ty = 7, g_fused_kchunk = 0, g_fused_minw = 2, g_fused_zwin = 1;
 static int g_fused_xcd = 0;     // XCD-aware tile order (FusedArgs::xcd_swizzle): measured 1.445 vs 1.440 ms at 256^3 -- no effect, off
-static int g_fused_lds = 0;     // 1: x / y windows from an LDS tile copy (ocn_tendency_lds.h), ntracers <= 2
 static int g_num_cus = 256;
 
 // Each workgroup primes 3 planes before its first cell closes, and the grid runs in rounds of one workgroup per CU (2 waves
@@ -358,7 +357,6 @@ static inline int pick_kchunk(int tiles_xy, int nz) {
     return best;
 }
 
-template <int NTR, int TY> static int launch_fused_lds_t(const DGrid &g, hipStream_t stream, FusedArgs &a);   // ocn_tendency_lds.h
 
 template <int NTR, int TY>
 static int launch_fused_t(const DGrid &g, hipStream_t stream, FusedArgs &a) {
@@ -417,11 +415,6 @@ static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, cons
     case NTR:                                                                        \
         if (g_fused_ty == 3) return launch_fused_t<NTR, 3>(g, stream, a);            \
         return launch_fused_t<NTR, 7>(g, stream, a);
-    if (g_fused_lds && g.Hx >= 3 && g.Hy >= 3) {
-        if (ntr == 0) return launch_fused_lds_t<0, 7>(g, stream, a);
-        if (ntr == 1) return launch_fused_lds_t<1, 7>(g, stream, a);
-        if (ntr == 2) return launch_fused_lds_t<2, 7>(g, stream, a);
-    }
     switch (ntr) {
         OCN_FUSED_CASE(0)
         OCN_FUSED_CASE(1)

@@ -224,6 +224,11 @@ class RectilinearGrid:
         for name, H, N in (("x", self.Hx, self.Nx), ("y", self.Hy, self.Ny)):      # input_validation.jl:86-92 (x and y only)
             if not H <= N:
                 raise ValueError(f"halo={H} must be ≤ size={N} for coordinate {name}")
+        if not self.Hz <= self.Nz:
+            # the reference's validate_halo does not look at z; its halo fills then index outside the array. The library refuses such a
+            # grid (ocn_grid_create) -- say so here, where the grid is written down, not when the lazy handle is first touched
+            raise ValueError(f"halo={self.Hz} must be ≤ size={self.Nz} for coordinate z (the reference checks x and y only, input_validation.jl:86-92; "
+                             "libocn_mi355x needs it in z too)")
         if extent is not None:
             if any(c is not None for c in (x, y, z)):
                 raise ValueError("Cannot specify both extent and x, y, z keyword arguments!")
@@ -240,8 +245,9 @@ class RectilinearGrid:
         self.Δyᵃᶜᵃ, self.Ly, self.y0 = _regular_coordinate(y, self.Ny, "y")
         self.Δxᶠᵃᵃ, self.Δyᵃᶠᵃ = self.Δxᶜᵃᵃ, self.Δyᵃᶜᵃ
         # node coordinates with halos (grid.xᶠᵃᵃ, xᶜᵃᵃ, yᵃᶠᵃ, yᵃᶜᵃ; array position H holds node 1): Julia ranges, see julia_range
-        self.xᶠᵃᵃ, self.xᶜᵃᵃ = (np.full(1, self.x0),) * 2 if flat[0] else _regular_nodes((self.x0, self.x0 + self.Lx), self.Nx, self.Hx, self.topology[0])
-        self.yᵃᶠᵃ, self.yᵃᶜᵃ = (np.full(1, self.y0),) * 2 if flat[1] else _regular_nodes((self.y0, self.y0 + self.Ly), self.Ny, self.Hy, self.topology[1])
+        # (the USER's end points go in: c₁, c₂ = BigFloat.(node_interval), grid_generation.jl:104-105 -- x0 + Lx is not always c₂ in Float64)
+        self.xᶠᵃᵃ, self.xᶜᵃᵃ = (np.full(1, self.x0),) * 2 if flat[0] else _regular_nodes((float(x[0]), float(x[1])), self.Nx, self.Hx, self.topology[0])
+        self.yᵃᶠᵃ, self.yᵃᶜᵃ = (np.full(1, self.y0),) * 2 if flat[1] else _regular_nodes((float(y[0]), float(y[1])), self.Ny, self.Hy, self.topology[1])
         n = self.Nz + 2 * self.Hz + 1
         if isinstance(z, tuple) and len(z) == 2 and np.isscalar(z[0]):
             dz, self.Lz, self.z0 = _regular_coordinate(z, self.Nz, "z")
@@ -249,7 +255,7 @@ class RectilinearGrid:
             self.Δzᵃᵃᶜ = np.full(n, dz)
             self.Δzᵃᵃᶠ = np.full(n, dz)
             self._dz = dz
-            self.zᵃᵃᶠ, self.zᵃᵃᶜ = (np.full(1, self.z0),) * 2 if flat[2] else _regular_nodes((self.z0, self.z0 + self.Lz), self.Nz, self.Hz, self.topology[2])
+            self.zᵃᵃᶠ, self.zᵃᵃᶜ = (np.full(1, self.z0),) * 2 if flat[2] else _regular_nodes((float(z[0]), float(z[1])), self.Nz, self.Hz, self.topology[2])
         else:
             if self.topology[2] is not Bounded:
                 raise NotImplementedError("a stretched z coordinate requires a Bounded z topology")

@@ -17,17 +17,13 @@ from .grids import Flat
 def cell_advection_timescale(model):
     """min over cells of 1 / (|u|/Δx + |v|/Δy + |w|/Δz); on a distributed model the minimum over ranks"""
     tau = C.c_double()
-    if hasattr(model, "backend"):                     # DistributedNonhydrostaticModel
-        b = model.backend
-        _lib.check(_lib.lib().ocn_cell_advection_timescale(model.grid.local.handle, b.U[0].data, b.U[1].data, b.U[2].data, C.byref(tau)))
-        return -model.ctx.allreduce_max(-tau.value)
     _lib.check(_lib.lib().ocn_model_cell_advection_timescale(model.handle, C.byref(tau)))
     return tau.value
 
 
 def cell_diffusion_timescale(model):
     """min(Δ² / ν, Δ² / max κ) with Δ the smallest spacing (ThreeDimensionalFormulation); Inf without a closure"""
-    closure = getattr(model, "closure", None) or getattr(getattr(model, "backend", None), "closure", None)
+    closure = getattr(model, "closure", None)
     if closure is None:
         return math.inf
     grid = model.grid.local if hasattr(model.grid, "local") else model.grid
@@ -36,12 +32,8 @@ def cell_diffusion_timescale(model):
     from .closures import AnisotropicMinimumDissipation
     if isinstance(closure, AnisotropicMinimumDissipation):
         # the eddy coefficients are fields: Δ² / max(νₑ, κₑ) over the model's diffusivity fields (and over the ranks)
-        D = getattr(model, "diffusivity_fields", None)
-        if D is not None:
-            arrays = [D[0].parent()] + [k.parent() for k in D[1]]
-        else:
-            b = model.backend
-            arrays = [b.nu_e.parent()] + [k.parent() for k in b.kappa_e]
+        D = model.diffusivity_fields
+        arrays = [D[0].parent()] + [k.parent() for k in D[1]]
         biggest = max(float(np.max(a)) for a in arrays)
         if hasattr(model, "ctx") and hasattr(model.ctx, "allreduce_max"):
             biggest = model.ctx.allreduce_max(biggest)
@@ -104,9 +96,7 @@ def new_time_step(old_Δt, wizard, model):
 def hasnan(obj):
     """hasnan(field) = any(isnan, parent(field)); hasnan(model) checks the first prognostic field (nan_checker.jl:32-33)"""
     field = obj
-    if hasattr(obj, "backend"):
-        field = obj.backend.U[0]
-    elif hasattr(obj, "velocities"):
+    if hasattr(obj, "velocities"):
         field = obj.velocities.u
     r = C.c_int()
     _lib.check(_lib.lib().ocn_hasnan(field.data, field.nbytes // 8, C.byref(r)))
@@ -136,7 +126,7 @@ class NaNChecker:
 
 def default_nan_checker(model):
     """NaNChecker on the first prognostic field, u (Models/Models.jl:173-184)"""
-    return NaNChecker({"u": model.velocities.u if hasattr(model, "velocities") else model.backend.U[0]})
+    return NaNChecker({"u": model.velocities.u})
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -237,10 +227,7 @@ class Simulation:
     def initialize(self):
         """initialize!(sim) (run.jl:196-251): update_state!, schedules, callbacks at iteration 0"""
         from .models import update_state
-        if hasattr(self.model, "backend"):             # DistributedNonhydrostaticModel (host-orchestrated partitioned model)
-            from . import distributed
-            distributed.update_state(self.model, True)
-        elif hasattr(self.model, "handle"):
+        if hasattr(self.model, "handle"):
             update_state(self.model, True)
         for cb in self.callbacks.values():
             cb.schedule.initialize(self.model)
@@ -260,11 +247,7 @@ class Simulation:
             self.initialize()
         if Δt < self.minimum_relative_step * self.Δt:
             raise NotImplementedError("skipping a tiny aligned time step needs a writable clock (minimum_relative_step > 0)")
-        if hasattr(self.model, "backend"):
-            from . import distributed
-            distributed.time_step(self.model, Δt)
-        else:
-            model_time_step(self.model, Δt)
+        model_time_step(self.model, Δt)
         for cb in self.callbacks.values():
             if cb.schedule(self.model):
                 cb(self)
@@ -272,10 +255,7 @@ class Simulation:
 
     def reset(self):
         """reset!(sim) (simulation.jl:203-213)"""
-        if hasattr(self.model, "backend"):
-            self.model.reset()
-        else:
-            _lib.check(_lib.lib().ocn_model_reset(self.model.handle))
+        _lib.check(_lib.lib().ocn_model_reset(self.model.handle))
         self.stop_iteration = self.stop_time = self.wall_time_limit = math.inf
         self.run_wall_time, self.initialized, self.running = 0.0, False, True
 

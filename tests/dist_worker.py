@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oldoceananigans_jl_amd as ocn  # noqa: E402
-from oldoceananigans_jl_amd import distributed as dist  # noqa: E402
+import host_orchestration as dist  # noqa: E402
 from cpu_backend import CpuBackend, OracleLocalGrid  # noqa: E402
 from helpers import smooth_state  # noqa: E402
 

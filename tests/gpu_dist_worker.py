@@ -16,7 +16,7 @@ def main():
         int(sys.argv[5]), sys.argv[6], int(sys.argv[7])
     import torch  # noqa: F401  (before the library)
     import oldoceananigans_jl_amd as ocn
-    from oldoceananigans_jl_amd import distributed as dist
+    import host_orchestration as dist
     from dist_worker import analytic
     from helpers import tanh_faces
     ctx = dist.init_process_group(int(os.environ.get("LOCAL_RANK", "0")), rehearse_on_one_gpu=True)

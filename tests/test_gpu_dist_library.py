@@ -537,3 +537,83 @@ def test_library_partition_with_conditions_on_the_diffusivity_fields(ocn, arch, 
     for r, (out, div, t, _off) in enumerate(results):
         assert div < 5e-8 and t == time
         _compare(out, ref, r, size[0] // R, size)
+
+
+def test_library_partition_amd_with_a_no_slip_bottom(ocn, arch, monkeypatch):
+    """ValueBoundaryCondition(0) on u and v at the bottom with the AMD closure on four x-slabs: the viscous flux through the bottom face of
+    a rank-edge column reads νₑ at (0, j, 0) / (Nx + 1, j, 0) -- cells of the x halo columns the rank evaluates itself AND of the z halo.
+    A serial Periodic run copies the z-filled value there; the partitioned fill now writes it too (the reference's only_local_halos fill
+    leaves it unwritten on a partitioned grid, halo_communication.jl:87-110 -- with a no-flux bottom the value multiplies zero, which is
+    why the other AMD cases never saw it). Against the single-GPU model, 1e-12."""
+    import test_gpu_dist_library as me
+    base = me._bcs
+
+    def no_slip(ocn_, zkind):
+        b = dict(base(ocn_, zkind))
+        F = ocn_.FieldBoundaryConditions
+        b["u"] = F(top=ocn_.FluxBoundaryCondition(-1e-4), bottom=ocn_.ValueBoundaryCondition(0.0))
+        b["v"] = F(bottom=ocn_.ValueBoundaryCondition(0.0))
+        return b
+    monkeypatch.setattr(me, "_bcs", no_slip)
+    _own_stream()
+    R, size, nsteps = 4, (32, 12, 10), 3
+    results = _run_library_ranks(ocn, arch, R, size, nsteps, "amd", {})
+    ref, time, _ = _single_gpu(ocn, arch, size, "amd", nsteps)
+    for r, (out, div, t, _off) in enumerate(results):
+        assert div < 5e-8 and t == time
+        _compare(out, ref, r, size[0] // R, size)
+
+
+def test_library_partition_with_a_flat_y_direction(ocn, arch):
+    """(Periodic, Flat, Bounded) on two x-slabs: `size` / `extent` list the non-Flat directions only, like RectilinearGrid's; the library
+    routes a Flat y to the gathered pressure solve. Against the single-GPU model."""
+    from oldoceananigans_jl_amd import distributed as dist
+    from loopback import PointerLoopbackWorld
+    from oldoceananigans_jl_amd import _lib
+    from helpers import tanh_faces
+    _own_stream()
+    R, nsteps = 2, 3
+    topo = (ocn.Periodic, ocn.Flat, ocn.Bounded)
+    size2, z = (32, 12), tanh_faces(12)
+    gridS = ocn.RectilinearGrid(arch, size=size2, x=(0.0, 2.0), z=z, topology=topo)
+    model = ocn.NonhydrostaticModel(grid=gridS, tracers=("T", "S"))
+    ocn.set_model(model, **{n: analytic(n, *gridS.nodes(f.loc)) for n, f in model.fields().items()})
+    dt = 0.1 * gridS.Δxᶜᵃᵃ / 0.6
+    for _ in range(nsteps):
+        ocn.time_step(model, dt)
+    ref = {n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent()}
+    world = PointerLoopbackWorld(R, _lib.lib())
+    results, errors = [None] * R, []
+
+    def worker(rank):
+        try:
+            ctx = dist.Distributed.transport(arch, world.collectives(rank), R, rank)
+            grid = dist.DistributedRectilinearGrid(ctx, size=size2, x=(0.0, 2.0), z=z, topology=topo)
+            m = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"))
+            assert m.get_option("dist_poisson_layout") == -2              # gathered solve
+            ocn.set_model(m, **{n: analytic(n, *grid.global_nodes(f.loc)) for n, f in m.fields().items()})
+            for _ in range(nsteps):
+                ocn.time_step(m, dt)
+            results[rank] = ({n: f.parent() for n, f in m.fields().items()} | {"p": m.pressures.pNHS.parent()}, ocn.max_abs_divergence(m))
+            m.close()
+            ctx.close()
+        except BaseException as e:          # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            world.barrier_obj.abort()
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    nxl = 32 // R
+    for r, (out, div) in enumerate(results):
+        assert div < 5e-8
+        for name, a in out.items():
+            hx = 3
+            want = ref[name][hx + r * nxl:hx + (r + 1) * nxl]
+            got = a[hx:hx + nxl]
+            inner = (slice(None),) + tuple(slice(3, -3) if s > 1 else slice(None) for s in want.shape[1:])
+            err = np.abs(got[inner] - want[inner]).max() / np.abs(ref[name]).max()
+            assert err <= 1e-12, (r, name, err)

@@ -50,7 +50,7 @@ def _closure(ocn, zkind):
 
 def _run_virtual_ranks(ocn, arch, R, size, nsteps, async_halos, zkind="periodic", thin_halos=True):
     import torch
-    from oldoceananigans_jl_amd import distributed as dist
+    import host_orchestration as dist
     from loopback import LoopbackWorld
     world = LoopbackWorld(R, torch, arch)
     results, errors = [None] * R, []
@@ -177,7 +177,7 @@ def _virtual_rank_case(ocn, oracle, arch, R, async_halos, size, zkind):
 def _in_virtual_ranks(arch, R, fn):
     """run fn(ctx, dist) on R virtual ranks (threads) and return the per-rank results"""
     import torch
-    from oldoceananigans_jl_amd import distributed as dist
+    import host_orchestration as dist
     from loopback import LoopbackWorld
     world = LoopbackWorld(R, torch, arch)
     results, errors = [None] * R, []
@@ -303,7 +303,8 @@ def test_self_loop_rank_equals_single_gpu(ocn, arch, size, zkind, substructured)
     unpack, strips, thin exchanges, gathered interface solve) with device copies; the fields equal the single-GPU model's"""
     import ctypes as C
     import torch
-    from oldoceananigans_jl_amd import _lib, distributed as dist
+    from oldoceananigans_jl_amd import _lib
+    import host_orchestration as dist
     _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     ocn.set_option("dist_substructured", substructured)
     try:
@@ -341,7 +342,8 @@ def test_substructured_solver_layouts(ocn, arch):
     (what rocFFT leaves when it refuses the interleaved-batch 2-D layout), paired real columns (option dist_zfirst = 0)"""
     import ctypes as C
     import torch
-    from oldoceananigans_jl_amd import _lib, distributed as dist
+    from oldoceananigans_jl_amd import _lib
+    import host_orchestration as dist
     _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     outs, layouts = [], []
     for size, zfirst in (((256, 24, 16), 1), ((256, 24, 16), 0), ((64, 24, 16), 1), ((64, 24, 16), 0)):
@@ -368,19 +370,17 @@ def test_substructured_solver_layouts(ocn, arch):
 
 
 def test_simulation_drives_a_partitioned_model(ocn, arch):
-    """Simulation(model) with the host-orchestrated partitioned model (its clock view, reset, initialize through the distributed
-    update_state!) and with the library's partitioned model: run! with a stop iteration and a TimeInterval callback, against the same
-    Simulation of the single-GPU model (the Simulation branches on `model.backend` were never driven)"""
+    """Simulation(model) with the library's partitioned model (a one-rank self-loop: the N > 1 code path): run! with a stop iteration and a
+    TimeInterval callback, reset!, against the same Simulation of the single-GPU model"""
     import ctypes as C
-    import torch
     from oldoceananigans_jl_amd import _lib, distributed as dist
-    _lib.check(_lib.lib().ocn_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    _lib.check(_lib.lib().ocn_own_stream())
     size = (32, 16, 8)
     z, topo = _z_and_topology(ocn, "periodic", size[2])
 
-    def drive(model, set_fn, nodes_grid):
-        set_fn(model, **{n: analytic(n, *nodes_grid.nodes(f.loc)) for n, f in model.fields().items()})
-        dt = 0.1 * nodes_grid.Δxᶜᵃᵃ / 0.6
+    def drive(model, nodes_of):
+        ocn.set_model(model, **{n: analytic(n, *nodes_of(f.loc)) for n, f in model.fields().items()})
+        dt = 0.1 * (2.0 / size[0]) / 0.6
         sim = ocn.Simulation(model, Δt=dt, stop_iteration=5)
         hits = []
         sim.callbacks["probe"] = ocn.Callback(lambda s: hits.append((s.model.clock.iteration, s.model.clock.time)), ocn.TimeInterval(2.5 * dt))
@@ -391,18 +391,21 @@ def test_simulation_drives_a_partitioned_model(ocn, arch):
         assert model.clock.iteration == 0 and model.clock.time == 0.0
         return first
 
-    ctx = dist.SelfLoopContext(0, 1, torch.device("cuda", 0), torch, None, arch)
+    uid = C.create_string_buffer(128)
+    _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+    ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
     grid = dist.DistributedRectilinearGrid(ctx, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
-    host_model = dist.DistributedNonhydrostaticModel(grid=grid, tracers=("T", "S"))
-    out_host, hits_host, t_host = drive(host_model, dist.set_model, grid.local)
-    host_model.backend.close()
+    lib_model = dist.LibraryDistributedModel(grid=grid, tracers=("T", "S"))
+    out_lib, hits_lib, t_lib = drive(lib_model, grid.global_nodes)
+    lib_model.close()
+    ctx.close()
     sgrid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 2.0), y=(0.0, 1.0), z=z, topology=topo)
     smodel = ocn.NonhydrostaticModel(grid=sgrid, tracers=("T", "S"))
-    out_ref, hits_ref, t_ref = drive(smodel, ocn.set_model, sgrid)
-    assert t_host == t_ref and [h[0] for h in hits_host] == [h[0] for h in hits_ref] and len(hits_ref) >= 2
-    assert all(abs(a[1] - b[1]) < 1e-15 for a, b in zip(hits_host, hits_ref))
+    out_ref, hits_ref, t_ref = drive(smodel, sgrid.nodes)
+    assert t_lib == t_ref and [h[0] for h in hits_lib] == [h[0] for h in hits_ref] and len(hits_ref) >= 2
+    assert all(abs(a[1] - b[1]) < 1e-15 for a, b in zip(hits_lib, hits_ref))
     for n in out_ref:
-        err = np.abs(out_host[n][3:-3, 3:-3, 3:-3] - out_ref[n][3:-3, 3:-3, 3:-3]).max() / np.abs(out_ref[n]).max()
+        err = np.abs(out_lib[n][3:-3, 3:-3, 3:-3] - out_ref[n][3:-3, 3:-3, 3:-3]).max() / np.abs(out_ref[n]).max()
         assert err <= 1e-12, (n, err)
 
 

@@ -434,6 +434,17 @@ def test_node_coordinates_are_julia_ranges(ocn_host):
                             topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
     dz = np.asarray(g.Δzᵃᵃᶜ[3:3 + Nz])
     assert (_six(dz.min()), _six(dz.max()), g.Δxᶜᵃᵃ) == (2.40764, 49.0086, 156.25) and g.zᵃᵃᶠ[3] == -1000.0
+    # the range's end points come from the USER's interval in BigFloat (c₁, c₂ = BigFloat.(node_interval), grid_generation.jl:104-110), not
+    # from c₁ + FT(L): for x = (-0.1, 0.2) the rounded extent gives -0.1 + 0.30000000000000004 = 0.20000000000000004 != 0.2. A Julia range
+    # hits its two end points exactly, and those are F₋ = c₁ - H Δ and F₊ = c₂ + (H - 1) Δ (Periodic) rounded ONCE
+    from fractions import Fraction
+    c1, c2, N, H = Fraction(-0.1), Fraction(0.2), 6, 3
+    assert float(c1) + float(c2 - c1) != 0.2                       # the case tells the two constructions apart
+    g = ocn.RectilinearGrid(None, size=(N, N, N), x=(-0.1, 0.2), y=(-0.1, 0.2), z=(-0.1, 0.2))
+    D = (c2 - c1) / N
+    for faces, centres in ((g.xᶠᵃᵃ, g.xᶜᵃᵃ), (g.yᵃᶠᵃ, g.yᵃᶜᵃ), (g.zᵃᵃᶠ, g.zᵃᵃᶜ)):
+        assert faces[0] == float(c1 - H * D) and faces[-1] == float(c2 + (H - 1) * D)
+        assert centres[0] == float(c1 - H * D + D / 2) and centres[-1] == float(c2 + H * D - D / 2)
 
 
 def test_stretched_coordinate_full_precision_docstring_numbers(ocn_host, oracle):

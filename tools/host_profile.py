@@ -11,7 +11,8 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
 import torch  # noqa
 import oldoceananigans_jl_amd as ocn
-from oldoceananigans_jl_amd import distributed as dist
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import host_orchestration as dist
 from bench import initial_state
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = dist.init_process_group(0)

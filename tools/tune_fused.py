@@ -15,7 +15,7 @@ ocn.set_model(model, **vals)
 ref = None
 variants = [(0, 8, 16, 4, 0, 0), (1, 7, 0, 2, 1, 0), (1, 7, 0, 2, 1, 1), (1, 7, 32, 2, 1, 1), (1, 7, 52, 2, 1, 1), (1, 7, 22, 2, 1, 1)]
 for impl, ty, kc, mw, zw, lds in variants:
-    model.set_option("tendency_impl", impl); model.set_option("fused_ty", ty); model.set_option("fused_kchunk", kc); model.set_option("fused_minw", mw); model.set_option("fused_zwin", zw); model.set_option("fused_lds", lds)
+    model.set_option("tendency_impl", impl); model.set_option("fused_ty", ty); model.set_option("fused_kchunk", kc); model.set_option("fused_minw", mw); model.set_option("fused_zwin", zw);
     ocn.update_state(model, True); ocn.synchronize()
     G = [model.tendency(n).parent() for n in flds]
     if ref is None: ref = G
