@@ -49,6 +49,7 @@ typedef struct ocn_grid_s *ocn_grid_t;
 typedef struct ocn_poisson_s *ocn_poisson_t;
 typedef struct ocn_model_s *ocn_model_t;
 typedef struct ocn_dist_s *ocn_dist_t;
+typedef struct ocn_transposable_s *ocn_transposable_t;   /* TransposableField (transposable_field.jl:5-13) */
 
 /* ---------------------------------------------------------------- runtime (src/Architectures.jl:35-123) ---------- */
 int ocn_init(int device_id);                                  /* device!(arch, id) */
@@ -406,6 +407,10 @@ typedef struct {
      * returns -- `lo_send` goes to peer_lo and lands in ITS hi_recv, `hi_send` goes to peer_hi and lands in its lo_recv */
     int (*exchange_peers)(void *user, int peer_lo, int peer_hi, const double *lo_send, const double *hi_send, double *lo_recv,
                           double *hi_recv, size_t count, void *stream);
+    /* pencil transposes only (may be NULL otherwise): MPI.Alltoallv! with equal counts on a sub-communicator given as the list of its
+     * members' world ranks (this rank included, in group order): chunk q of `send` (count doubles) goes to peers[q], chunk q of `recv`
+     * comes from peers[q]; complete in stream order when it returns */
+    int (*all_to_all_group)(void *user, const int *peers, int npeers, const double *send, double *recv, size_t count, void *stream);
 } ocn_transport_t;
 int ocn_dist_create_transport(ocn_dist_t *dist, const ocn_transport_t *transport, int world, int rank);
 int ocn_dist_destroy(ocn_dist_t dist);
@@ -459,6 +464,21 @@ int ocn_dist_set_layout(ocn_dist_t dist, int Rx, int Ry);
 int ocn_dist_model_create_pencil(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global,
                                  double Ly_global, int Rx, int Ry, const int *sizes_x, const int *sizes_y, int global_x_topology,
                                  int global_y_topology);
+/* ---- TransposableField and its transposes (pencil partitions; row f.4 of SURVEY.md 8) ----------------------------------------------
+ * TransposableField(field_in, ComplexF64) (transposable_field.jl:49-105) for a field of GLOBAL size (Nx, Ny, Nz) on the communicator's
+ * Partition(Rx, Ry) (ocn_dist_set_layout): complex (re, im interleaved) fields without halos, x fastest --
+ * zfield (Nx/Rx, Ny/Ry, Nz), yfield (Nx/Rx, Ny, Nz/Ry), xfield (Nx, Ny/Rx, Nz/Ry); yfield is zfield when Ry = 1, xfield is yfield when
+ * Rx = 1. Equal chunks as in the reference: Rx | Nx, Ry | Ny, Ry | Nz, Rx | Ny (distributed_fft_based_poisson_solver.jl:213-226). */
+int ocn_transposable_create(ocn_transposable_t *field, ocn_dist_t dist, int Nx, int Ny, int Nz);
+int ocn_transposable_destroy(ocn_transposable_t field);
+/* device pointers and sizes of the three configurations (any output may be NULL) */
+int ocn_transposable_fields(ocn_transposable_t field, double **zfield, double **yfield, double **xfield, int zsize[3], int ysize[3], int xsize[3]);
+/* transpose_z_to_y! / transpose_y_to_x! / transpose_x_to_y! / transpose_y_to_z! (distributed_transpose.jl:25-95,185-191): pack kernel,
+ * all-to-all inside the group of ranks that share ix (z <-> y) or iy (y <-> x), unpack kernel; bit-exact copies; no-ops on slabs (:12-15) */
+int ocn_transpose_z_to_y(ocn_transposable_t field);
+int ocn_transpose_y_to_x(ocn_transposable_t field);
+int ocn_transpose_x_to_y(ocn_transposable_t field);
+int ocn_transpose_y_to_z(ocn_transposable_t field);
 int ocn_dist_model_max_abs_divergence(ocn_model_t model, double *value);    /* global maximum; synchronous */
 
 #ifdef __cplusplus

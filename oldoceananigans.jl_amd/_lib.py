@@ -41,12 +41,13 @@ class Transport(C.Structure):
     ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
     ALLREDUCE_MAX = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double))
     EXCHANGE_PEERS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+    ALL_TO_ALL_GROUP = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 Transport._fields_ = [("exchange_start", Transport.EXCHANGE_START), ("exchange_wait", Transport.EXCHANGE_WAIT),
                       ("all_to_all", Transport.ALL_TO_ALL), ("all_gather", Transport.ALL_GATHER),
                       ("allreduce_max", Transport.ALLREDUCE_MAX), ("user", C.c_void_p),
-                      ("exchange_peers", Transport.EXCHANGE_PEERS)]
+                      ("exchange_peers", Transport.EXCHANGE_PEERS), ("all_to_all_group", Transport.ALL_TO_ALL_GROUP)]
 
 SYMBOLS = {
     "ocn_dist_unique_id": (C.c_int, [_vp]),
@@ -68,6 +69,13 @@ SYMBOLS = {
     "ocn_dist_set_layout": (C.c_int, [_vp, C.c_int, C.c_int]),
     "ocn_dist_model_create_pencil": (C.c_int, [_pp, _vp, C.c_int, _vp, C.c_double, C.c_double, C.c_int, C.c_int, _ip, _ip, C.c_int, C.c_int]),
     "ocn_dist_model_max_abs_divergence": (C.c_int, [_vp, _dp]),
+    "ocn_transposable_create": (C.c_int, [_pp, _vp, C.c_int, C.c_int, C.c_int]),
+    "ocn_transposable_destroy": (C.c_int, [_vp]),
+    "ocn_transposable_fields": (C.c_int, [_vp, _pp, _pp, _pp, _ip, _ip, _ip]),
+    "ocn_transpose_z_to_y": (C.c_int, [_vp]),
+    "ocn_transpose_y_to_x": (C.c_int, [_vp]),
+    "ocn_transpose_x_to_y": (C.c_int, [_vp]),
+    "ocn_transpose_y_to_z": (C.c_int, [_vp]),
     "ocn_init": (C.c_int, [C.c_int]),
     "ocn_device_count": (C.c_int, [_ip]),
     "ocn_sync": (C.c_int, []),

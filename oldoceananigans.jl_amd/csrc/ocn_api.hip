@@ -960,6 +960,7 @@ static int g_fused_zfft = 1;
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
 static int g_dist_xfast = 1;           // substructured x solve in the fields' own x-fastest layout (paired z transform in LDS, one-wave-per-line Thomas scans) when sizes allow
+static int g_dist_pencil_transposes = 1;   // pencil partitions of triply Periodic grids: the reference's transposing solver (0: gathered solve)
 static int g_dist_fused_step = 1;      // partitioned model, (connected, Periodic, Periodic) slabs: the pressure step without fills / copies between its stages (ocn_dist.h)
 static int g_dist_yline = 1;           // z Bounded: local y transform by strided_line_fft_kernel (Ny = 2^m <= 1024) instead of rocFFT's 1-D strided plan
 static int g_dist_zfirst = 1;          // substructured solve on the z-fastest layout (R2C along z); 0: paired-column layout
@@ -2450,6 +2451,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_yline")) { g_dist_yline = value; return OCN_OK; }
     if (!strcmp(key, "dist_fused_step")) { g_dist_fused_step = value; return OCN_OK; }
     if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
+    if (!strcmp(key, "dist_pencil_transposes")) { g_dist_pencil_transposes = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);

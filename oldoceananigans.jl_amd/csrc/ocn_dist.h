@@ -337,6 +337,8 @@ extern "C" int ocn_dist_barrier(ocn_dist_t d) {
     return ocn_dist_allreduce_max(d, &v);
 }
 
+#include "ocn_transpose.h"
+
 // ---------------------------------------------------------------------------------------------------------------------
 // the partitioned model: NonhydrostaticModel on Distributed(GPU(); partition = Partition(R)) (x-slabs)
 // ---------------------------------------------------------------------------------------------------------------------
@@ -354,6 +356,7 @@ struct DistModel {
     ocn_dist_t dist = nullptr;
     ocn_dist_poisson_t solver = nullptr;
     GatheredSolve *gs = nullptr;
+    PencilSolve *ps = nullptr;          // pencil partition of a triply Periodic regular grid: the reference's transposing FFT solver
     double *ws = nullptr, *es = nullptr, *wr = nullptr, *er = nullptr;     // halo buffers: Hx columns of every prognostic field per side
     size_t slab_total = 0;
     double *p2 = nullptr;                                                   // the solver's raw solution (p dt); the correction passes write p / dt into the model's pressure
@@ -381,6 +384,7 @@ struct DistModel {
 static void dist_model_free(DistModel *dm) {
     if (!dm) return;
     ocn_dist_poisson_destroy(dm->solver);
+    pencil_solve_free(dm->ps);
     if (dm->gs) {
         ocn_poisson_destroy(dm->gs->solver);
         ocn_grid_destroy(dm->gs->ggrid);
@@ -486,6 +490,16 @@ static int dist_fill_halo_regions(ocn_model_s *m, double *const *fields, const i
 static int dist_solve_for_pressure(ocn_model_s *m) {
     DistModel *dm = m->dm;
     int rc;
+    if (dm->ps) {
+        // pencil partition, triply Periodic: source term into the z-local complex field, the transposing solve, real part into p dt
+        const DGrid &g = m->grid->d;
+        if ((rc = source_term(g, m->U[0], m->U[1], m->U[2], dm->ps->tf->zfield, false))) return rc;
+        if ((rc = pencil_solve(dm->ps))) return rc;
+        hipLaunchKernelGGL(copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, dm->p2, LOC_C),
+                           (const double2 *)dm->ps->tf->zfield, 1.0, false, (const double2 *)nullptr);
+        KERNEL_CHECK();
+        return OCN_OK;
+    }
     if (dm->gs) {
         // irregular partition: every rank gathers the whole source term and runs the single-GPU solver on the global grid
         GatheredSolve *q = dm->gs;
@@ -820,6 +834,21 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
             hipMemsetAsync(*b, 0, rows * sizeof(double), g_stream);
         }
     }
+    // Partition(Rx, Ry) pencils of a triply Periodic regular grid with equal blocks that the reference's transposes can move
+    // (distributed_fft_based_poisson_solver.jl:213-226): its DistributedFFTBasedPoissonSolver (z / y / x transforms with two transposes
+    // each way); every other pencil keeps the gathered solve
+    if (pencil && g_dist_pencil_transposes && !irregular && global_x_topology == OCN_PERIODIC && global_y_topology == OCN_PERIODIC &&
+        g.tz == OCN_PERIODIC && local_grid->z_regular) {
+        bool equal_y = true;
+        if (sizes_y)
+            for (int r = 0; r < Ry; ++r) equal_y = equal_y && sizes_y[r] == sizes_y[0];
+        const int N[3] = {g.Nx * Rx, g.Ny * Ry, g.Nz};
+        if (equal_y && N[2] % Ry == 0 && N[1] % Rx == 0) {
+            const double L[3] = {Lx_global, Ly_global, local_grid->L[2]};
+            if ((rc = pencil_solve_create(&dm->ps, dist, N, L))) return bail(rc);
+            return OCN_OK;
+        }
+    }
     if (irregular || dm->general()) {
         if (dist->self_loop) return bail(fail(OCN_EINVAL, "self_loop has one slab"));
         std::vector<int> equal((size_t)Rx, g.Nx);
@@ -884,8 +913,8 @@ static int dist_model_get_option(const ocn_model_s *m, const char *key, int *val
     const DistModel *dm = m->dm;
     if (!dm) return -1;
     // which distributed pressure solver the model runs: ocn_dist_poisson_layout's code (4 x-fastest, 1..3 z-fastest, 0 paired columns,
-    // -1 transposing), -2 = the gathered solve on the global grid
-    if (!strcmp(key, "dist_poisson_layout")) { *value = dm->gs ? -2 : -1; return dm->solver ? ocn_dist_poisson_layout(dm->solver, value) : OCN_OK; }
+    // -1 transposing), -2 = the gathered solve on the global grid, -3 = the pencil transposes (TransposableField)
+    if (!strcmp(key, "dist_poisson_layout")) { *value = dm->gs ? -2 : (dm->ps ? -3 : -1); return dm->solver ? ocn_dist_poisson_layout(dm->solver, value) : OCN_OK; }
     if (!strcmp(key, "fused_step")) { *value = dm->fused() ? 1 : 0; return OCN_OK; }
     if (!strcmp(key, "async_halos")) { *value = dm->async_halos; return OCN_OK; }
     if (!strcmp(key, "thin_halos")) { *value = dm->thin_halos; return OCN_OK; }

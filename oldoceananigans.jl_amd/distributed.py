@@ -269,6 +269,8 @@ class Distributed:
             allreduce_max=T.ALLREDUCE_MAX(guard(allreduce)))
         if hasattr(collectives, "exchange_peers"):      # pencil partitions: exchange with an explicit pair of peers
             cbs["exchange_peers"] = T.EXCHANGE_PEERS(guard(lambda u, pl, ph, ls, hs, lr, hr, n, st: collectives.exchange_peers(pl, ph, ls, hs, lr, hr, n)))
+        if hasattr(collectives, "all_to_all_group"):    # pencil transposes: all-to-all inside a group given by its members' ranks
+            cbs["all_to_all_group"] = T.ALL_TO_ALL_GROUP(guard(lambda u, peers, n, s_, r_, cnt, st: collectives.all_to_all_group([peers[q] for q in range(n)], s_, r_, cnt)))
         t = T(user=None, **cbs)
         h = C.c_void_p()
         _lib.check(_lib.lib().ocn_dist_create_transport(C.byref(h), C.byref(t), int(world), int(rank)))

@@ -131,6 +131,18 @@ class PointerLoopback:
             self._copy(recv + 8 * n * s, w.slots[s], n)
         w.barrier_obj.wait()
 
+    def all_to_all_group(self, peers, send, recv, n):
+        """MPI.Alltoallv! on a sub-communicator (the pencil transposes): chunk q of `recv` is the chunk of peers[q]'s send buffer that is
+        addressed to this rank, i.e. the one at this rank's position in the (common) group list. Every rank of the world is inside
+        such a call at the same time, each in its own group, so the world barrier still orders submissions."""
+        w = self.w
+        w.slots[self.rank] = send
+        w.barrier_obj.wait()
+        me = peers.index(self.rank)
+        for q, peer in enumerate(peers):
+            self._copy(recv + 8 * n * q, w.slots[peer] + 8 * n * me, n)
+        w.barrier_obj.wait()
+
     def allreduce_max(self, value):
         w = self.w
         w.vals[self.rank] = float(value)

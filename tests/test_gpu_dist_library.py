@@ -177,7 +177,7 @@ def test_library_collectives_over_rccl_world_1(ocn, arch):
     _lib.check(L.ocn_dist_destroy(d))
 
 
-def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=False, ybounded=False, partition=None):
+def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=False, ybounded=False, partition=None, probe=None):
     from oldoceananigans_jl_amd import _lib, distributed as dist
     from loopback import PointerLoopbackWorld
     world = PointerLoopbackWorld(R, _lib.lib())
@@ -190,6 +190,8 @@ def _run_library_ranks(ocn, arch, R, size, nsteps, zkind, options, xbounded=Fals
             grid, model = _library_model(ocn, dist, ctx, size, zkind, xbounded, ybounded, partition)
             for k, v in options.items():
                 model.set_option(k, v)
+            if probe is not None:
+                probe(model)
             for _ in range(nsteps):
                 ocn.time_step(model, dt)
             div = ocn.max_abs_divergence(model)
@@ -617,3 +619,92 @@ def test_library_partition_with_a_flat_y_direction(ocn, arch):
             inner = (slice(None),) + tuple(slice(3, -3) if s > 1 else slice(None) for s in want.shape[1:])
             err = np.abs(got[inner] - want[inner]).max() / np.abs(ref[name]).max()
             assert err <= 1e-12, (r, name, err)
+
+
+# test/test_distributed_transpose.jl:13-54 -- the reference's sizes and partitions (the topology plays no part in a transpose)
+_TRANSPOSE_CASES = [((44, 44, 8), (4, 1)), ((16, 44, 8), (4, 1)), ((44, 44, 8), (1, 4)), ((44, 16, 8), (1, 4)), ((16, 44, 8), (1, 4)),
+                    ((44, 16, 8), (2, 2)), ((16, 44, 8), (2, 2))]
+
+
+@pytest.mark.parametrize("size,partition", _TRANSPOSE_CASES)
+def test_reference_distributed_transpose_round_trip_is_bit_exact(ocn, arch, size, partition):
+    """TransposableField + transpose_z_to_y! / y_to_x! / x_to_y! / y_to_z! (distributed_transpose.jl:25-95,185-191) on virtual ranks: the
+    reference's test -- random ComplexF64 data makes the full cycle z -> y -> x -> y -> z and comes back bit for bit
+    (test_distributed_transpose.jl:13-54) -- and, stronger, every intermediate configuration holds exactly its block of the global array:
+    yfield = G[x block ix, :, z block iy], xfield = G[:, y block ix, z block iy] (the twin grids of transposable_field.jl:122-182)."""
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    from loopback import PointerLoopbackWorld
+    _own_stream()
+    L = _lib.lib()
+    Rx, Ry = partition
+    R = Rx * Ry
+    Nx, Ny, Nz = size
+    rng = np.random.default_rng(5)
+    G = rng.random(size) + 1j * rng.random(size)                       # the global field, G[i, j, k]
+    world = PointerLoopbackWorld(R, L)
+    errors = []
+
+    def read(ptr, shape):
+        a = np.empty(shape, dtype=np.complex128, order="F")
+        _lib.check(L.ocn_memcpy_d2h(a.ctypes.data, ptr, a.nbytes))
+        return a
+
+    def worker(rank):
+        try:
+            ctx = dist.Distributed.transport(arch, world.collectives(rank), R, rank)
+            _lib.check(L.ocn_dist_set_layout(ctx.handle, Rx, Ry))
+            tf = C.c_void_p()
+            _lib.check(L.ocn_transposable_create(C.byref(tf), ctx.handle, Nx, Ny, Nz))
+            zf, yf, xf = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            zs, ys, xs = (C.c_int * 3)(), (C.c_int * 3)(), (C.c_int * 3)()
+            _lib.check(L.ocn_transposable_fields(tf, C.byref(zf), C.byref(yf), C.byref(xf), zs, ys, xs))
+            ix, iy = rank // Ry, rank % Ry
+            nx, ny, nz, nyx = Nx // Rx, Ny // Ry, Nz // Ry, Ny // Rx
+            assert tuple(zs) == (nx, ny, Nz) and tuple(ys) == (nx, Ny, nz) and tuple(xs) == (Nx, nyx, nz)
+            mine = np.asfortranarray(G[ix * nx:(ix + 1) * nx, iy * ny:(iy + 1) * ny, :])
+            _lib.check(L.ocn_memcpy_h2d(zf, mine.ctypes.data, mine.nbytes))
+            _lib.check(L.ocn_transpose_z_to_y(tf))
+            assert np.array_equal(read(yf, tuple(ys)), G[ix * nx:(ix + 1) * nx, :, iy * nz:(iy + 1) * nz]), "y-local block"
+            _lib.check(L.ocn_transpose_y_to_x(tf))
+            assert np.array_equal(read(xf, tuple(xs)), G[:, ix * nyx:(ix + 1) * nyx, iy * nz:(iy + 1) * nz]), "x-local block"
+            _lib.check(L.ocn_transpose_x_to_y(tf))
+            assert np.array_equal(read(yf, tuple(ys)), G[ix * nx:(ix + 1) * nx, :, iy * nz:(iy + 1) * nz]), "back in the y-local block"
+            if Ry > 1:          # (on x-slabs yfield IS zfield: keep its content for the last comparison, scramble it otherwise)
+                _lib.check(L.ocn_memset_zero(zf, mine.nbytes))
+            _lib.check(L.ocn_transpose_y_to_z(tf))
+            back = read(zf, tuple(zs))
+            assert np.array_equal(back.real, mine.real) and np.array_equal(back.imag, mine.imag), "round trip"
+            _lib.check(L.ocn_transposable_destroy(tf))
+            ctx.close()
+        except BaseException as e:          # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()))
+            world.barrier_obj.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("partition,size", [((2, 2), (16, 16, 8)), ((1, 4), (16, 16, 8)), ((4, 2), (32, 16, 8)), ((2, 4), (16, 32, 16))])
+def test_library_pencil_models_take_the_transposing_solver(ocn, arch, partition, size):
+    """pencil partitions of a triply Periodic regular grid run the reference's DistributedFFTBasedPoissonSolver -- z / y / x transforms on
+    the TransposableField with its two transposes each way (distributed_fft_based_poisson_solver.jl:141-178) -- instead of the gathered
+    solve (option dist_pencil_transposes = 0 brings that back): both against the single-GPU model, three RK3 steps, 1e-12"""
+    _own_stream()
+    R = partition[0] * partition[1]
+    ref, time, _ = _single_gpu(ocn, arch, size, "periodic", 3)
+    for transposes in (1, 0):
+        ocn.set_option("dist_pencil_transposes", transposes)
+        try:
+            layouts = []
+            results = _run_library_ranks(ocn, arch, R, size, 3, "periodic", {}, partition=partition, probe=lambda m: layouts.append(m.get_option("dist_poisson_layout")))
+        finally:
+            ocn.set_option("dist_pencil_transposes", 1)
+        assert layouts == [-3 if transposes else -2] * R, layouts
+        for r, (out, div, t, (i0, j0)) in enumerate(results):
+            assert div < 5e-8 and t == time
+            _compare(out, ref, r, None, size, offset=i0, joffset=j0)
