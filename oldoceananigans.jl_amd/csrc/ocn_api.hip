@@ -150,7 +150,7 @@ struct ocn_grid_s {
     DGrid d;
     double L[3];
     bool z_regular;
-    double *tables;   // one device allocation holding dzc, dzf, ax, ay, vinv_c, vinv_f, rdzf
+    double *tables;   // one device allocation holding dzc, dzf, ax, ay, vinv_c, vinv_f, rdzf, rdzc
     std::vector<double> h_dzc, h_dzf;
     // why the advection scheme cannot be evaluated on this grid (empty: it can). A grid whose halo is smaller than the scheme needs
     // -- RectilinearGrid(halo = (1, 1, 1)), what test/test_halo_regions.jl fills -- serves fields, halo fills and the Poisson
@@ -241,7 +241,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
     }
     for (int k = 1; k <= N[2]; ++k)
         if (g->h_dzc[k - 1 + H[2]] != g->h_dzc[H[2]] || g->h_dzf[k - 1 + H[2]] != g->h_dzc[H[2]]) g->z_regular = false;
-    std::vector<double> tab(7 * (size_t)n);
+    std::vector<double> tab(8 * (size_t)n);
     for (int q = 0; q < n; ++q) {
         const double zc = g->h_dzc[q], zf = g->h_dzf[q];
         tab[0 * n + q] = zc;
@@ -251,6 +251,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
         tab[4 * n + q] = 1.0 / ((dx * dy) * zc);        // V⁻¹ = 1 / (Az Δz)  (:369-378, reciprocal_metric_operators.jl)
         tab[5 * n + q] = 1.0 / ((dx * dy) * zf);
         tab[6 * n + q] = 1.0 / zf;
+        tab[7 * n + q] = 1.0 / zc;
     }
     hipError_t e = dev_alloc((void **)&g->tables, tab.size() * sizeof(double));
     if (e != hipSuccess) { delete g; return fail((int)e, "dev_alloc(grid tables): %s", hipGetErrorString(e)); }
@@ -258,6 +259,7 @@ extern "C" int ocn_grid_create(ocn_grid_t *grid, const int N[3], const int H[3],
     if (e != hipSuccess) { hipFree(g->tables); delete g; return fail((int)e, "hipMemcpy(grid tables): %s", hipGetErrorString(e)); }
     D.dzc = g->tables; D.dzf = g->tables + n; D.ax = g->tables + 2 * n; D.ay = g->tables + 3 * n;
     D.vinv_c = g->tables + 4 * n; D.vinv_f = g->tables + 5 * n; D.rdzf = g->tables + 6 * n;
+    D.rdzc = g->tables + 7 * n;
     *grid = g;
     return OCN_OK;
 }
@@ -714,6 +716,7 @@ extern "C" int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const doubl
     return closure_tendencies(grid->d, u, v, w, tracers, ntracers, 0.0, nullptr, Gu, Gv, Gw, Gc, range, nu_e, kappa_e);
 }
 
+static int g_amd_march = 1;            // eddy diffusivities by the z-marching kernel that shares the point operands (0: one thread per cell, everything recomputed)
 static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, const double *u, const double *v, const double *w,
                              const double *const *tr, int ntr, double *nu_e, double *const *kappa_e, const int *range = nullptr) {
     if (g.tx == OCN_FLAT || g.ty == OCN_FLAT || g.tz == OCN_FLAT)
@@ -738,7 +741,20 @@ static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, c
         a.kappa_e[t] = make_view(g, kappa_e[t], LOC_C);
         a.Ck[t] = Ckappa[t];
     }
-    hipLaunchKernelGGL(amd_diffusivities_kernel, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, a);
+    if (g_amd_march && ntr <= 3) {
+        // z-marching kernel (ocn_kernels.h): 63 columns per wave, 4 rows per block, chunks of levels so that ~2000 blocks fill the chip
+        const int bx = (nx + 62) / 63, by = (ny + 3) / 4;
+        const int want = std::max(1, 2048 / std::max(1, bx * by));
+        const int kchunk = std::min(OCN_AMD_MAXCHUNK, std::max(std::min(nz, 8), (nz + want - 1) / want));
+        const dim3 grd(bx, by, (nz + kchunk - 1) / kchunk), blk(64, 4);
+        switch (ntr) {
+            case 0: hipLaunchKernelGGL(amd_diffusivities_march_kernel<0>, grd, blk, 0, g_stream, g, a, kchunk); break;
+            case 1: hipLaunchKernelGGL(amd_diffusivities_march_kernel<1>, grd, blk, 0, g_stream, g, a, kchunk); break;
+            case 2: hipLaunchKernelGGL(amd_diffusivities_march_kernel<2>, grd, blk, 0, g_stream, g, a, kchunk); break;
+            default: hipLaunchKernelGGL(amd_diffusivities_march_kernel<3>, grd, blk, 0, g_stream, g, a, kchunk); break;
+        }
+    } else
+        hipLaunchKernelGGL(amd_diffusivities_kernel, grid3(nx, ny, nz, BLK), BLK, 0, g_stream, g, a);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -2452,6 +2468,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_fused_step")) { g_dist_fused_step = value; return OCN_OK; }
     if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
     if (!strcmp(key, "dist_pencil_transposes")) { g_dist_pencil_transposes = value; return OCN_OK; }
+    if (!strcmp(key, "amd_march")) { g_amd_march = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);

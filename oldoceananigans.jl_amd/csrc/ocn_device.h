@@ -25,6 +25,7 @@ struct DGrid {
     const double *vinv_c;      // 1 / ((Δx Δy) Δzᶜ)   = V⁻¹ᶜᶜᶜ = V⁻¹ᶠᶜᶜ = V⁻¹ᶜᶠᶜ
     const double *vinv_f;      // 1 / ((Δx Δy) Δzᶠ)   = V⁻¹ᶜᶜᶠ
     const double *rdzf;        // 1 / Δzᶠ
+    const double *rdzc;        // 1 / Δzᶜ   (the same IEEE quotient `1.0 / dzc` a kernel would form: table look-up == recomputation)
     // adapt_advection_order (Advection/adapt_advection_order.jl:18-96): buffer of the scheme a direction ends up with --
     // 3: WENO{3} (order 5), 2: WENO{2} = WENO(order = 2N-1) when N = 2, 1: UpwindBiased{1} (unused: N = 1 is refused)
     int Bx, By, Bz;

@@ -137,13 +137,15 @@ struct ClosureCtx {
     __device__ __forceinline__ double K_cff(int i, int j, int k) const { return var ? 0.5 * (K_cfc(i, j, k - 1) + K_cfc(i, j, k)) : nu; }
     __device__ __forceinline__ double dzc(int k) const { return g.dzc[k - 1 + g.Hz]; }
     __device__ __forceinline__ double dzf(int k) const { return g.dzf[k - 1 + g.Hz]; }
-    // ∂ at Center-in-d (f[+1] - f[0]) and at Face-in-d (f[0] - f[-1])
-    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i + 1, j, k) - f.at(i, j, k)) * (1.0 / g.dx); }
-    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j + 1, k) - f.at(i, j, k)) * (1.0 / g.dy); }
-    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k + 1) - f.at(i, j, k)) * (1.0 / dzc(k)); }
-    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i, j, k) - f.at(i - 1, j, k)) * (1.0 / g.dx); }
-    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j, k) - f.at(i, j - 1, k)) * (1.0 / g.dy); }
-    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k) - f.at(i, j, k - 1)) * (1.0 / dzf(k)); }
+    // ∂ at Center-in-d (f[+1] - f[0]) and at Face-in-d (f[0] - f[-1]); `δ * Δ⁻¹` (Operators/derivative_operators.jl:20-26) with the reciprocal
+    // spacings from the grid's tables: the host formed them as the same IEEE quotients 1.0 / Δ, so a look-up equals the division it replaces
+    // (four FP64 divisions per thread of the one-pass epilogue, a third of its arithmetic)
+    __device__ __forceinline__ double ddx_c(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i + 1, j, k) - f.at(i, j, k)) * g.rdx; }
+    __device__ __forceinline__ double ddy_c(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j + 1, k) - f.at(i, j, k)) * g.rdy; }
+    __device__ __forceinline__ double ddz_c(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k + 1) - f.at(i, j, k)) * g.rdzc[k - 1 + g.Hz]; }
+    __device__ __forceinline__ double ddx_f(const FView &f, int i, int j, int k) const { return fx ? 0.0 : (f.at(i, j, k) - f.at(i - 1, j, k)) * g.rdx; }
+    __device__ __forceinline__ double ddy_f(const FView &f, int i, int j, int k) const { return fy ? 0.0 : (f.at(i, j, k) - f.at(i, j - 1, k)) * g.rdy; }
+    __device__ __forceinline__ double ddz_f(const FView &f, int i, int j, int k) const { return fz ? 0.0 : (f.at(i, j, k) - f.at(i, j, k - 1)) * g.rdzf[k - 1 + g.Hz]; }
     __device__ __forceinline__ double S11(int i, int j, int k) const { return ddx_c(u, i, j, k); }
     __device__ __forceinline__ double S22(int i, int j, int k) const { return ddy_c(v, i, j, k); }
     __device__ __forceinline__ double S33(int i, int j, int k) const { return ddz_c(w, i, j, k); }
@@ -371,6 +373,179 @@ __global__ void __launch_bounds__(256, OCN_AMD_WAVES) amd_diffusivities_kernel(D
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same numbers with every POINT operand evaluated once instead of up to four times. Each of the twelve base operands lives
+// at a face-face-centre kind of point; a cell's doubly interpolated terms read it at 4 such points (2 for the tracer terms), which it
+// shares with its neighbours -- amd_diffusivities_kernel recomputes them all (~1100 FP64 instructions per cell). Here a wave owns a
+// 64-wide row of columns and MARCHES along z:
+//   x: the operand of the next column is the neighbouring LANE's -- one DPP move per 32 bits (wave_shl:1), no LDS, no recomputation;
+//      lane 63 only supplies its column to lane 62 (a wave writes 63 columns);
+//   z: the x / y interpolated operands of level k + 1 become those of level k in the next iteration -- registers;
+//   y: the thread evaluates the rows j and j + 1 itself (2x instead of 4x; no LDS, no barrier).
+// The cell is then assembled by the SAME amd_viscosity / amd_diffusivity templates from a context that returns the stored interpolants,
+// so every floating-point operation and its operands are those of the per-cell kernel: bit-identical (tests: == against the oracle and
+// against amd_diffusivities_kernel at full size). ~350 FP64 instructions + ~60 lane moves per cell.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_next(double x) {              // the value lane + 1 holds (lane 63: 0)
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double ix_lane(double x) { return 0.5 * (x + lane_next(x)); }      // Ix: 0.5 * (op(i) + op(i + 1))
+
+#define OCN_AMD_MAXCHUNK 64
+enum { AM_SQ1 = 0, AM_SQ2, AM_P1, AM_P2, AM_A, AM_B, AM_S, AM_N };      // per point kind: a², b², a s, b s, a, b, s = 0.5 (b + a)  [order as listed below]
+template <int NTR>
+struct AmdMarchCtx : AmdFields {
+    // interpolants of the cell being assembled
+    double ixy[AM_N];          // ffc kind: DXV2, DYU2, DXV_S12, DYU_S12, DXV, DYU, S12
+    double ixz[AM_N + 1];      // fcf kind: DXW2, DZU2, DXW_S13, DZU_S13, DXW, DZU, S13; [7] = Ixz of DYW (anisotropic_minimum_dissipation.jl:323 as written)
+    double iyz[AM_N];          // cff kind: DYW2, DZV2, DYW_S23, DZV_S23, DYW, DZV, S23
+    double tx, tx2, ty, ty2, tz, tz2;      // tracer being assembled: Ix<DXC>, Ix<DXC2>, Iy<DYC>, Iy<DYC2>, Iz<DZC>, Iz<DZC2>
+    // wave-uniform per-level factors of the cell being assembled, evaluated ONCE per block (same expressions as AmdFields::FZ / delta2 --
+    // the per-cell kernel repeats these divisions in every thread: 4 per delta2, once per eddy coefficient)
+    double fz_k, delta2_k;
+    // ∂x u, ∂y v, ∂z w at the cell (AmdFields::ddx_c ... with their reciprocal spacings taken from the table): evaluated once, used by the
+    // viscosity and by every tracer's diffusivity
+    double dxu_k, dyv_k, dzw_k;
+    __device__ __forceinline__ AmdMarchCtx(const DGrid &g_, const FView &u_, const FView &v_, const FView &w_) : AmdFields(g_, u_, v_, w_, u_) {}
+    __device__ __forceinline__ double FZ(int) const { return fz_k; }
+    __device__ __forceinline__ double delta2(int) const { return delta2_k; }
+    __device__ __forceinline__ double ddx_c(const FView &, int, int, int) const { return dxu_k; }
+    __device__ __forceinline__ double ddy_c(const FView &, int, int, int) const { return dyv_k; }
+    __device__ __forceinline__ double ddz_c(const FView &, int, int, int) const { return dzw_k; }
+    template <int OP> __device__ __forceinline__ double Ixy(int, int, int) const {
+        return OP == A_DXV2 ? ixy[AM_SQ1] : OP == A_DYU2 ? ixy[AM_SQ2] : OP == A_DXV_S12 ? ixy[AM_P1] : OP == A_DYU_S12 ? ixy[AM_P2]
+             : OP == A_DXV ? ixy[AM_A] : OP == A_DYU ? ixy[AM_B] : ixy[AM_S];
+    }
+    template <int OP> __device__ __forceinline__ double Ixz(int, int, int) const {
+        return OP == A_DXW2 ? ixz[AM_SQ1] : OP == A_DZU2 ? ixz[AM_SQ2] : OP == A_DXW_S13 ? ixz[AM_P1] : OP == A_DZU_S13 ? ixz[AM_P2]
+             : OP == A_DXW ? ixz[AM_A] : OP == A_DZU ? ixz[AM_B] : OP == A_S13 ? ixz[AM_S] : ixz[AM_N];
+    }
+    template <int OP> __device__ __forceinline__ double Iyz(int, int, int) const {
+        return OP == A_DYW2 ? iyz[AM_SQ1] : OP == A_DZV2 ? iyz[AM_SQ2] : OP == A_DYW_S23 ? iyz[AM_P1] : OP == A_DZV_S23 ? iyz[AM_P2]
+             : OP == A_DYW ? iyz[AM_A] : OP == A_DZV ? iyz[AM_B] : iyz[AM_S];
+    }
+    template <int OP> __device__ __forceinline__ double Ix(int, int, int) const { return OP == A_DXC2 ? tx2 : tx; }
+    template <int OP> __device__ __forceinline__ double Iy(int, int, int) const { return OP == A_DYC2 ? ty2 : ty; }
+    template <int OP> __device__ __forceinline__ double Iz(int, int, int) const { return OP == A_DZC2 ? tz2 : tz; }
+};
+
+// the seven values of a point kind from its two base operands, in AmdTerms::op's forms: a * a, b * b, a * s, b * s, a, b, s = 0.5 * (b + a)
+// (S12 = 0.5 (DYU + DXV): a = DXV, b = DYU; S13 = 0.5 (DZU + DXW): a = DXW, b = DZU; S23 = 0.5 (DZV + DYW): a = DYW, b = DZV)
+__device__ __forceinline__ void amd_point(double a, double b, double out[AM_N]) {
+    const double s = 0.5 * (b + a);
+    out[AM_SQ1] = a * a; out[AM_SQ2] = b * b; out[AM_P1] = a * s; out[AM_P2] = b * s; out[AM_A] = a; out[AM_B] = b; out[AM_S] = s;
+}
+
+template <int NTR>
+__global__ void __launch_bounds__(256, 2) amd_diffusivities_march_kernel(DGrid g, AmdArgs a, int kchunk) {
+    // per-level factors of the levels kc0 .. kc1 + 1 of this block: FZ = 2 Δzᶜ, 1 / Δzᶠ, the four metric ratios of the normalised
+    // gradients, δ² -- wave-uniform, ~17 FP64 divisions per cell in the per-cell kernel
+    __shared__ double lev[8][OCN_AMD_MAXCHUNK + 2];
+    const int lane = threadIdx.x;                                        // block (64, 4): a wave per row
+    const int i = a.r.i0 + blockIdx.x * 63 + lane;
+    const int j = a.r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int kc0 = a.r.k0 + blockIdx.z * kchunk, kc1 = min(kc0 + kchunk - 1, a.r.k1);
+    AmdMarchCtx<NTR> A(g, a.u, a.v, a.w);
+    const double fx = A.FX(), fy = A.FY(), rdx = 1.0 / g.dx, rdy = 1.0 / g.dy;
+    for (int q = threadIdx.x + 64 * threadIdx.y; q <= kc1 + 1 - kc0; q += 256) {
+        const int L = kc0 + q;
+        const double fz = 2 * A.dzc(L);
+        lev[0][q] = fz; lev[1][q] = 1.0 / A.dzf(L);
+        lev[2][q] = fx / fz; lev[3][q] = fz / fx; lev[4][q] = fy / fz; lev[5][q] = fz / fy;
+        lev[6][q] = 3 / ((1 / (fx * fx) + 1 / (fy * fy)) + 1 / (fz * fz));
+        lev[7][q] = 1.0 / A.dzc(L);
+    }
+    __syncthreads();
+    if (j > a.r.j1) return;                                              // (rows are independent from here on: no further barrier)
+    const bool out_lane = lane < 63 && i <= a.r.i1;
+    const int ic = min(i, a.r.i1 + 1);                                   // lanes beyond the last needed column repeat it (in bounds)
+    const double fxfy = fx / fy, fyfx = fy / fx;
+    const FView &u = a.u, &v = a.v, &w = a.w;
+
+    // level state carried from one iteration to the next (see the section comment)
+    double ixy[AM_N], ix_fcf[AM_N + 1], iy_cff[AM_N];
+    double t_ix[NTR > 0 ? NTR : 1], t_ix2[NTR > 0 ? NTR : 1], t_iy[NTR > 0 ? NTR : 1], t_iy2[NTR > 0 ? NTR : 1], t_z[NTR > 0 ? NTR : 1], t_z2[NTR > 0 ? NTR : 1];
+    double n_fcf[AM_N + 1], n_cff[AM_N], n_z[NTR > 0 ? NTR : 1], n_z2[NTR > 0 ? NTR : 1];
+
+    // fcf / cff kinds and the tracers' z operand at level L (what a cell needs of the level ABOVE it)
+    auto vertical = [&](int L, double fcf[AM_N + 1], double cff[AM_N], double tz[], double tz2[]) {
+        const int q = L - kc0;
+        const double fz = lev[0][q], rdzf = lev[1][q], fxfz = lev[2][q], fzfx = lev[3][q], fyfz = lev[4][q], fzfy = lev[5][q];
+        const double uc = u.at(ic, j, L), vc = v.at(ic, j, L), wc = w.at(ic, j, L);
+        {   // (ic, j, L): DXW = FX / FZ * ∂x w, DZU = FZ / FX * ∂z u
+            double p[AM_N];
+            amd_point(fxfz * ((wc - w.at(ic - 1, j, L)) * rdx), fzfx * ((uc - u.at(ic, j, L - 1)) * rdzf), p);
+#pragma unroll
+            for (int q = 0; q < AM_N; ++q) fcf[q] = ix_lane(p[q]);
+        }
+        double dyw0;
+        {   // rows j and j + 1: DYW = FY / FZ * ∂y w, DZV = FZ / FY * ∂z v
+            double p0[AM_N], p1[AM_N];
+            const double wn = w.at(ic, j + 1, L), vn = v.at(ic, j + 1, L);
+            dyw0 = fyfz * ((wc - w.at(ic, j - 1, L)) * rdy);
+            amd_point(dyw0, fzfy * ((vc - v.at(ic, j, L - 1)) * rdzf), p0);
+            amd_point(fyfz * ((wn - wc) * rdy), fzfy * ((vn - v.at(ic, j + 1, L - 1)) * rdzf), p1);
+#pragma unroll
+            for (int q = 0; q < AM_N; ++q) cff[q] = 0.5 * (p0[q] + p1[q]);
+        }
+        fcf[AM_N] = ix_lane(dyw0);                                       // Ix of DYW at (·, j, L)
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            const FView &c = a.c[t];
+            const double dzc = fz * ((c.at(ic, j, L) - c.at(ic, j, L - 1)) * rdzf);
+            tz[t] = dzc; tz2[t] = dzc * dzc;
+        }
+    };
+    // ffc kind and the tracers' x / y operands at level L (what a cell needs of its OWN level)
+    auto horizontal = [&](int L) {
+        double p0[AM_N], p1[AM_N];
+        const double uc = u.at(ic, j, L), un = u.at(ic, j + 1, L), vc = v.at(ic, j, L), vn = v.at(ic, j + 1, L);
+        amd_point(fxfy * ((vc - v.at(ic - 1, j, L)) * rdx), fyfx * ((uc - u.at(ic, j - 1, L)) * rdy), p0);
+        amd_point(fxfy * ((vn - v.at(ic - 1, j + 1, L)) * rdx), fyfx * ((un - uc) * rdy), p1);
+#pragma unroll
+        for (int q = 0; q < AM_N; ++q) ixy[q] = 0.5 * (ix_lane(p0[q]) + ix_lane(p1[q]));
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            const FView &c = a.c[t];
+            const double cc = c.at(ic, j, L);
+            const double dxc = fx * ((cc - c.at(ic - 1, j, L)) * rdx);
+            t_ix[t] = ix_lane(dxc); t_ix2[t] = ix_lane(dxc * dxc);
+            const double dyc0 = fy * ((cc - c.at(ic, j - 1, L)) * rdy), dyc1 = fy * ((c.at(ic, j + 1, L) - cc) * rdy);
+            t_iy[t] = 0.5 * (dyc0 + dyc1); t_iy2[t] = 0.5 * (dyc0 * dyc0 + dyc1 * dyc1);
+        }
+    };
+
+    vertical(kc0, ix_fcf, iy_cff, t_z, t_z2);
+    horizontal(kc0);
+    for (int k = kc0; k <= kc1; ++k) {
+        vertical(k + 1, n_fcf, n_cff, n_z, n_z2);
+#pragma unroll
+        for (int q = 0; q < AM_N; ++q) { A.ixy[q] = ixy[q]; A.ixz[q] = 0.5 * (ix_fcf[q] + n_fcf[q]); A.iyz[q] = 0.5 * (iy_cff[q] + n_cff[q]); }
+        A.ixz[AM_N] = 0.5 * (ix_fcf[AM_N] + n_fcf[AM_N]);
+        A.fz_k = lev[0][k - kc0]; A.delta2_k = lev[6][k - kc0];
+        A.dxu_k = (u.at(ic + 1, j, k) - u.at(ic, j, k)) * rdx;
+        A.dyv_k = (v.at(ic, j + 1, k) - v.at(ic, j, k)) * rdy;
+        A.dzw_k = (w.at(ic, j, k + 1) - w.at(ic, j, k)) * lev[7][k - kc0];
+        if (out_lane) a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            A.tx = t_ix[t]; A.tx2 = t_ix2[t]; A.ty = t_iy[t]; A.ty2 = t_iy2[t];
+            A.tz = 0.5 * (t_z[t] + n_z[t]); A.tz2 = 0.5 * (t_z2[t] + n_z2[t]);
+            if (out_lane) a.kappa_e[t].at(i, j, k) = amd_diffusivity(A, a.Ck[t], i, j, k);
+        }
+#pragma unroll
+        for (int q = 0; q <= AM_N; ++q) ix_fcf[q] = n_fcf[q];
+#pragma unroll
+        for (int q = 0; q < AM_N; ++q) iy_cff[q] = n_cff[q];
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) { t_z[t] = n_z[t]; t_z2[t] = n_z2[t]; }
+        if (k < kc1) horizontal(k + 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Buoyancy: BuoyancyTracer | SeawaterBuoyancy(LinearEquationOfState), gravity along -z.
 // _update_hydrostatic_pressure! (Models/NonhydrostaticModels/update_hydrostatic_pressure.jl:12-22) over i = 0:Nx+1, j = 0:Ny+1
 // (:43-50): pHY′[Nz] = -z_dot_g_b(Nz+1) Δzᶠ(Nz+1); pHY′[k] = pHY′[k+1] - z_dot_g_b(k+1) Δzᶠ(k+1), z_dot_g_bᶜᶜᶠ = 1 * ℑzᵃᵃᶠ(b)
@@ -419,10 +594,10 @@ __global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FVie
 // G_u -= ∂xᶠᶜᶜ pHY′, G_v -= ∂yᶜᶠᶜ pHY′ (nonhydrostatic_tendency_kernel_functions.jl:14-19,97,159) on tendencies holding the
 // advective part; ranges = the tendency ranges of u and v
 __device__ __forceinline__ double hydrostatic_gradient_x(const DGrid &g, const FView &p, int i, int j, int k) {
-    return g.tx == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i - 1, j, k)) * (1.0 / g.dx);
+    return g.tx == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i - 1, j, k)) * g.rdx;
 }
 __device__ __forceinline__ double hydrostatic_gradient_y(const DGrid &g, const FView &p, int i, int j, int k) {
-    return g.ty == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i, j - 1, k)) * (1.0 / g.dy);
+    return g.ty == OCN_FLAT ? 0.0 : (p.at(i, j, k) - p.at(i, j - 1, k)) * g.rdy;
 }
 
 __global__ void __launch_bounds__(256) hydrostatic_gradient_kernel(DGrid g, FView p, FView Gu, FView Gv, Range6 ru, Range6 rv) {
@@ -517,6 +692,11 @@ struct EpilogueArgs {
 // loads waited one after the other (0.94 -> see DESIGN.md for the measured time at 256 x 256 x 128).
 template <bool COR, bool BUOY, int CLO>
 __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
+    // Measured in round 3 at 256 x 256 x 128 with the configs[4] physics (0.66 ms, 2.3 GB of HBM-side traffic = 3.5 TB/s, VALU busy < 50 %), none
+    // faster: reciprocal spacings from tables instead of four FP64 divisions per thread (a third of the arithmetic: same time -- kept);
+    // non-temporal tendency / next-stage streams (same time); an XCD-aware block order, every XCD a contiguous range of (level, field) planes
+    // (FETCH_SIZE 1.03 -> 1.65 GB raw, 0.69 ms: with the plain order all eight XCDs work on the same levels and share them through the Infinity
+    // Cache); one thread per cell looping over the fields (1.09 ms).
     const int f = blockIdx.z % a.n;
     const Range6 r = a.r[f];
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;

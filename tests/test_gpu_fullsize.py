@@ -401,3 +401,31 @@ def test_config3_local_slab_with_the_survey_state_unchanged(ocn, arch):
     for n in ("u", "v", "w", "T"):
         assert errs[n] < 1e-12, errs
     assert errs["S"] <= offset_tracer_bound(size, nsteps), errs
+
+
+def test_marching_amd_kernel_equals_the_per_cell_kernel_at_config2_size(ocn, arch):
+    """AnisotropicMinimumDissipation's eddy coefficients at 256 x 256 x 128 (stretched Bounded z): the z-marching kernel that evaluates
+    every point operand once (x neighbours by lane moves, z neighbours carried in registers, per-level factors from an LDS table;
+    amd_diffusivities_march_kernel) against the one-thread-per-cell kernel that recomputes everything (option amd_march = 0; bit-identical
+    to the oracle at small sizes, tests/test_gpu_parity.py) -- every cell of ν_e, κ_e(T), κ_e(S) bit for bit, also on a range that reaches
+    into the x halos like the one an x-slab rank evaluates"""
+    from helpers import tanh_faces
+    grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2),
+                               topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+    closure = ocn.AnisotropicMinimumDissipation()
+    model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), closure=closure)
+    ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=3))
+    flds = list(model.fields().values())
+    outs = []
+    for rng in (None, (0, N + 1, 1, N, 1, N // 2)):
+        for march in (1, 0):
+            ocn.set_option("amd_march", march)
+            try:
+                nu, ka = ocn.CenterField(grid), [ocn.CenterField(grid), ocn.CenterField(grid)]
+                ocn.kernels.compute_amd_diffusivities(grid, closure, ("T", "S"), flds, nu, ka, kernel_parameters=rng)
+                outs.append([nu.parent()] + [k.parent() for k in ka])
+            finally:
+                ocn.set_option("amd_march", 1)
+        for a, b in zip(outs[-2], outs[-1]):
+            assert np.array_equal(a, b) and np.isfinite(a).all() and a.max() > 0
+    model.close()
