@@ -854,11 +854,11 @@ extern "C" int ocn_cache_tendencies(ocn_grid_t grid, double *const *Gm, const do
 // pressure source term / correction
 // ---------------------------------------------------------------------------------------------------------------------
 static int source_term(const DGrid &g, const double *u, const double *v, const double *w, void *rhs, bool weight, bool real_out = false,
-                       long sj = 0, long sk = 0, bool pad = false, bool wrap = false) {
+                       long sj = 0, long sk = 0, bool pad = false, bool wrap = false, int wrap_mask = 0, const double *u_east = nullptr) {
     if (sj == 0) { sj = g.Nx; sk = (long)g.Nx * g.Ny; }
     if (real_out)
         hipLaunchKernelGGL(source_term_kernel<true>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
-                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, pad, wrap);
+                           make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, pad, wrap ? 7 : wrap_mask, u_east);
     else
         hipLaunchKernelGGL(source_term_kernel<false>, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U),
                            make_view(g, v, LOC_V), make_view(g, w, LOC_W), rhs, weight, sj, sk, false);
@@ -2116,6 +2116,7 @@ static int dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi, bool k
         const long C = (long)s->Nxl * s->Ny / 2, P = (long)s->Nxl * s->Ny;
         launch_strided_line_fft(s->xs, s->ytw, (long)s->Nxl, (long)s->Nxl, (unsigned)s->Nzh, s->Ny, s->logn_y, 1, 1.0, P);
         launch_paired_zline(false, s->xs, (double2 *)s->rx, s->ztw, C, s->Nz, s->logn_z, 1.0);
+        if (!keep_zfast && !phi) return fail(OCN_EINVAL, "NULL pressure field");
         if (!keep_zfast)           // (here: keep the dense x-fastest solution in s->rx)
             hipLaunchKernelGGL(copy_dense_to_field_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C), (const double *)s->rx);
         KERNEL_CHECK();
@@ -2137,6 +2138,7 @@ static int dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi, bool k
         }
         if ((rcz = plan_set_stream(s->plan_zc2r))) return rcz;
         FFT_TRY(hipfftExecZ2D(s->plan_zc2r, (hipfftDoubleComplex *)s->spec, s->rreal));
+        if (!keep_zfast && !phi) return fail(OCN_EINVAL, "NULL pressure field");
         if (!keep_zfast)
             hipLaunchKernelGGL(copy_real_zfast_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
                                make_view(g, phi, LOC_C), s->rreal);
@@ -2149,6 +2151,7 @@ static int dist_poisson_backward_local(ocn_dist_poisson_t s, double *phi, bool k
     int rc;
     if ((rc = plan_set_stream(s->plan_loc))) return rc;
     FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
+    if (!phi) return fail(OCN_EINVAL, "this layout of the substructured solver writes the haloed pressure field: NULL given");
     hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
                        (const double *)s->zfield, s->Nxe);
     KERNEL_CHECK();
@@ -2187,6 +2190,9 @@ static int dist_poisson_source_term_wrapped(ocn_dist_poisson_t s, const double *
         KERNEL_CHECK();
         return OCN_OK;
     }
+    if (!s->zfirst)     // transposing solvers (paired-column layout): y wraps (Periodic), z wraps when Periodic; a Bounded z reads its wall faces
+        return source_term(g, u, v, w, s->zfield, s->zmode == 1, true, (long)s->Nxe * s->Nz, (long)s->Nxe, s->Nxe != s->Nxl, false,
+                           2 | (s->zmode == 0 ? 4 : 0), u_east);
     hipLaunchKernelGGL(source_term_zfast_wrapped_kernel, dim3((g.Nx + 31) / 32, (g.Nz + 31) / 32, g.Ny), dim3(32, 8), 0, g_stream, g,
                        make_view(g, u, LOC_U), make_view(g, v, LOC_V), make_view(g, w, LOC_W), u_east, s->rreal);
     KERNEL_CHECK();
@@ -2261,9 +2267,15 @@ extern "C" int ocn_dist_poisson_solve_x(ocn_dist_poisson_t s) {
 }
 
 // stage 3: rebuild the paired spectrum, local backward transform, copy into the haloed pressure (:167-178)
+static int dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi, bool keep_dense);
 extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
     NEED_INIT();
     if (!s || !s->recv || !phi) return fail(OCN_EINVAL, "solver / buffers not set");
+    return dist_poisson_backward_yz(s, phi, false);
+}
+// keep_dense: leave the solution in the paired-column real array (element (i, j, k) at (i-1) + Nxe ((k-1) + Nz (j-1)) of s->zfield) for the
+// partitioned model's dense pressure correction instead of copying it into a haloed field
+static int dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi, bool keep_dense) {
     const DGrid &g = s->grid->d;
     int rc;
     hipLaunchKernelGGL(dist_combine_backward_kernel, grid3(s->Nxh, s->Ny, s->Nz, BLK), BLK, 0, g_stream, s->recv, s->zfield, s->Nxl, s->Nxh,
@@ -2275,8 +2287,11 @@ extern "C" int ocn_dist_poisson_backward_yz(ocn_dist_poisson_t s, double *phi) {
         if ((rc = plan_set_stream(s->plan_loc))) return rc;
         FFT_TRY(hipfftExecZ2Z(s->plan_loc, (hipfftDoubleComplex *)s->zfield, (hipfftDoubleComplex *)s->zfield, HIPFFT_BACKWARD));
     }
-    hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
-                       (const double *)s->zfield, s->Nxe);
+    if (!keep_dense) {
+        if (!phi) return fail(OCN_EINVAL, "NULL pressure field");
+        hipLaunchKernelGGL(dist_copy_real_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, phi, LOC_C),
+                           (const double *)s->zfield, s->Nxe);
+    }
     KERNEL_CHECK();
     return OCN_OK;
 }

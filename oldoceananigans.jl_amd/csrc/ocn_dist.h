@@ -545,29 +545,48 @@ static int dist_solve_for_pressure(ocn_model_s *m) {
 // compute_pressure_correction! (pressure_correction.jl:8-20). Of the x halos only ONE column is read before update_state! fills
 // everything again: u[Nx+1] by the divergence, p[0] by the correction. The reference's generic fills move Hx columns of u, v, w and of
 // p here; `thin_halos` exchanges the one column of u and of p -- identical results in every cell that is read.
+// where the solver leaves its dense solution and how cell (i, j, k) is addressed in it: (i-1) + sj (j-1) + sk (k-1)
+struct DenseSolution { const double *p; long sj, sk; };
+static DenseSolution dist_dense_solution(const ocn_dist_poisson_s *s, const DGrid &g) {
+    if (s->xfast) return {(const double *)s->rx, (long)g.Nx, (long)g.Nx * g.Ny};
+    return {(const double *)s->zfield, (long)s->Nxe * s->Nz, (long)s->Nxe};          // transposing solvers: paired-column layout (x, z, y)
+}
+
 static int dist_compute_pressure_correction_fused(ocn_model_s *m) {
     // fill_halo_regions!(velocities) reduces to ONE column of u going west (the divergence at i = Nx reads u[Nx+1]; y / z neighbours are
-    // read at wrapped interior indices); solve; fill_halo_regions!(pNHS) reduces to ONE column of p dt going east (the correction at
-    // i = 1 reads p[0]). Both columns travel as dense (Ny, Nz) buffers the consumer kernels read directly.
+    // read at wrapped interior indices) -- plus, on a Bounded z, the local fill that sets the wall faces of w --; solve;
+    // fill_halo_regions!(pNHS) reduces to ONE column of p dt going east (the correction at i = 1 reads p[0]). Both columns travel as
+    // dense (Ny, Nz) buffers the consumer kernels read directly.
     DistModel *dm = m->dm;
     const DGrid &g = m->grid->d;
     ocn_dist_poisson_s *s = dm->solver;
     const size_t col = (size_t)g.Ny * g.Nz;
     int rc;
+    if (g.tz != OCN_PERIODIC && (rc = fill_halo_regions(m->grid, m->U, m->loc, 3, true, m->any_bc ? m->bcs : nullptr))) return rc;
     hipLaunchKernelGGL(column_pack_kernel, dim3((g.Ny + 255) / 256, g.Nz), dim3(256), 0, g_stream, g, make_view(g, m->U[0], LOC_U), 1, g.Nx,
                        dm->cws, dm->ces);
     KERNEL_CHECK();
     if ((rc = dist_exchange_inline(dm->dist, dm->cws, dm->ces, dm->cwr, dm->cer, col))) return rc;
     if ((rc = dist_poisson_source_term_wrapped(s, m->U[0], m->U[1], m->U[2], dm->cer))) return rc;     // from the east neighbour: its u[1]
-    if ((rc = ocn_dist_poisson_forward_local(s))) return rc;
-    if ((rc = ocn_dist_all_gather(dm->dist, dm->buf_a, dm->buf_b, 2 * dm->payload))) return rc;
-    if ((rc = dist_poisson_backward_local(s, nullptr, /*keep_zfast=*/true))) return rc;
-    if (s->xfast)
-        hipLaunchKernelGGL(column_pack_dense_kernel, dim3((g.Ny + 255) / 256, g.Nz), dim3(256), 0, g_stream, g.Nx, g.Ny, g.Nz, (const double *)s->rx,
-                           dm->cws, dm->ces);
-    else
+    if (s->sub) {
+        if ((rc = ocn_dist_poisson_forward_local(s))) return rc;
+        if ((rc = ocn_dist_all_gather(dm->dist, dm->buf_a, dm->buf_b, 2 * dm->payload))) return rc;
+        if ((rc = dist_poisson_backward_local(s, nullptr, /*keep_zfast=*/true))) return rc;
+    } else {
+        const size_t per_rank = 2 * dm->nbuf / (size_t)dm->dist->world;
+        if ((rc = ocn_dist_poisson_forward_yz(s))) return rc;
+        if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_y_to_x!
+        if ((rc = ocn_dist_poisson_solve_x(s))) return rc;
+        if (dm->buf_a != dm->buf_b && (rc = ocn_dist_all_to_all(dm->dist, dm->buf_a, dm->buf_b, per_rank))) return rc;      // transpose_x_to_y!
+        if ((rc = dist_poisson_backward_yz(s, nullptr, /*keep_dense=*/true))) return rc;
+    }
+    if (s->zfirst)
         hipLaunchKernelGGL(column_pack_zfast_kernel, dim3((g.Nz + 255) / 256, g.Ny), dim3(256), 0, g_stream, g.Nx, g.Ny, g.Nz, (const double *)s->rreal,
                            dm->cws, dm->ces);
+    else {
+        const DenseSolution d = dist_dense_solution(s, g);
+        hipLaunchKernelGGL(column_pack_dense_kernel, dim3((g.Ny + 255) / 256, g.Nz), dim3(256), 0, g_stream, g.Nx, g.Ny, g.Nz, d.p, dm->cws, dm->ces, d.sj, d.sk);
+    }
     KERNEL_CHECK();
     return dist_exchange_inline(dm->dist, dm->cws, dm->ces, dm->cwr, dm->cer, col);                      // cwr: the west neighbour's p[Nx] = our p[0]
 }
@@ -597,12 +616,14 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
     if (dm->fused()) {
         // corrections straight from the z-fastest solution (p[0] from the received column): both strips in one launch, pack from wrapped
         // interior indices (no local fill of the strips), start the exchange, then the interior
-        const bool xf = dm->solver->xfast;
-        const double *pd = (const double *)(xf ? dm->solver->rx : dm->solver->rreal), *pw = (const double *)dm->cwr;
+        const bool zf = dm->solver->zfirst, zb = g.tz != OCN_PERIODIC;
+        const DenseSolution d = dist_dense_solution(dm->solver, g);
+        const double *pd = zf ? (const double *)dm->solver->rreal : d.p, *pw = (const double *)dm->cwr;
         const FView vu = make_view(g, m->U[0], LOC_U), vv = make_view(g, m->U[1], LOC_V), vw = make_view(g, m->U[2], LOC_W), vp = make_view(g, m->p, LOC_C);
         auto pcz = [&](int ia, int ib) {
-            if (xf)          // the solution is dense and x-fastest: the single-GPU path's dense correction on a column range
-                hipLaunchKernelGGL(pressure_correction_dense_slab_kernel, grid3(ib - ia + 1, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib);
+            if (!zf)         // the solution is dense and x-fastest: the single-GPU path's dense correction on a column range
+                hipLaunchKernelGGL(pressure_correction_dense_slab_kernel, grid3(ib - ia + 1, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib,
+                                   d.sj, d.sk, zb);
             else
                 hipLaunchKernelGGL(pressure_correction_zfast_kernel, dim3((ib - ia + 32) / 32, (g.Nz + 31) / 32, (g.Ny + OCN_ZC_JB - 1) / OCN_ZC_JB), dim3(32, 8), 0,
                                    g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib);
@@ -610,12 +631,16 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
             return e == hipSuccess ? OCN_OK : fail((int)e, "pressure correction (partitioned slab): %s", hipGetErrorString(e));
         };
         if (!early) return pcz(1, g.Nx);
-        if (xf)
-            hipLaunchKernelGGL(pressure_correction_dense_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx);
+        if (!zf)
+            hipLaunchKernelGGL(pressure_correction_dense_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx,
+                               d.sj, d.sk, zb);
         else
             hipLaunchKernelGGL(pressure_correction_zfast_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx);
         KERNEL_CHECK();
-        if ((rc = x_halo_pack_wrapped(g, m->U, m->loc, m->nf, dm->ws, dm->es))) return rc;
+        if (zb) {            // a Bounded z: the strips' z halos come from their boundary conditions -- local fill, then the plain pack
+            if ((rc = fill_halo_regions(m->grid, m->U, m->loc, m->nf, false, m->any_bc ? m->bcs : nullptr))) return rc;
+            if ((rc = x_halo_buffers(g, m->U, m->loc, m->nf, dm->ws, dm->es, true))) return rc;
+        } else if ((rc = x_halo_pack_wrapped(g, m->U, m->loc, m->nf, dm->ws, dm->es))) return rc;
         if ((rc = ocn_dist_exchange_start(dm->dist, dm->ws, dm->es, dm->wr, dm->er, dm->slab_total))) return rc;
         dm->halos_in_flight = true;
         return pcz(g.Hx + 1, g.Nx - g.Hx);
@@ -773,6 +798,23 @@ static int gathered_solve_create(DistModel *dm, ocn_grid_t local_grid, double Lx
     return OCN_OK;
 }
 
+// the pressure step without fills / copies between its stages (ocn_kernels.h "Round 3"): a partitioned (connected, Periodic, *) slab with one
+// of the accelerated solvers -- the substructured ones (z Periodic: every field shares one parent shape, which the wrapped pack relies on)
+// or the transposing ones (z Periodic or Bounded: the solution stays in their dense paired-column array)
+static int dist_enable_fused_step(DistModel *dm, const DGrid &g, bool part) {
+    if (!(g_dist_fused_step && part && g.ty == OCN_PERIODIC && g.Nx >= 2 && (g.tz == OCN_PERIODIC || g.tz == OCN_BOUNDED))) return OCN_OK;
+    if (dm->solver->sub && (g.tz != OCN_PERIODIC || !(dm->solver->zfirst || dm->solver->xfast))) return OCN_OK;    // (the paired-column substructured layout keeps the unfused step)
+    const size_t col = (size_t)g.Ny * g.Nz * sizeof(double);
+    double **cb[4] = {&dm->cws, &dm->ces, &dm->cwr, &dm->cer};
+    for (auto b : cb) {
+        hipError_t e = dev_alloc((void **)b, col);
+        if (e != hipSuccess) return fail((int)e, "dev_alloc(column buffers): %s", hipGetErrorString(e));
+        hipMemsetAsync(*b, 0, col, g_stream);
+    }
+    dm->fused_step = true;
+    return OCN_OK;
+}
+
 static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntracers, ocn_dist_t dist, double Lx_global, const int *local_sizes,
                              int global_x_topology, double Ly_global, const int *sizes_y, int global_y_topology) {
     NEED_INIT();
@@ -867,18 +909,7 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
         hipMemsetAsync(dm->buf_a, 0, 2 * n * sizeof(double), g_stream);
         hipMemsetAsync(dm->buf_b, 0, 2 * n * sizeof(double) * (size_t)dist->world, g_stream);
         if ((rc = ocn_dist_poisson_set_gather_buffers(dm->solver, dm->buf_a, dm->buf_b))) return bail(rc);
-        // the pressure step without fills / copies between its stages: z-fastest substructured solver on a partitioned slab whose y and
-        // z directions are Periodic (every field then shares one parent shape, which the wrapped pack relies on)
-        if (g_dist_fused_step && part && (dm->solver->zfirst || dm->solver->xfast) && g.ty == OCN_PERIODIC && g.tz == OCN_PERIODIC && g.Nx >= 2) {
-            const size_t col = (size_t)g.Ny * g.Nz * sizeof(double);
-            double **cb[4] = {&dm->cws, &dm->ces, &dm->cwr, &dm->cer};
-            for (auto b : cb) {
-                e = dev_alloc((void **)b, col);
-                if (e != hipSuccess) return bail(fail((int)e, "dev_alloc(column buffers): %s", hipGetErrorString(e)));
-                hipMemsetAsync(*b, 0, col, g_stream);
-            }
-            dm->fused_step = true;
-        }
+        if ((rc = dist_enable_fused_step(dm, g, part))) return bail(rc);
     } else {
         ocn_dist_poisson_buffer_size(dm->solver, &n);
         dm->nbuf = n;
@@ -890,6 +921,7 @@ static int dist_model_create(ocn_model_t *model, ocn_grid_t local_grid, int ntra
         hipMemsetAsync(dm->buf_a, 0, 2 * n * sizeof(double), g_stream);
         if (dm->buf_b != dm->buf_a) hipMemsetAsync(dm->buf_b, 0, 2 * n * sizeof(double), g_stream);
         if ((rc = ocn_dist_poisson_set_buffers(dm->solver, dm->buf_a, dm->buf_b))) return bail(rc);
+        if ((rc = dist_enable_fused_step(dm, g, part))) return bail(rc);
     }
     return OCN_OK;
 }

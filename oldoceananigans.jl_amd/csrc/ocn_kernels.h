@@ -1050,13 +1050,16 @@ __global__ void __launch_bounds__(256) cache_tendencies_kernel(SubstepArgs a) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the source term of the pressure equation at cell (i, j, k): divᶜᶜᶜ(u*) [x Δzᶜ for the Fourier-tridiagonal solver]
 // (solve_for_pressure.jl:12-84, Operators/divergence_operators.jl:16-19)
+// wrap: bit 0 / 1 / 2 = the upper x / y / z neighbour of the last cell is read at its wrapped interior index instead of the halo;
+// ue (x-slab ranks): u[Nx + 1, j, k] is read from this dense (Ny, Nz) buffer -- the east neighbour's first column, just received
 __device__ __forceinline__ double source_value(const DGrid &g, const FView &u, const FView &v, const FView &w, int i, int j, int k,
-                                               bool weight_by_dz, bool wrap) {
+                                               bool weight_by_dz, int wrap, const double *ue = nullptr) {
     const int kk = k - 1 + g.Hz;
     const double ax = g.ax[kk], ay = g.ay[kk], az = g.az;
-    const int ip = (wrap && i == g.Nx) ? 1 : i + 1, jp = (wrap && j == g.Ny) ? 1 : j + 1, kp = (wrap && k == g.Nz) ? 1 : k + 1;
+    const int ip = ((wrap & 1) && i == g.Nx) ? 1 : i + 1, jp = ((wrap & 2) && j == g.Ny) ? 1 : j + 1, kp = ((wrap & 4) && k == g.Nz) ? 1 : k + 1;
+    const double up = (ue && i == g.Nx) ? ue[(long)(j - 1) + (long)g.Ny * (k - 1)] : u.at(ip, j, k);
     // δ along a Flat direction is zero(FT) (Operators/difference_operators.jl:30-49)
-    double dx = g.tx == OCN_FLAT ? 0.0 : ax * u.at(ip, j, k) - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
+    double dx = g.tx == OCN_FLAT ? 0.0 : ax * up - ax * u.at(i, j, k);      // δxᶜᶜᶜ(Ax_qᶠᶜᶜ, u)
     double dy = g.ty == OCN_FLAT ? 0.0 : ay * v.at(i, jp, k) - ay * v.at(i, j, k);
     double dz = g.tz == OCN_FLAT ? 0.0 : az * w.at(i, j, kp) - az * w.at(i, j, k);
     double div = g.vinv_c[kk] * ((dx + dy) + dz);                 // divᶜᶜᶜ, Operators/divergence_operators.jl:16-19
@@ -1069,12 +1072,12 @@ template <bool REAL_OUT>
 // wrap (triply periodic grids only): the upper neighbours are read at their wrapped INTERIOR index instead of the halo, so the
 // velocity halo fill that precedes the solve in the reference can be left to the next update_state! (same values by construction)
 __global__ void __launch_bounds__(256) source_term_kernel(DGrid g, FView u, FView v, FView w, void *rhs, bool weight_by_dz,
-                                                          long sj, long sk, bool pad, bool wrap = false) {
+                                                          long sj, long sk, bool pad, int wrap = 0, const double *ue = nullptr) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > g.Nx || j > g.Ny || k > g.Nz) return;
-    const double val = source_value(g, u, v, w, i, j, k, weight_by_dz, wrap);
+    const double val = source_value(g, u, v, w, i, j, k, weight_by_dz, wrap, ue);
     const long q = (long)(i - 1) + sj * (j - 1) + sk * (k - 1);
     if (REAL_OUT) {                                         // real-transform paths (rhs is real by construction)
         ((double *)rhs)[q] = val;
@@ -2393,28 +2396,30 @@ __global__ void __launch_bounds__(256) source_term_dense_wrapped_kernel(DGrid g,
 }
 
 // first / last column of the dense x-fastest array -> dense (Ny, Nz) buffers [j-1 + Ny (k-1)]
-__global__ void __launch_bounds__(256) column_pack_dense_kernel(int Nx, int Ny, int Nz, const double *r, double *west, double *east) {
+__global__ void __launch_bounds__(256) column_pack_dense_kernel(int Nx, int Ny, int Nz, const double *r, double *west, double *east, long sj, long sk) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
     if (j >= Ny || k >= Nz) return;
-    const long row = (long)Nx * (j + (long)Ny * k), b = (long)j + (long)Ny * k;
+    const long row = sj * j + sk * k, b = (long)j + (long)Ny * k;
     west[b] = r[row];
     east[b] = r[row + Nx - 1];
 }
 
 // pressure_correction_dense_kernel on the columns ia .. ib of a partitioned slab: p[0, j, k] = pw[j-1 + Ny (k-1)] (the west neighbour's
 // last column, received) instead of the periodic wrap; y and z Periodic. Same expressions.
+// The dense array holds cell (i, j, k) at (i-1) + sj (j-1) + sk (k-1): (Nx, Nx Ny) for the x-fastest substructured solve, (Nxe Nz, Nxe) for the
+// transposing solvers' paired-column layout; zbounded: p[0] = p[1] (the no-flux halo of a Bounded z: the bottom face keeps its w).
 __global__ void __launch_bounds__(256) pressure_correction_dense_slab_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
-                                                                             FView p, double divisor, int ia, int ib) {
+                                                                             FView p, double divisor, int ia, int ib, long sj, long sk, bool zbounded) {
     const int i = ia + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
     if (i > ib || j > g.Ny || k > g.Nz) return;
-    const long sx = g.Nx, sxy = (long)g.Nx * g.Ny;
+    const long sx = sj, sxy = sk;
     const long q = (long)(i - 1) + sx * (j - 1) + sxy * (k - 1);
     const double pc = pd[q];
     const double pim = i == 1 ? pw[(long)(j - 1) + (long)g.Ny * (k - 1)] : pd[q - 1];
     const double pjm = pd[j == 1 ? q + sx * (g.Ny - 1) : q - sx];
-    const double pkm = pd[k == 1 ? q + sxy * (g.Nz - 1) : q - sxy];
+    const double pkm = k == 1 ? (zbounded ? pc : pd[q + sxy * (g.Nz - 1)]) : pd[q - sxy];
     u.at(i, j, k) -= (pc - pim) * g.rdx;
     v.at(i, j, k) -= (pc - pjm) * g.rdy;
     w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
@@ -2422,16 +2427,16 @@ __global__ void __launch_bounds__(256) pressure_correction_dense_slab_kernel(DGr
 }
 // ... and on the two Hx-wide boundary strips in one launch (threads along (column, y))
 __global__ void __launch_bounds__(256) pressure_correction_dense_strips_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
-                                                                               FView p, double divisor, int H) {
+                                                                               FView p, double divisor, int H, long sj, long sk, bool zbounded) {
     const int c = threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
     if (c >= 2 * H || j > g.Ny || k > g.Nz) return;
     const int i = c < H ? 1 + c : g.Nx - 2 * H + 1 + c;
-    const long sx = g.Nx, sxy = (long)g.Nx * g.Ny;
+    const long sx = sj, sxy = sk;
     const long q = (long)(i - 1) + sx * (j - 1) + sxy * (k - 1);
     const double pc = pd[q];
     const double pim = i == 1 ? pw[(long)(j - 1) + (long)g.Ny * (k - 1)] : pd[q - 1];
     const double pjm = pd[j == 1 ? q + sx * (g.Ny - 1) : q - sx];
-    const double pkm = pd[k == 1 ? q + sxy * (g.Nz - 1) : q - sxy];
+    const double pkm = k == 1 ? (zbounded ? pc : pd[q + sxy * (g.Nz - 1)]) : pd[q - sxy];
     u.at(i, j, k) -= (pc - pim) * g.rdx;
     v.at(i, j, k) -= (pc - pjm) * g.rdy;
     w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
