@@ -560,6 +560,9 @@ __device__ __forceinline__ double buoyancy_perturbation(const BuoyancyArgs &B, l
     return B.kind == 1 ? B.bT[q] : B.grav * (B.alpha * B.bT[q] - B.beta * B.S[q]);
 }
 
+#ifndef OCN_HYDRO_TB
+#define OCN_HYDRO_TB 32
+#endif
 __global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FView c, BuoyancyArgs B, double *pHY, int i0, int i1, int j0, int j1) {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
@@ -568,8 +571,9 @@ __global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FVie
     long q = c.lin(i, j, Nz + 1);
     double bk1 = buoyancy_perturbation(B, q);          // b[k+1]
     double p = 0.0;
-    // the recurrence is serial in k but its loads are not: fetch TB levels, then sweep them (few columns => latency-bound otherwise)
-    constexpr int TB = 8;
+    // the recurrence is serial in k but its loads are not: fetch TB levels, then sweep them (few columns => latency-bound otherwise:
+    // 66 K columns at 256 x 256 are one wave per SIMD; TB = 8 -> 32 measured in round 3)
+    constexpr int TB = OCN_HYDRO_TB;
     for (int k0 = Nz; k0 >= 1; k0 -= TB) {
         double bb[TB];
 #pragma unroll
