@@ -43,6 +43,9 @@ env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL
 if mode == "ok":
     print(json.dumps(env)); sys.exit(0)
 if mode == "fail" and rank == 1:
+    n, t0 = int(os.environ["WORLD_SIZE"]), time.time()      # fail once every peer is up (a loaded machine starts them slowly): the test counts their pids
+    while time.time() - t0 < 20 and not all(os.path.exists(os.path.join(piddir, f"pid{r}")) for r in range(n)):
+        time.sleep(0.05)
     print("rank 1 about to fail", file=sys.stderr); sys.exit(3)
 if mode == "leave" and rank == 0:
     sys.exit(0)
