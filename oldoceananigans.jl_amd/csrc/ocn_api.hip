@@ -5,6 +5,7 @@
 #include "ocn_kernels.h"
 #include "ocn_tendency_fused.h"
 #include "ocn_tendency_roles.h"
+#include "ocn_epilogue_march.h"
 #include <hipfft/hipfft.h>
 #include <cmath>
 #include <cstdarg>
@@ -716,6 +717,9 @@ extern "C" int ocn_compute_closure_tendencies_field(ocn_grid_t grid, const doubl
     return closure_tendencies(grid->d, u, v, w, tracers, ntracers, 0.0, nullptr, Gu, Gv, Gw, Gc, range, nu_e, kappa_e);
 }
 
+static int g_epilogue_march = 1;       // closure / Coriolis / pHY′ epilogue as a z-march that shares the symmetric flux tensor (0: one thread per field value)
+static int g_epilogue_rows = 4;        // rows (waves) per block of that kernel
+static int g_epilogue_kchunk = 0;      // levels per block of that kernel (0: automatic)
 static int g_amd_march = 1;            // eddy diffusivities by the z-marching kernel that shares the point operands (0: one thread per cell, everything recomputed)
 static int amd_diffusivities(const DGrid &g, double Cnu, const double *Ckappa, const double *u, const double *v, const double *w,
                              const double *const *tr, int ntr, double *nu_e, double *const *kappa_e, const int *range = nullptr) {
@@ -2484,6 +2488,9 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
     if (!strcmp(key, "dist_pencil_transposes")) { g_dist_pencil_transposes = value; return OCN_OK; }
     if (!strcmp(key, "amd_march")) { g_amd_march = value; return OCN_OK; }
+    if (!strcmp(key, "epilogue_march")) { g_epilogue_march = value; return OCN_OK; }
+    if (!strcmp(key, "epilogue_rows")) { if (value < 1 || value > 8) return fail(OCN_EINVAL, "epilogue_rows is 1 .. 8"); g_epilogue_rows = value; return OCN_OK; }
+    if (!strcmp(key, "epilogue_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "epilogue_kchunk must be >= 0 (0 = automatic)"); g_epilogue_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
@@ -2552,8 +2559,46 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
             if (sd < 3) a.loc[f][sd] = f < m->nf ? m->loc[f][sd] : 0;
         }
     if (nx <= 0 || ny <= 0 || nz <= 0) return OCN_OK;
-    const dim3 grd = grid3(nx, ny, nz * m->nf, BLK);
     const int clo = m->has_amd ? 2 : (m->has_closure ? 1 : 0);
+    // closure terms on a grid without Flat directions: the z-marching form (ocn_epilogue_march.h) -- the union of the fields' ranges, one
+    // column of halo around it readable
+    if (g_epilogue_march && clo != 0 && m->ntr <= 2 && g.tx != OCN_FLAT && g.ty != OCN_FLAT && g.tz != OCN_FLAT) {
+        Range6 R = a.r[0];
+        for (int f = 1; f < m->nf; ++f) {
+            R.i0 = std::min(R.i0, a.r[f].i0); R.i1 = std::max(R.i1, a.r[f].i1); R.j0 = std::min(R.j0, a.r[f].j0); R.j1 = std::max(R.j1, a.r[f].j1);
+            R.k0 = std::min(R.k0, a.r[f].k0); R.k1 = std::max(R.k1, a.r[f].k1);
+        }
+        if (R.i0 - 1 >= 1 - g.Hx && R.i1 + 1 <= g.Nx + g.Hx && R.j0 - 1 >= 1 - g.Hy && R.j1 + 1 <= g.Ny + g.Hy && R.k0 - 1 >= 1 - g.Hz && R.k1 + 1 <= g.Nz + g.Hz) {
+            const int ni = R.i1 - R.i0 + 1, nj = R.j1 - R.j0 + 1, nk = R.k1 - R.k0 + 1;
+            const int bx = (ni + OCN_EPI_MARCH_COLS - 1) / OCN_EPI_MARCH_COLS, by = (nj + g_epilogue_rows - 1) / g_epilogue_rows;
+            int kchunk = g_epilogue_kchunk;
+            if (kchunk <= 0) {                       // >= ~8 waves per SIMD over the chip, chunks of at least 8 levels
+                kchunk = nk;
+                while (kchunk > 8 && (long)bx * by * ((nk + kchunk - 1) / kchunk) * g_epilogue_rows < 8192) kchunk = (kchunk + 1) / 2;
+            }
+            const dim3 mg(bx, by, (nk + kchunk - 1) / kchunk), mb(64, g_epilogue_rows);
+#define OCN_EPM(COR, BUOY, CLO, NTR) hipLaunchKernelGGL((tendency_epilogue_march_kernel<COR, BUOY, CLO, NTR>), mg, mb, 0, g_stream, g, a, R, kchunk)
+#define OCN_EPM_N(COR, BUOY, CLO) do { if (m->ntr == 2) OCN_EPM(COR, BUOY, CLO, 2); else if (m->ntr == 1) OCN_EPM(COR, BUOY, CLO, 1); else OCN_EPM(COR, BUOY, CLO, 0); } while (0)
+#define OCN_EPM_CLO(COR, BUOY) do { if (clo == 2) OCN_EPM_N(COR, BUOY, 2); else OCN_EPM_N(COR, BUOY, 1); } while (0)
+            if (a.has_coriolis) { if (a.has_buoyancy) OCN_EPM_CLO(true, true); else OCN_EPM_CLO(true, false); }
+            else                { if (a.has_buoyancy) OCN_EPM_CLO(false, true); else OCN_EPM_CLO(false, false); }
+#undef OCN_EPM_CLO
+#undef OCN_EPM_N
+#undef OCN_EPM
+            KERNEL_CHECK();
+            int mask = 0;
+            for (int f = 0; f < m->nf; ++f)
+                for (int sd = 0; sd < 6; ++sd)
+                    if ((a.any_flux && a.has_flux[f][sd]) || m->lin[f][sd].on) mask |= 1 << sd;
+            if (mask) {
+                const int na = std::max(g.Nx, g.Ny), nb = std::max(g.Ny, g.Nz);
+                hipLaunchKernelGGL(epilogue_flux_shell_kernel, dim3((na + 63) / 64, (nb + 3) / 4, 6), dim3(64, 4), 0, g_stream, g, a, mask);
+                KERNEL_CHECK();
+            }
+            return OCN_OK;
+        }
+    }
+    const dim3 grd = grid3(nx, ny, nz * m->nf, BLK);
 #define OCN_EPI(COR, BUOY, CLO) hipLaunchKernelGGL((tendency_epilogue_kernel<COR, BUOY, CLO>), grd, BLK, 0, g_stream, g, a)
 #define OCN_EPI_CLO(COR, BUOY) do { if (clo == 2) OCN_EPI(COR, BUOY, 2); else if (clo == 1) OCN_EPI(COR, BUOY, 1); else OCN_EPI(COR, BUOY, 0); } while (0)
     if (a.has_coriolis) { if (a.has_buoyancy) OCN_EPI_CLO(true, true); else OCN_EPI_CLO(true, false); }

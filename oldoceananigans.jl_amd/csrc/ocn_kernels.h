@@ -626,28 +626,37 @@ __device__ __forceinline__ bool inactive_cell(const DGrid &g, int i, int j, int 
            (g.tz == OCN_BOUNDED && (k < 1 || k > g.Nz));
 }
 
-// x_f_cross_U at (f, c, c) and y_f_cross_U at (c, f, c)
-__device__ __forceinline__ double x_f_cross_U(const DGrid &g, double f, const FView &v, int i, int j, int k) {
+// x_f_cross_U at (f, c, c) and y_f_cross_U at (c, f, c). The field is read through `q(di, dj)` = value at (i + di, j + dj, k): from memory
+// (the stand-alone kernels) or from the registers of the marching epilogue -- one body for both, so the same operations on the same values.
+template <class Q>
+__device__ __forceinline__ double x_f_cross_U_of(const DGrid &g, double f, Q q, int i, int j, int k) {
     const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
     // ℑxyᶠᶜᵃ = ℑyᵃᶜᵃ(ℑxᶠᵃᵃ ·): X(jj) = 0.5 (q[i-1, jj] + q[i, jj]); 0.5 (X(j) + X(j+1)); not_peripheral at (c, f, c)
-    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii, jj - 1, k)) ? 1.0 : 0.0; };
-    auto Xq = [&](int jj) { return fx ? v.at(i, jj, k) : 0.5 * (v.at(i - 1, jj, k) + v.at(i, jj, k)); };
+    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) || inactive_cell(g, ii, jj - 1, k)) ? 1.0 : 0.0; };
+    auto Xq = [&](int dj) { return fx ? q(0, dj) : 0.5 * (q(-1, dj) + q(0, dj)); };
     auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i - 1, jj) + np(i, jj)); };
-    const double qa = fy ? Xq(j) : 0.5 * (Xq(j) + Xq(j + 1));
+    const double qa = fy ? Xq(0) : 0.5 * (Xq(0) + Xq(1));
     const double an = fy ? Xn(j) : 0.5 * (Xn(j) + Xn(j + 1));
     const double aw = an == 0 ? 0.0 : qa / an;
     return -f * aw;
 }
-__device__ __forceinline__ double y_f_cross_U(const DGrid &g, double f, const FView &u, int i, int j, int k) {
+template <class Q>
+__device__ __forceinline__ double y_f_cross_U_of(const DGrid &g, double f, Q q, int i, int j, int k) {
     const bool fx = g.tx == OCN_FLAT, fy = g.ty == OCN_FLAT;
     // ℑxyᶜᶠᵃ = ℑyᵃᶠᵃ(ℑxᶜᵃᵃ ·): X(jj) = 0.5 (q[i, jj] + q[i+1, jj]); 0.5 (X(j-1) + X(j)); not_peripheral at (f, c, c)
-    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) | inactive_cell(g, ii - 1, jj, k)) ? 1.0 : 0.0; };
-    auto Xq = [&](int jj) { return fx ? u.at(i, jj, k) : 0.5 * (u.at(i, jj, k) + u.at(i + 1, jj, k)); };
+    auto np = [&](int ii, int jj) { return !(inactive_cell(g, ii, jj, k) || inactive_cell(g, ii - 1, jj, k)) ? 1.0 : 0.0; };
+    auto Xq = [&](int dj) { return fx ? q(0, dj) : 0.5 * (q(0, dj) + q(1, dj)); };
     auto Xn = [&](int jj) { return fx ? np(i, jj) : 0.5 * (np(i, jj) + np(i + 1, jj)); };
-    const double qa = fy ? Xq(j) : 0.5 * (Xq(j - 1) + Xq(j));
+    const double qa = fy ? Xq(0) : 0.5 * (Xq(-1) + Xq(0));
     const double an = fy ? Xn(j) : 0.5 * (Xn(j - 1) + Xn(j));
     const double aw = an == 0 ? 0.0 : qa / an;
     return f * aw;
+}
+__device__ __forceinline__ double x_f_cross_U(const DGrid &g, double f, const FView &v, int i, int j, int k) {
+    return x_f_cross_U_of(g, f, [&](int di, int dj) { return v.at(i + di, j + dj, k); }, i, j, k);
+}
+__device__ __forceinline__ double y_f_cross_U(const DGrid &g, double f, const FView &u, int i, int j, int k) {
+    return y_f_cross_U_of(g, f, [&](int di, int dj) { return u.at(i + di, j + dj, k); }, i, j, k);
 }
 
 __global__ void __launch_bounds__(256) fplane_coriolis_kernel(DGrid g, double f, FView u, FView v, FView Gu, FView Gv, Range6 ru, Range6 rv) {
@@ -691,41 +700,9 @@ struct EpilogueArgs {
     struct Lin { int f, side, dep; double a, b; } lin[OCN_EPILOGUE_MAX_LIN];
 };
 
-// COR / BUOY / CLO (0 none, 1 constant ν, κ, 2 eddy-coefficient arrays) are compile-time: the terms of one cell then form ONE basic
-// block whose ~40 loads the compiler issues together -- with run-time flags every term was its own block behind a branch and its
-// loads waited one after the other (0.94 -> see DESIGN.md for the measured time at 256 x 256 x 128).
-template <bool COR, bool BUOY, int CLO>
-__global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
-    // Measured in round 3 at 256 x 256 x 128 with the configs[4] physics (0.66 ms, 2.3 GB of HBM-side traffic = 3.5 TB/s, VALU busy < 50 %), none
-    // faster: reciprocal spacings from tables instead of four FP64 divisions per thread (a third of the arithmetic: same time -- kept);
-    // non-temporal tendency / next-stage streams (same time); an XCD-aware block order, every XCD a contiguous range of (level, field) planes
-    // (FETCH_SIZE 1.03 -> 1.65 GB raw, 0.69 ms: with the plain order all eight XCDs work on the same levels and share them through the Infinity
-    // Cache); one thread per cell looping over the fields (1.09 ms).
-    const int f = blockIdx.z % a.n;
-    const Range6 r = a.r[f];
-    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
-    const int k = r.k0 + blockIdx.z / a.n;
-    if (i > r.i1 || j > r.j1 || k > r.k1) return;
-    const FView &fv = f == 0 ? a.u : (f == 1 ? a.v : (f == 2 ? a.w : a.c[f - 3]));
-    const long q = fv.lin(i, j, k);
-    double G = a.Gn[f][q];
-    constexpr bool VAR = CLO == 2;
-    if (f == 0) {
-        if (COR) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
-        if (BUOY) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
-        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
-    } else if (f == 1) {
-        if (COR) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
-        if (BUOY) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
-        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
-    } else if (f == 2) {
-        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
-    } else {
-        const double kap = a.kappa[f - 3];
-        if (CLO && (VAR || kap != 0.0))
-            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, VAR, a.kappa_e[f - 3])) + 0.0;
-    }
+// the valued and the linear field-dependent Flux conditions of field f at (i, j, k) (parent index q), applied to a tendency G that holds
+// the interior terms
+__device__ __forceinline__ double epilogue_flux_conditions(const DGrid &g, const EpilogueArgs &a, int f, int i, int j, int k, long q, double G) {
     if (a.any_flux) {
         // compute_x/y/z_bcs!: G[1] += flux A / V, G[N] -= flux A / V (x, then y, then z as the reference launches them)
         const double dz = a.loc[f][2] == OCN_FACE ? g.dzf[k - 1 + g.Hz] : g.dzc[k - 1 + g.Hz];
@@ -761,6 +738,45 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
         if (sd & 1) G -= flux * area / vol;
         else        G += flux * area / vol;
     }
+    return G;
+}
+
+// COR / BUOY / CLO (0 none, 1 constant ν, κ, 2 eddy-coefficient arrays) are compile-time: the terms of one cell then form ONE basic
+// block whose ~40 loads the compiler issues together -- with run-time flags every term was its own block behind a branch and its
+// loads waited one after the other (0.94 -> see DESIGN.md for the measured time at 256 x 256 x 128).
+template <bool COR, bool BUOY, int CLO>
+__global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
+    // Measured in round 3 at 256 x 256 x 128 with the configs[4] physics (0.66 ms, 2.3 GB of HBM-side traffic = 3.5 TB/s, VALU busy < 50 %), none
+    // faster: reciprocal spacings from tables instead of four FP64 divisions per thread (a third of the arithmetic: same time -- kept);
+    // non-temporal tendency / next-stage streams (same time); an XCD-aware block order, every XCD a contiguous range of (level, field) planes
+    // (FETCH_SIZE 1.03 -> 1.65 GB raw, 0.69 ms: with the plain order all eight XCDs work on the same levels and share them through the Infinity
+    // Cache); one thread per cell looping over the fields (1.09 ms).
+    const int f = blockIdx.z % a.n;
+    const Range6 r = a.r[f];
+    const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = r.j0 + blockIdx.y * blockDim.y + threadIdx.y;
+    const int k = r.k0 + blockIdx.z / a.n;
+    if (i > r.i1 || j > r.j1 || k > r.k1) return;
+    const FView &fv = f == 0 ? a.u : (f == 1 ? a.v : (f == 2 ? a.w : a.c[f - 3]));
+    const long q = fv.lin(i, j, k);
+    double G = a.Gn[f][q];
+    constexpr bool VAR = CLO == 2;
+    if (f == 0) {
+        if (COR) G = G - x_f_cross_U(g, a.fcor, a.v, i, j, k);
+        if (BUOY) G = G - hydrostatic_gradient_x(g, a.pHY, i, j, k);
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_U>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
+    } else if (f == 1) {
+        if (COR) G = G - y_f_cross_U(g, a.fcor, a.u, i, j, k);
+        if (BUOY) G = G - hydrostatic_gradient_y(g, a.pHY, i, j, k);
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_V>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
+    } else if (f == 2) {
+        if (CLO && (VAR || a.nu != 0.0)) G = (G - closure_divergence<F_W>(g, a.u, a.v, a.w, a.u, a.nu, i, j, k, VAR, a.nu_e)) + 0.0;
+    } else {
+        const double kap = a.kappa[f - 3];
+        if (CLO && (VAR || kap != 0.0))
+            G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, VAR, a.kappa_e[f - 3])) + 0.0;
+    }
+    G = epilogue_flux_conditions(g, a, f, i, j, k, q, G);
     a.Gn[f][q] = G;
     if (a.substep) {
         double Uv = fv.p[q];

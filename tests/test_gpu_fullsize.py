@@ -429,3 +429,52 @@ def test_marching_amd_kernel_equals_the_per_cell_kernel_at_config2_size(ocn, arc
         for a, b in zip(outs[-2], outs[-1]):
             assert np.array_equal(a, b) and np.isfinite(a).all() and a.max() > 0
     model.close()
+
+
+@pytest.mark.parametrize("case", ["configs4_physics_256x256x128", "walls_scalar_diffusivity", "walls_no_tracer_amd"])
+def test_marching_epilogue_equals_the_one_thread_per_value_epilogue(ocn, arch, case):
+    """the pass that completes the tendencies after the advective part -- Coriolis, pHY′ gradient, closure fluxes, Flux conditions, the next
+    stage's substep -- as a z-march that evaluates the symmetric viscous flux tensor once per point (tendency_epilogue_march_kernel + the
+    boundary-cell kernel for Flux conditions, csrc/ocn_epilogue_march.h) against the one-thread-per-field-value kernel (option epilogue_march
+    = 0; both bit-identical to the oracle at small sizes, tests/test_gpu_parity.py): fields, tendencies and pressure after 2 RK3 steps, bit for
+    bit -- at the bench's configs[4]-physics size, and on wall-bounded grids with Flux conditions on every kind of side, sizes that are no
+    multiple of the 62 columns / 4 rows a block covers"""
+    from helpers import tanh_faces
+    F = ocn.FieldBoundaryConditions
+    if case == "configs4_physics_256x256x128":
+        import bench
+        grid = ocn.RectilinearGrid(arch, size=(N, N, N // 2), x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(N // 2), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        kw = dict(tracers=("T", "S"), coriolis=ocn.FPlane(f=1e-4), **bench.workload_physics(ocn, "ppb_amd"))
+        dt = 0.1 / N / 0.6
+    elif case == "walls_scalar_diffusivity":
+        grid = ocn.RectilinearGrid(arch, size=(70, 37, 21), x=(0.0, 1.0), y=(0.0, 0.6), z=tanh_faces(21), topology=(ocn.Bounded, ocn.Bounded, ocn.Bounded))
+        kw = dict(tracers=("T", "S"), closure=ocn.ScalarDiffusivity(ν=2e-3, κ=1e-3), coriolis=ocn.FPlane(f=0.4), buoyancy=ocn.SeawaterBuoyancy(),
+                  boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-3), south=ocn.FluxBoundaryCondition(2e-3)),
+                                       "v": F(east=ocn.FluxBoundaryCondition(3e-3), bottom=ocn.FluxBoundaryCondition(-2e-3)),
+                                       "w": F(west=ocn.FluxBoundaryCondition(1e-3), north=ocn.FluxBoundaryCondition(-1e-3)),
+                                       "T": F(top=ocn.FluxBoundaryCondition(4e-3), west=ocn.FluxBoundaryCondition(-3e-3), north=ocn.FluxBoundaryCondition(2e-3)),
+                                       "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-2.5e-3), field_dependencies="S"), east=ocn.FluxBoundaryCondition(1e-3))})
+        dt = 2e-3
+    else:
+        grid = ocn.RectilinearGrid(arch, size=(63, 9, 40), x=(0.0, 1.0), y=(0.0, 0.2), z=(0.0, 0.5), topology=(ocn.Periodic, ocn.Bounded, ocn.Bounded))
+        kw = dict(tracers=(), closure=ocn.AnisotropicMinimumDissipation(), coriolis=ocn.FPlane(f=0.4),
+                  boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-3)), "v": F(bottom=ocn.FluxBoundaryCondition(2e-3))})
+        dt = 2e-3
+    outs = []
+    for march in (1, 0):
+        ocn.set_option("epilogue_march", march)
+        try:
+            model = ocn.NonhydrostaticModel(grid=grid, **kw)
+            ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=5))
+            for _ in range(2):
+                ocn.time_step(model, dt)
+            out = {n: f.parent() for n, f in model.fields().items()}
+            out.update({"G" + n: model.tendency(n).parent() for n in model.fields()})
+            out["pNHS"] = model.pressures.pNHS.parent()
+            outs.append(out)
+            model.close()
+        finally:
+            ocn.set_option("epilogue_march", 1)
+    for n in outs[0]:
+        assert np.isfinite(outs[0][n]).all() and np.array_equal(outs[0][n], outs[1][n]), (case, n)
+    assert np.abs(outs[0]["Gu"]).max() > 0
