@@ -617,8 +617,9 @@ static int update_hydrostatic_pressure(const DGrid &g, int kind, const double *b
     const int j0 = g.ty == OCN_FLAT ? 1 : 0, j1 = g.ty == OCN_FLAT ? g.Ny : g.Ny + 1;
     const BuoyancyArgs B{kind, bT, S, grav, alpha, beta};
     const dim3 blk(64, 4, 1);
-    hipLaunchKernelGGL(hydrostatic_pressure_kernel, dim3((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4), blk, 0, g_stream, g, make_view(g, bT, LOC_C), B,
-                       pHY, i0, i1, j0, j1);
+    const dim3 grd((i1 - i0 + 64) / 64, (j1 - j0 + 4) / 4);
+    if (kind == 1) hipLaunchKernelGGL(hydrostatic_pressure_kernel<1>, grd, blk, 0, g_stream, g, make_view(g, bT, LOC_C), B, pHY, i0, i1, j0, j1);
+    else           hipLaunchKernelGGL(hydrostatic_pressure_kernel<2>, grd, blk, 0, g_stream, g, make_view(g, bT, LOC_C), B, pHY, i0, i1, j0, j1);
     KERNEL_CHECK();
     return OCN_OK;
 }
@@ -2591,8 +2592,15 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
                 for (int sd = 0; sd < 6; ++sd)
                     if ((a.any_flux && a.has_flux[f][sd]) || m->lin[f][sd].on) mask |= 1 << sd;
             if (mask) {
-                const int na = std::max(g.Nx, g.Ny), nb = std::max(g.Ny, g.Nz);
-                hipLaunchKernelGGL(epilogue_flux_shell_kernel, dim3((na + 63) / 64, (nb + 3) / 4, 6), dim3(64, 4), 0, g_stream, g, a, mask);
+                SideList sl;
+                sl.n = 0;
+                int na = 1, nb = 1;
+                for (int sd = 0; sd < 6; ++sd)
+                    if ((mask >> sd) & 1) {
+                        sl.side[sl.n++] = sd;
+                        na = std::max(na, sd < 2 ? g.Ny : g.Nx); nb = std::max(nb, sd < 4 ? g.Nz : g.Ny);
+                    }
+                hipLaunchKernelGGL(epilogue_flux_shell_kernel, dim3((na + 63) / 64, (nb + 3) / 4, sl.n), dim3(64, 4), 0, g_stream, g, a, mask, sl);
                 KERNEL_CHECK();
             }
             return OCN_OK;

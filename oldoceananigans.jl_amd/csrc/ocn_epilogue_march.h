@@ -205,9 +205,9 @@ __global__ void __launch_bounds__(512) tendency_epilogue_march_kernel(DGrid g, E
 // sides that carry a condition for some field) take their condition terms -- epilogue_flux_conditions on the tendency the march left, the
 // same call the one-pass kernel makes -- and, when the substep rides along, their next-stage value again from the completed tendency (same
 // expression, same operands as the fused form). A cell on several listed sides is handled by the first of them.
-__global__ void __launch_bounds__(256) epilogue_flux_shell_kernel(DGrid g, EpilogueArgs a, int mask) {
-    const int s = blockIdx.z;
-    if (!((mask >> s) & 1)) return;
+struct SideList { int n, side[6]; };
+__global__ void __launch_bounds__(256) epilogue_flux_shell_kernel(DGrid g, EpilogueArgs a, int mask, SideList sl) {
+    const int s = sl.side[blockIdx.z];                                   // the listed sides only
     const int d = s >> 1;
     const int N[3] = {g.Nx, g.Ny, g.Nz};
     const int ta = blockIdx.x * blockDim.x + threadIdx.x, tb = blockIdx.y * blockDim.y + threadIdx.y;

@@ -563,32 +563,39 @@ __device__ __forceinline__ double buoyancy_perturbation(const BuoyancyArgs &B, l
 #ifndef OCN_HYDRO_TB
 #define OCN_HYDRO_TB 32
 #endif
+// KIND (BuoyancyArgs::kind) is compile-time and the levels of a batch are clamped instead of guarded, so that the 2 * TB loads of a batch are
+// straight-line code: with the run-time `kind` test and the `k >= 1` guard around each load the compiler waited for every level's pair before
+// issuing the next (one memory round trip per level: 0.098 ms at 256 x 256 x 128, one wave per SIMD, nothing to hide it behind).
+template <int KIND>
 __global__ void __launch_bounds__(256) hydrostatic_pressure_kernel(DGrid g, FView c, BuoyancyArgs B, double *pHY, int i0, int i1, int j0, int j1) {
     const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = j0 + blockIdx.y * blockDim.y + threadIdx.y;
     if (i > i1 || j > j1) return;
     const int Nz = g.Nz;
-    long q = c.lin(i, j, Nz + 1);
-    double bk1 = buoyancy_perturbation(B, q);          // b[k+1]
+    const long q1 = c.lin(i, j, 1);                                     // level k at q1 + (k - 1) s2
+    auto b_of = [&](double t, double s) { return KIND == 1 ? t : B.grav * (B.alpha * t - B.beta * s); };
+    double bk1 = b_of(B.bT[q1 + (long)Nz * c.s2], KIND == 1 ? 0.0 : B.S[q1 + (long)Nz * c.s2]);          // b[Nz + 1]
     double p = 0.0;
     // the recurrence is serial in k but its loads are not: fetch TB levels, then sweep them (few columns => latency-bound otherwise:
-    // 66 K columns at 256 x 256 are one wave per SIMD; TB = 8 -> 32 measured in round 3)
+    // 66 K columns at 256 x 256 are one wave per SIMD)
     constexpr int TB = OCN_HYDRO_TB;
     for (int k0 = Nz; k0 >= 1; k0 -= TB) {
-        double bb[TB];
+        double tb[TB], sb[TB];
 #pragma unroll
-        for (int n = 0; n < TB; ++n)
-            if (k0 - n >= 1) bb[n] = buoyancy_perturbation(B, q - (long)(n + 1) * c.s2);
+        for (int n = 0; n < TB; ++n) {
+            const long q = q1 + (long)(max(k0 - n, 1) - 1) * c.s2;      // below the bottom: level 1 again (in bounds, unused)
+            tb[n] = B.bT[q];
+            sb[n] = KIND == 1 ? 0.0 : B.S[q];
+        }
 #pragma unroll
         for (int n = 0; n < TB; ++n) {
             const int k = k0 - n;
             if (k >= 1) {
-                q -= c.s2;
-                const double bk = bb[n];
+                const double bk = b_of(tb[n], sb[n]);
                 const double zb = 1 * (0.5 * (bk + bk1));
                 const double dzf = g.dzf[k + g.Hz];            // Δzᶠ(k+1)
                 p = k == Nz ? -zb * dzf : p - zb * dzf;
-                pHY[q] = p;
+                pHY[q1 + (long)(k - 1) * c.s2] = p;
                 bk1 = bk;
             }
         }
@@ -746,11 +753,8 @@ __device__ __forceinline__ double epilogue_flux_conditions(const DGrid &g, const
 // loads waited one after the other (0.94 -> see DESIGN.md for the measured time at 256 x 256 x 128).
 template <bool COR, bool BUOY, int CLO>
 __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, EpilogueArgs a) {
-    // Measured in round 3 at 256 x 256 x 128 with the configs[4] physics (0.66 ms, 2.3 GB of HBM-side traffic = 3.5 TB/s, VALU busy < 50 %), none
-    // faster: reciprocal spacings from tables instead of four FP64 divisions per thread (a third of the arithmetic: same time -- kept);
-    // non-temporal tendency / next-stage streams (same time); an XCD-aware block order, every XCD a contiguous range of (level, field) planes
-    // (FETCH_SIZE 1.03 -> 1.65 GB raw, 0.69 ms: with the plain order all eight XCDs work on the same levels and share them through the Infinity
-    // Cache); one thread per cell looping over the fields (1.09 ms).
+    // 0.66 ms at 256 x 256 x 128 with the configs[4] physics: ~200 loads per cell, bound on the address / L1 path (VALU busy < 50 %, 3.5 TB/s). Grids without
+    // a Flat direction run tendency_epilogue_march_kernel (ocn_epilogue_march.h, 0.48 ms) instead; this kernel stays for the others and as its reference.
     const int f = blockIdx.z % a.n;
     const Range6 r = a.r[f];
     const int i = r.i0 + blockIdx.x * blockDim.x + threadIdx.x;
