@@ -570,7 +570,10 @@ extern "C" int ocn_compute_Gc(ocn_grid_t grid, const double *u, const double *v,
 static int g_tendency_impl = 2;
 
 static bool fused_path(const DGrid &g, const int *range, int ntr, int impl) {
-    return (impl == 1 || impl == 2) && fused_tendency_supported(g, range) && ntr <= 3;
+    // the role kernel's limit is on the plane size, the all-fields kernel's on the array (4 GiB): a role launch falls back to the all-fields
+    // kernel, and that one to the per-field kernels
+    return (impl == 1 || impl == 2) && fused_tendency_supported(g, range) && ntr <= 3 &&
+           ((impl == 2 && role_tendency_supported(g)) || fused_tendency_size_supported(g));
 }
 
 static int compute_tendencies(const DGrid &g, const double *u, const double *v, const double *w, const double *const *tr,
@@ -580,7 +583,7 @@ static int compute_tendencies(const DGrid &g, const double *u, const double *v, 
     if (fused_path(g, range, ntr, impl)) {
         int rc = check_range(g, range, nullptr);
         if (rc) return rc;
-        if (impl == 2 && !role_tendency_supported(g)) impl = 1;          // parent arrays of 2 GiB and more: the all-fields kernel
+        if (impl == 2 && !role_tendency_supported(g)) impl = 1;          // planes too large for the role kernel's offsets: the all-fields kernel
         rc = impl == 2 ? launch_role_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub)
                        : launch_fused_tendency(g, g_stream, u, v, w, tr, ntr, Gu, Gv, Gw, Gc, range, sub);
         if (rc) return fail(rc, "fused tendency launch failed");

@@ -328,13 +328,16 @@ __global__ void __launch_bounds__(64 * (TY + 1), MINW) fused_tendency_kernel(DGr
     }
 }
 
+// grids the flux-sharing kernels (this file and ocn_tendency_roles.h) handle
 static inline bool fused_tendency_supported(const DGrid &g, const int *range) {
     (void)range;
-    const double bytes = 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy) * (g.Nz + 2.0 * g.Hz + 1.0);
     return g.tx != 1 && g.tx != 4 && g.tx != 5 && g.ty != 1 && g.ty != 4 && g.ty != 5 &&     // x, y Periodic or FullyConnected (no wall): identical x / y parent extents for all fields
            g.tx != 3 && g.ty != 3 && g.tz != 3 &&   // Flat directions take the per-field kernels
-           g.Bx == 3 && g.By == 3 && g.Bz == 3 &&   // so do directions with an adapted (reduced-order) scheme
-           bytes < 4294967296.0;         // 32-bit byte offsets inside a parent array
+           g.Bx == 3 && g.By == 3 && g.Bz == 3;     // so do directions with an adapted (reduced-order) scheme
+}
+// the all-fields kernel of this file addresses a parent array with 32-bit byte offsets
+static inline bool fused_tendency_size_supported(const DGrid &g) {
+    return 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy) * (g.Nz + 2.0 * g.Hz + 1.0) < 4294967296.0;
 }
 
 // tuned on MI355X at 256^3 (tools/tune_fused.py): 64 x 7 tiles, register z-windows, 2 waves/SIMD (no spills);

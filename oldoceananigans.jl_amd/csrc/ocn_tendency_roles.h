@@ -258,14 +258,18 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     o.c = 8u * (unsigned)(a.off + i - 3 + (long)a.s1 * j);
     e.c = 8u * (unsigned)(a.off + ie - 3 + (long)a.s1 * je);
 
+    // The descriptors of a workgroup start at the lowest plane it can touch (level kc0 - 3), not at the array: every offset below is
+    // relative to that plane and stays under 2^31 for parent arrays of any size (role_tendency_supported: (kchunk + 8) planes).
+    const long pb = max(0L, (long)(kc0 - 1 + Hz) - 3);
+    const long sh = pb * (long)a.s2;
     PlaneCtx p;
-    p.u = make_rsrc(a.U[0]); p.v = make_rsrc(a.U[1]); p.w = make_rsrc(a.U[2]);
-    p.q = ROLE == ROLE_U ? p.u : (ROLE == ROLE_V ? p.v : (ROLE == ROLE_W ? p.w : make_rsrc(a.U[fidx])));
+    p.u = make_rsrc(a.U[0] + sh); p.v = make_rsrc(a.U[1] + sh); p.w = make_rsrc(a.U[2] + sh);
+    p.q = ROLE == ROLE_U ? p.u : (ROLE == ROLE_V ? p.v : (ROLE == ROLE_W ? p.w : make_rsrc(a.U[fidx] + sh)));
     p.s2 = s2;
-    p.so = s2 * (unsigned)(kc0 - 1 + Hz);             // plane of level kc0
+    p.so = s2 * (unsigned)((long)(kc0 - 1 + Hz) - pb);   // plane of level kc0
     // the streams touched once per cell: tendency out, previous tendency in (a.Gm is the tendency array itself when the substep has
     // no zeta: loaded and not used), next-stage field out
-    const Rsrc rG = make_rsrc(a.G[fidx]), rUn = make_rsrc(SUB ? a.Un[fidx] : a.G[fidx]), rGm = make_rsrc(SUB ? a.Gm[fidx] : a.G[fidx]);
+    const Rsrc rG = make_rsrc(a.G[fidx] + sh), rUn = make_rsrc((SUB ? a.Un[fidx] : a.G[fidx]) + sh), rGm = make_rsrc((SUB ? a.Gm[fidx] : a.G[fidx]) + sh);
     const unsigned cell_off = cell_r ? 0u : ROLE_OOB;
 
     double fz_prev = 0, qn = 0, gmn = 0;
@@ -442,16 +446,17 @@ __global__ void __launch_bounds__(64 * (TY + 1), OCN_ROLE_WAVES) role_tendency_k
     else role_march<ROLE_C, TY, SUB, BZ, ARITH>(g, a, (int)role, i0, j0, kc0, kc1, FX, FY);
 }
 
-// The role kernel addresses a parent array with a 31-bit byte offset (bit 31 is the out-of-range flag of its buffer descriptor, whose
-// num_records is 2 GiB): plane offset + up to four planes of look-ahead + the row / column offsets must stay below 2^31. Larger arrays
-// (e.g. a single-GPU 1024 x 1024 x 256 grid: 2.2 GB per field) take the all-fields kernel, whose offsets are full 32-bit.
+// The role kernel addresses memory with a 31-bit byte offset (bit 31 is the out-of-range flag of its buffer descriptors, whose num_records
+// is 2 GiB) relative to the lowest plane of the workgroup's chunk: (kchunk + 3 below + 4 of look-ahead + 1) planes + the row / column offsets
+// must stay below 2^31 -- a limit on the PLANE size (29 MB at the largest chunk: 1900 x 1900 points), not on the array (a single-GPU
+// 1024 x 1024 x 256 grid, 2.2 GB per field, took the slower all-fields kernel before round 3's per-workgroup descriptor base).
+static int g_role_kchunk = 0;      // 0: automatic
 static inline bool role_tendency_supported(const DGrid &g) {
     const double plane = 8.0 * (g.Nx + 2.0 * g.Hx) * (g.Ny + 2.0 * g.Hy);
-    return plane * (g.Nz + 2.0 * g.Hz + 1.0 + 4.0) < 2147483648.0;
+    return plane * ((g_role_kchunk > 0 ? g_role_kchunk : 64) + 8.0) < 2147483648.0;
 }
 
 static int g_arithmetic = 0;       // 0: the reference's operation sequence (bit-identical to the oracle); 1: contracted WENO flux (ocn_device.h)
-static int g_role_kchunk = 0;      // 0: automatic
 static int g_role_ldspad = 0;      // experiments: extra dynamic LDS per workgroup (bytes) to limit the workgroups per CU
 
 // Work per launch in plane-iterations: blocks x (kchunk + 1) spread over the resident workgroups (3 per CU at <= 80 VGPRs); smaller chunks balance the

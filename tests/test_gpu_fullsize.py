@@ -478,3 +478,35 @@ def test_marching_epilogue_equals_the_one_thread_per_value_epilogue(ocn, arch, c
     for n in outs[0]:
         assert np.isfinite(outs[0][n]).all() and np.array_equal(outs[0][n], outs[1][n]), (case, n)
     assert np.abs(outs[0]["Gu"]).max() > 0
+
+
+@pytest.mark.parametrize("size", [(1024, 1024, 256), (1024, 1024, 512)])
+def test_role_kernel_on_parent_arrays_beyond_2_and_4_gib(ocn, arch, size):
+    """288 GB of HBM hold single-GPU grids whose fields exceed the 31-bit byte offsets of the role kernel's buffer descriptors (1024 x 1024 x 256:
+    2.2 GB per field) and the 32-bit ones of the all-fields kernel (1024 x 1024 x 512: 4.4 GB). Since round 3 a workgroup's descriptors start at
+    the lowest plane of its own chunk, so the limit is on the plane, not on the array: the role kernel (default) against the per-field kernels
+    (the reference's launch structure, FView's 64-bit indexing), whole parent arrays bit for bit. Fields are separable products set through
+    set_parent (no projection: this is about addressing)."""
+    grid = ocn.RectilinearGrid(arch, size=size, extent=(1, 1, 1))
+    model = ocn.NonhydrostaticModel(grid=grid, advection=ocn.WENO(), tracers=("T", "S"))
+    assert model.get_option("tendency_impl") == 2
+    two_pi = 2 * np.pi
+    for n, (name, f) in enumerate(model.fields().items()):
+        P = f.shape
+        ax = [np.arange(P[d]) / size[d] for d in range(3)]
+        a = (np.sin(two_pi * ax[0] + 0.3 * n)[:, None, None] * np.cos(two_pi * ax[1] + 0.2 * n)[None, :, None]) * (1.0 + 0.25 * np.cos(two_pi * ax[2] + n))[None, None, :]
+        f.set_parent(a + (0.5 if name in ("T", "S") else 0.0))
+        del a
+    want = None
+    for impl in (2, 0):
+        model.set_option("tendency_impl", impl)
+        ocn.update_state(model, True)
+        got = [model.tendency(n).parent() for n in model.fields()]
+        if want is None:
+            want = got
+            continue
+        for a, b, n in zip(want, got, model.fields()):
+            assert np.array_equal(a, b), (size, n)
+            assert np.isfinite(a).all() and np.abs(a[3:-3, 3:-3, -6]).max() > 0 and np.abs(a[3:-3, 3:-3, 3]).max() > 0
+    model.set_option("tendency_impl", 2)
+    model.close()
