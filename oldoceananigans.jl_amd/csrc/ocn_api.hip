@@ -983,6 +983,7 @@ static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
+static int g_dist_fuse_source = 1;     // x-fastest solve: source term and paired z transform in one kernel (no dense real right-hand side)
 static int g_dist_xfast = 1;           // substructured x solve in the fields' own x-fastest layout (paired z transform in LDS, one-wave-per-line Thomas scans) when sizes allow
 static int g_dist_pencil_transposes = 1;   // pencil partitions of triply Periodic grids: the reference's transposing solver (0: gathered solve)
 static int g_dist_fused_step = 1;      // partitioned model, (connected, Periodic, Periodic) slabs: the pressure step without fills / copies between its stages (ocn_dist.h)
@@ -1681,6 +1682,7 @@ struct ocn_dist_poisson_s {
     // x-fastest variant of the substructured solve (ocn_kernels.h, "xfast"): dense real array rx (Nx, Ny, Nz), spectrum xs (Nx, Ny, Nz/2 + 1),
     // Thomas factors rden_x in the spectrum's layout, first / last entry of s = T⁻¹e₀ per mode
     bool xfast = false;
+    bool src_in_spectrum = false;   // the fused source-term + z transform already filled xs: forward_local skips its z transform
     int xE = 0, logn_z = 0;
     double *rx = nullptr, *rden_x = nullptr, *s_first = nullptr, *s_last = nullptr;
     double2 *xs = nullptr, *ztw = nullptr;
@@ -2071,7 +2073,8 @@ extern "C" int ocn_dist_poisson_forward_local(ocn_dist_poisson_t s) {
     const double a = 1.0 / (s->grid->d.dx * s->grid->d.dx);
     if (s->xfast) {
         const long C = (long)s->Nxl * s->Ny / 2, P = (long)s->Nxl * s->Ny;
-        launch_paired_zline(true, (const double2 *)s->rx, s->xs, s->ztw, C, s->Nz, s->logn_z, 1.0);
+        if (!s->src_in_spectrum) launch_paired_zline(true, (const double2 *)s->rx, s->xs, s->ztw, C, s->Nz, s->logn_z, 1.0);
+        s->src_in_spectrum = false;
         launch_strided_line_fft(s->xs, s->ytw, (long)s->Nxl, (long)s->Nxl, (unsigned)s->Nzh, s->Ny, s->logn_y, 0, 1.0, P);
         launch_xline_thomas<false>(s->xE, s->xs, s->rden_x, s->M, s->Nxl, a, s->payload, nullptr, 1.0);      // reads only: the payload
         KERNEL_CHECK();
@@ -2192,6 +2195,18 @@ extern "C" int ocn_dist_poisson_source_term(ocn_dist_poisson_t s, const double *
 // (Ny, Nz) column received by the one-column exchange
 static int dist_poisson_source_term_wrapped(ocn_dist_poisson_t s, const double *u, const double *v, const double *w, const double *u_east) {
     const DGrid &g = s->grid->d;
+    if (s->xfast && g_dist_fuse_source) {
+        const long C = (long)s->Nxl * s->Ny / 2;
+        const int zl = line_zl(s->Nz);
+        const dim3 grd((unsigned)((C + zl - 1) / zl));
+        const size_t lds = (size_t)s->Nz * zl * sizeof(double2);
+        const FView fu = make_view(g, u, LOC_U), fv = make_view(g, v, LOC_V), fw = make_view(g, w, LOC_W);
+        if (zl == 4) hipLaunchKernelGGL(source_paired_zline_r2c_kernel<4>, grd, dim3(256), lds, g_stream, g, fu, fv, fw, u_east, s->xs, s->ztw, C, s->Nz, s->logn_z);
+        else         hipLaunchKernelGGL(source_paired_zline_r2c_kernel<8>, grd, dim3(256), lds, g_stream, g, fu, fv, fw, u_east, s->xs, s->ztw, C, s->Nz, s->logn_z);
+        KERNEL_CHECK();
+        s->src_in_spectrum = true;
+        return OCN_OK;
+    }
     if (s->xfast) {
         hipLaunchKernelGGL(source_term_dense_wrapped_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, u, LOC_U), make_view(g, v, LOC_V),
                            make_view(g, w, LOC_W), u_east, s->rx);
@@ -2490,6 +2505,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_yline")) { g_dist_yline = value; return OCN_OK; }
     if (!strcmp(key, "dist_fused_step")) { g_dist_fused_step = value; return OCN_OK; }
     if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
+    if (!strcmp(key, "dist_fuse_source")) { g_dist_fuse_source = value; return OCN_OK; }
     if (!strcmp(key, "dist_pencil_transposes")) { g_dist_pencil_transposes = value; return OCN_OK; }
     if (!strcmp(key, "amd_march")) { g_amd_march = value; return OCN_OK; }
     if (!strcmp(key, "epilogue_march")) { g_epilogue_march = value; return OCN_OK; }

@@ -134,6 +134,34 @@ def test_library_x_solve_layouts_agree(ocn, arch, size, R):
             _compare(out, ref, r, nxl, size)
 
 
+def test_fused_source_term_and_z_transform_is_bit_identical(ocn, arch):
+    """x-fastest substructured solve: the source term written straight into the LDS line buffer of the paired z transform
+    (source_paired_zline_r2c_kernel) against the two separate kernels (option dist_fuse_source = 0): same expressions on the same operands,
+    so every field and the pressure after three steps bit for bit (one rank, self-loop over RCCL; 256 and 512-point z lines: both line widths)"""
+    from oldoceananigans_jl_amd import _lib, distributed as dist
+    _own_stream()
+    for size in ((64, 32, 256), (32, 16, 512)):
+        outs = []
+        for fuse in (1, 0):
+            ocn.set_option("dist_fuse_source", fuse)
+            try:
+                uid = C.create_string_buffer(128)
+                _lib.check(_lib.lib().ocn_dist_unique_id(uid))
+                ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)
+                grid, model = _library_model(ocn, dist, ctx, size, "periodic")
+                assert model.get_option("dist_poisson_layout") == 4 and model.get_option("fused_step") == 1
+                for _ in range(3):
+                    ocn.time_step(model, 1e-3)
+                outs.append({n: f.parent() for n, f in model.fields().items()} | {"p": model.pressures.pNHS.parent()})
+                assert ocn.max_abs_divergence(model) < 5e-8
+                model.close()
+                ctx.close()
+            finally:
+                ocn.set_option("dist_fuse_source", 1)
+        for n in outs[0]:
+            assert np.array_equal(outs[0][n], outs[1][n]), (size, n)
+
+
 def test_library_collectives_over_rccl_world_1(ocn, arch):
     """the raw collectives of the boundary with a one-rank RCCL communicator: an exchange swaps the sides (what leaves through the
     west side arrives in the east halo), all-to-all / all-gather are copies, the reduction returns its argument"""
