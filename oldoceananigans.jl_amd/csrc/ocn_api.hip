@@ -939,7 +939,8 @@ extern "C" int ocn_divide_interior(ocn_grid_t grid, double *p, double divisor) {
 #ifndef OCN_LINE_MAX
 #define OCN_LINE_MAX 1024
 #endif
-static inline int line_zl(int n) { return n >= 512 ? 4 : 8; }
+static int g_line_zl512 = 4;            // lines per workgroup of the LDS line-FFT kernels at 512-point lines (8: 64 KB of LDS per workgroup)
+static inline int line_zl(int n) { return n >= 1024 ? 4 : (n >= 512 ? g_line_zl512 : 8); }
 static inline void launch_strided_line_fft(double2 *data, const double2 *tw, long C, long ncols, unsigned batches, int N, int logn, int inverse,
                                            double scale, long plane_stride = 0) {
     const int zl = line_zl(N);
@@ -960,9 +961,20 @@ static inline void launch_paired_zline(bool forward, const double2 *in, double2 
         else         hipLaunchKernelGGL(paired_zline_c2r_kernel<8>, grd, dim3(256), lds, g_stream, in, out, tw, C, N, logn, scale);
     }
 }
+static int g_dist_xline_group = 1;     // x-fastest solve on short local lines (32 / 64 / 128 points): several lines per wave instead of one
 template <bool SOLVE>
 static inline void launch_xline_thomas(int E, double2 *S, const double *rden, long M, int N, double a, double2 *payload, const double2 *iface, double scale) {
-    const dim3 grd((unsigned)((M + 3) / 4)), blk(256);
+    const dim3 blk(256);
+    // short lines (thin slabs): 4 elements per lane and N / 4 lanes per line -- 2, 4 or 8 lines per wave
+    if (g_dist_xline_group && (N == 32 || N == 64 || N == 128)) {
+        const int lpw = 256 / N;
+        const dim3 grp((unsigned)((M + 4 * lpw - 1) / (4 * lpw)));
+        if (N == 32)       hipLaunchKernelGGL((xline_thomas_kernel<4, SOLVE, 8>), grp, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale);
+        else if (N == 64)  hipLaunchKernelGGL((xline_thomas_kernel<4, SOLVE, 16>), grp, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale);
+        else               hipLaunchKernelGGL((xline_thomas_kernel<4, SOLVE, 32>), grp, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale);
+        return;
+    }
+    const dim3 grd((unsigned)((M + 3) / 4));
     switch (E) {
         case 1: hipLaunchKernelGGL((xline_thomas_kernel<1, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
         case 2: hipLaunchKernelGGL((xline_thomas_kernel<2, SOLVE>), grd, blk, 0, g_stream, S, rden, M, N, a, payload, iface, scale); break;
@@ -2506,6 +2518,8 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "dist_fused_step")) { g_dist_fused_step = value; return OCN_OK; }
     if (!strcmp(key, "dist_xfast")) { g_dist_xfast = value; return OCN_OK; }
     if (!strcmp(key, "dist_fuse_source")) { g_dist_fuse_source = value; return OCN_OK; }
+    if (!strcmp(key, "line_zl512")) { if (value != 4 && value != 8) return fail(OCN_EINVAL, "line_zl512 is 4 or 8"); g_line_zl512 = value; return OCN_OK; }
+    if (!strcmp(key, "dist_xline_group")) { g_dist_xline_group = value; return OCN_OK; }
     if (!strcmp(key, "dist_pencil_transposes")) { g_dist_pencil_transposes = value; return OCN_OK; }
     if (!strcmp(key, "amd_march")) { g_amd_march = value; return OCN_OK; }
     if (!strcmp(key, "epilogue_march")) { g_epilogue_march = value; return OCN_OK; }

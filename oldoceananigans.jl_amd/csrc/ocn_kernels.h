@@ -2251,15 +2251,22 @@ __global__ void __launch_bounds__(256) sub_setup_xfast_kernel(long M, int n0, in
     }
 }
 
-// One wave per x line (mode m): the Dirichlet solve y = T^-1 r by Thomas, both recurrences as shuffle scans of affine maps (see the
-// section comment). SOLVE = false: reads only, payload[m] = y[0], payload[M + m] = y[N-1], payload[2M] = sum_i y[i] of mode 0.
+// W lanes per x line (mode m; W = 64: one wave per line, W = 8 / 16 / 32: the 8 / 4 / 2 lines of a wave for the short lines of thin slabs --
+// with one element per lane a 64-point line spent its time in the six scan steps: 0.115 ms per pass on a 64 x 512 x 512 slab): the Dirichlet
+// solve y = T^-1 r by Thomas, both recurrences as shuffle scans of affine maps over the W lanes (see the section comment).
+// SOLVE = false: reads only, payload[m] = y[0], payload[M + m] = y[N-1], payload[2M] = sum_i y[i] of mode 0.
 // SOLVE = true: r_0 -= a gL, r_{N-1} -= a gR (iface[m], iface[M + m]) first, writes (y - mean[mode 0]) * scale in place.
-template <int E, bool SOLVE>
+template <int E, bool SOLVE, int W = 64>
 __global__ void __launch_bounds__(256) xline_thomas_kernel(double2 *S, const double *__restrict__ rden, long M, int N, double a, double2 *payload,
                                                            const double2 *__restrict__ iface, double scale) {
-    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;                                // whole waves leave together
-    const int lane = threadIdx.x & 63, i0 = lane * E;
+    constexpr int LPW = 64 / W;                        // lines per wave
+    const int lane = threadIdx.x & 63, sl = lane & (W - 1);
+    const long mw = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * LPW;
+    if (mw >= M) return;                               // whole waves leave together
+    const long mr = mw + lane / W;
+    const bool live = mr < M;                          // lines beyond the last one: lanes repeat the last line, write nothing
+    const long m = live ? mr : M - 1;
+    const int i0 = sl * E;
     double2 *line = S + (long)N * m;
     const double *dl = rden + (long)N * m;
     double2 r[E], f[E];
@@ -2287,12 +2294,12 @@ __global__ void __launch_bounds__(256) xline_thomas_kernel(double2 *S, const dou
         A = Ae * A;
     }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double Ap = __shfl_up(A, off, 64), Bpx = __shfl_up(Bx, off, 64), Bpy = __shfl_up(By, off, 64);
-        if (lane >= off) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
+    for (int off = 1; off < W; off <<= 1) {
+        const double Ap = __shfl_up(A, off, W), Bpx = __shfl_up(Bx, off, W), Bpy = __shfl_up(By, off, W);
+        if (sl >= off) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
     }
-    double2 prev = make_double2(__shfl_up(Bx, 1, 64), __shfl_up(By, 1, 64));
-    if (lane == 0) prev = make_double2(0.0, 0.0);
+    double2 prev = make_double2(__shfl_up(Bx, 1, W), __shfl_up(By, 1, W));
+    if (sl == 0) prev = make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         f[e] = make_double2((r[e].x - a * prev.x) * d[e], (r[e].y - a * prev.y) * d[e]);
@@ -2307,12 +2314,12 @@ __global__ void __launch_bounds__(256) xline_thomas_kernel(double2 *S, const dou
         A = Ae * A;
     }
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double Ap = __shfl_down(A, off, 64), Bpx = __shfl_down(Bx, off, 64), Bpy = __shfl_down(By, off, 64);
-        if (lane + off < 64) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
+    for (int off = 1; off < W; off <<= 1) {
+        const double Ap = __shfl_down(A, off, W), Bpx = __shfl_down(Bx, off, W), Bpy = __shfl_down(By, off, W);
+        if (sl + off < W) { Bx = A * Bpx + Bx; By = A * Bpy + By; A = A * Ap; }
     }
-    prev = make_double2(__shfl_down(Bx, 1, 64), __shfl_down(By, 1, 64));
-    if (lane == 63) prev = make_double2(0.0, 0.0);
+    prev = make_double2(__shfl_down(Bx, 1, W), __shfl_down(By, 1, W));
+    if (sl == W - 1) prev = make_double2(0.0, 0.0);
 #pragma unroll
     for (int e = E - 1; e >= 0; --e) {
         const double c = a * d[e];
@@ -2323,18 +2330,18 @@ __global__ void __launch_bounds__(256) xline_thomas_kernel(double2 *S, const dou
         const double2 mu = m == 0 ? iface[2 * M] : make_double2(0.0, 0.0);
 #pragma unroll
         for (int e = 0; e < E; ++e)
-            if (i0 + e < N) line[i0 + e] = make_double2((f[e].x - mu.x) * scale, (f[e].y - mu.y) * scale);
+            if (live && i0 + e < N) line[i0 + e] = make_double2((f[e].x - mu.x) * scale, (f[e].y - mu.y) * scale);
     } else {
 #pragma unroll
         for (int e = 0; e < E; ++e) {
-            if (i0 + e == 0) payload[m] = f[e];
-            if (i0 + e == N - 1) payload[M + m] = f[e];
+            if (live && i0 + e == 0) payload[m] = f[e];
+            if (live && i0 + e == N - 1) payload[M + m] = f[e];
         }
-        if (m == 0) {
+        if (mw == 0) {                                 // the wave that holds mode 0 (its first W lanes): the sum over that line
             double sx = 0.0, sy = 0.0;
 #pragma unroll
             for (int e = 0; e < E; ++e) { sx += f[e].x; sy += f[e].y; }        // entries beyond the line are zero
-            for (int off = 32; off > 0; off >>= 1) { sx += __shfl_down(sx, off, 64); sy += __shfl_down(sy, off, 64); }
+            for (int off = W / 2; off > 0; off >>= 1) { sx += __shfl_down(sx, off, W); sy += __shfl_down(sy, off, W); }
             if (lane == 0) payload[2 * M] = make_double2(sx, sy);
         }
     }

@@ -99,10 +99,10 @@ def test_library_self_loop_over_rccl_equals_single_gpu(ocn, arch, size, zkind, s
         assert np.array_equal(out[name][:3, 3:-3, 3:-3], out[name][-6:-3, 3:-3, 3:-3]), name
 
 
-@pytest.mark.parametrize("size,R", [((32, 16, 8), 1), ((64, 16, 16), 2), ((384, 8, 8), 2), ((1536, 8, 8), 2)])
+@pytest.mark.parametrize("size,R", [((32, 16, 8), 1), ((64, 16, 16), 2), ((384, 8, 8), 2), ((1536, 8, 8), 2), ((64, 16, 8), 1), ((256, 8, 16), 2)])
 def test_library_x_solve_layouts_agree(ocn, arch, size, R):
-    """the x-fastest substructured solve (paired z transform in LDS + one-wave-per-line Thomas scans, with 1, 4, 8 and 16 elements of a
-    line per lane: local Nx = 32, 32, 192, 768) against the z-fastest one (option dist_xfast = 0) and, with and without the pressure step
+    """the x-fastest substructured solve (paired z transform in LDS + Thomas scans over the lanes of a wave: one line per wave with 4 and 16
+    elements per lane -- local Nx = 192, 768 -- or, for short lines, 8 / 4 / 2 lines per wave -- local Nx = 32, 64, 128) against the z-fastest one (option dist_xfast = 0) and, with and without the pressure step
     that skips the fills / copies between its stages (fused_step), against the single-GPU model: three RK3 steps, 1e-12"""
     from oldoceananigans_jl_amd import _lib, distributed as dist
     _own_stream()

@@ -9,6 +9,8 @@ from helpers import smooth_state, tanh_faces
 shape = tuple(int(v) for v in sys.argv[1:4]); bounded = len(sys.argv) > 4 and sys.argv[4] == "bounded"
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 6
 arch = ocn.GPU(0)
+for kv in filter(None, os.environ.get("OCN_SET_OPTIONS", "").split(",")):      # library options for A/B runs: OCN_SET_OPTIONS=key=value,...
+    ocn.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 uid = C.create_string_buffer(128)
 _lib.check(_lib.lib().ocn_dist_unique_id(uid))
 ctx = dist.Distributed.rccl(arch, uid, 1, 0, self_loop=True)

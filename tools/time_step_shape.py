@@ -8,6 +8,8 @@ from helpers import smooth_state, tanh_faces
 shape = tuple(int(v) for v in sys.argv[1:4]); bounded = len(sys.argv) > 4 and sys.argv[4] == "bounded"
 steps = int(sys.argv[5]) if len(sys.argv) > 5 else 6
 arch = ocn.GPU(0)
+for kv in filter(None, os.environ.get("OCN_SET_OPTIONS", "").split(",")):      # library options for A/B runs: OCN_SET_OPTIONS=key=value,...
+    ocn.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 if bounded:
     grid = ocn.RectilinearGrid(arch, size=shape, x=(0.0, 1.0), y=(0.0, 1.0), z=tanh_faces(shape[2]), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
 else:
