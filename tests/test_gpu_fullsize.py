@@ -510,3 +510,66 @@ def test_role_kernel_on_parent_arrays_beyond_2_and_4_gib(ocn, arch, size):
             assert np.isfinite(a).all() and np.abs(a[3:-3, 3:-3, -6]).max() > 0 and np.abs(a[3:-3, 3:-3, 3]).max() > 0
     model.set_option("tendency_impl", 2)
     model.close()
+
+
+def test_marching_kernels_on_seeded_random_small_configurations(ocn, arch):
+    """forty seeded random small models -- sizes from 4 to 70 that are no multiple of a block's 62 columns / 4 rows / 16 levels, every mix of
+    Periodic / Bounded directions, 0 to 2 tracers, ScalarDiffusivity or AnisotropicMinimumDissipation, with / without Coriolis and buoyancy,
+    Flux conditions on random walls -- stepped twice with the z-marching epilogue and eddy-diffusivity kernels and with the one-thread-per-value
+    kernels (options epilogue_march / amd_march = 0): fields, tendencies and pressure bit for bit"""
+    from helpers import tanh_faces
+    rng = np.random.default_rng(20251005)
+    F = ocn.FieldBoundaryConditions
+    ran = 0
+    for case in range(40):
+        size = tuple(int(rng.integers(4, 71 if d == 0 else 24)) for d in range(3))
+        topo = tuple(ocn.Bounded if rng.random() < 0.5 else ocn.Periodic for _ in range(3))
+        z = tanh_faces(size[2]) if (topo[2] is ocn.Bounded and rng.random() < 0.5) else (0.0, 0.7)
+        ntr = int(rng.integers(0, 3))
+        tracers = ("T", "S")[:ntr]
+        amd = rng.random() < 0.5
+        kw = dict(tracers=tracers, closure=ocn.AnisotropicMinimumDissipation() if amd else ocn.ScalarDiffusivity(ν=2e-3, κ=1e-3))
+        if rng.random() < 0.5:
+            kw["coriolis"] = ocn.FPlane(f=0.4)
+        if ntr == 2 and rng.random() < 0.6:
+            kw["buoyancy"] = ocn.SeawaterBuoyancy()
+        elif ntr >= 1 and rng.random() < 0.3:
+            kw["tracers"] = ("b",) + tracers[1:]
+            kw["buoyancy"] = ocn.BuoyancyTracer()
+        bcs = {}
+        sides = {0: ("west", "east"), 1: ("south", "north"), 2: ("bottom", "top")}
+        normal = {"u": 0, "v": 1, "w": 2}
+        for name in ("u", "v", "w") + tuple(kw["tracers"]):
+            conds = {}
+            for d in range(3):
+                if topo[d] is ocn.Bounded and normal.get(name) != d:
+                    for sd in sides[d]:
+                        if rng.random() < 0.35:
+                            conds[sd] = ocn.FluxBoundaryCondition(float(rng.normal()) * 1e-3)
+            if conds:
+                bcs[name] = F(**conds)
+        if bcs:
+            kw["boundary_conditions"] = bcs
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 0.8), z=z, topology=topo)
+        outs = []
+        for march in (1, 0):
+            ocn.set_option("epilogue_march", march)
+            ocn.set_option("amd_march", march)
+            try:
+                model = ocn.NonhydrostaticModel(grid=grid, **kw)
+                ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, seed=100 + case))
+                for _ in range(2):
+                    ocn.time_step(model, 1e-3)
+                out = {n: f.parent() for n, f in model.fields().items()}
+                out.update({"G" + n: model.tendency(n).parent() for n in model.fields()})
+                out["pNHS"] = model.pressures.pNHS.parent()
+                outs.append(out)
+                model.close()
+            finally:
+                ocn.set_option("epilogue_march", 1)
+                ocn.set_option("amd_march", 1)
+        for n in outs[0]:
+            assert np.array_equal(outs[0][n], outs[1][n], equal_nan=True), (case, size, [t.__name__ for t in topo], kw.keys(), n)
+        assert np.isfinite(outs[0]["u"]).all(), (case, size)
+        ran += 1
+    assert ran == 40
