@@ -347,7 +347,14 @@ int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, 
  *     inverse z FFT as one LDS pass), "split_solve" (model time-step: 1-D x plans on 128-B-padded rows + LDS column-FFT kernel for y +
  *     pressure correction and p/Δt from the dense solution);
  *   x-slab solve: "dist_substructured" (1: gathered interface solve, 0: the reference's two transposes), "dist_zfirst" (z-fastest
- *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform);
+ *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform), "dist_xfast" (the substructured solve in the fields'
+ *     own x-fastest layout), "dist_fuse_source" (source term written straight into the z transform's line buffer), "dist_xline_group"
+ *     (several short x lines per wave in the Thomas scans), "dist_fused_step" (pressure step without fills / copies between its stages),
+ *     "dist_pencil_transposes" (pencil partitions: the reference's transposing solver; 0: gathered solve), "line_zl512" (4 | 8 lines per
+ *     workgroup of the LDS line transforms at 512-point lines);
+ *   physics passes: "amd_march" / "epilogue_march" (z-marching eddy-diffusivity kernel / tendency epilogue that evaluate every point
+ *     operand / face flux once; 0: one thread per value, everything recomputed -- same bits), "epilogue_kchunk" (levels per workgroup,
+ *     0 = automatic), "epilogue_rows" (rows per workgroup, 1 .. 8);
  *   fused tendency kernel: "fused_ty" (tile rows 3 | 7), "fused_kchunk" (levels per workgroup, 0 = automatic), "fused_minw",
  *     "fused_zwin" (register z-windows), "fused_xcd" (XCD-aware tile order; measured: no effect);
  *   halo fills: "fused_halo" (one launch per periodic fill);
