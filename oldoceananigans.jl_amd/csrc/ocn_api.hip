@@ -2531,6 +2531,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
 }
 
 static int dist_model_set_option(ocn_model_s *m, const char *key, int value);
+static void dist_abandon_exchange(ocn_model_s *m);
 static int dist_model_get_option(const ocn_model_s *m, const char *key, int *value);
 extern "C" int ocn_model_set_option(ocn_model_t m, const char *key, int value) {
     if (!m || !key) return fail(OCN_EINVAL, "NULL argument");
@@ -3047,7 +3048,14 @@ extern "C" int ocn_model_time_step(ocn_model_t m, double dt) {
     if (!m) return fail(OCN_EINVAL, "NULL argument");
     // graphs: not on the first step (it also evaluates the initial tendencies), not while tendency launches are being timed, and only
     // on a stream the library owns (a borrowed stream may be the legacy default stream, which cannot be captured)
-    if (!m->use_graph || m->profile || m->iteration == 0 || !g_stream_owned || m->dm) return rk3_time_step(m, dt);
+    if (m->dm) {
+        // a step that fails after make_pressure_correction! has started the halo exchange of the coming update_state! must not leave that
+        // exchange "in flight": the next call would report it instead of the original error
+        const int rc = rk3_time_step(m, dt);
+        if (rc) dist_abandon_exchange(m);
+        return rc;
+    }
+    if (!m->use_graph || m->profile || m->iteration == 0 || !g_stream_owned) return rk3_time_step(m, dt);
     if (m->graph_exec && m->graph_dt == dt && m->graph_epoch == m->epoch * 1000003ull + g_epoch) {
         hipError_t e = hipGraphLaunch(m->graph_exec, g_stream);
         if (e != hipSuccess) return fail((int)e, "hipGraphLaunch: %s", hipGetErrorString(e));

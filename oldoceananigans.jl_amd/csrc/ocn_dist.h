@@ -552,6 +552,19 @@ static DenseSolution dist_dense_solution(const ocn_dist_poisson_s *s, const DGri
     return {(const double *)s->zfield, (long)s->Nxe * s->Nz, (long)s->Nxe};          // transposing solvers: paired-column layout (x, z, y)
 }
 
+// after a failed step: forget a started exchange (the error already on record stays the one reported)
+static void dist_abandon_exchange(ocn_model_s *m) {
+    DistModel *dm = m->dm;
+    if (!dm) return;
+    dm->halos_in_flight = false;
+    if (dm->dist && dm->dist->in_flight) {
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof g_err);
+        (void)ocn_dist_exchange_wait(dm->dist);
+        memcpy(g_err, keep, sizeof g_err);
+    }
+}
+
 static int dist_compute_pressure_correction_fused(ocn_model_s *m) {
     // fill_halo_regions!(velocities) reduces to ONE column of u going west (the divergence at i = Nx reads u[Nx+1]; y / z neighbours are
     // read at wrapped interior indices) -- plus, on a Bounded z, the local fill that sets the wall faces of w --; solve;
