@@ -16,6 +16,9 @@
 // The Flux conditions are NOT applied here (their run-time indexed description of sides and dependencies, inlined once per field, made the
 // compiler move the whole argument block to scratch memory): epilogue_flux_shell_kernel below re-does the boundary cells that carry one.
 //
+// An XCD-contiguous tile order (every XCD a contiguous range of (row block, chunk) tiles, so that the rows shared with the y neighbours sit in one
+// L2) was measured: no difference (6.02 / 6.02 ms per step) -- the re-reads are served by the Infinity Cache.
+//
 // Iteration L loads level L, forms the fluxes that live on level L (own level: vf11, vf22, vf12, the tracers' x / y fluxes, Coriolis and
 // pHY′ terms; face level L: vf13, vf23, the tracers' z flux; vf33 of level L - 1) and then completes cell L - 1.
 #pragma once
