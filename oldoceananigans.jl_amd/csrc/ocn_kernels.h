@@ -439,7 +439,10 @@ __device__ __forceinline__ void amd_point(double a, double b, double out[AM_N]) 
 }
 
 template <int NTR>
-__global__ void __launch_bounds__(256, 2) amd_diffusivities_march_kernel(DGrid g, AmdArgs a, int kchunk) {
+#ifndef OCN_AMD_MARCH_WAVES
+#define OCN_AMD_MARCH_WAVES 2       // 204 VGPRs; 3 waves per SIMD (168 VGPRs, 17 doubles spilled): 0.80 ms instead of 0.29 (measured)
+#endif
+__global__ void __launch_bounds__(256, OCN_AMD_MARCH_WAVES) amd_diffusivities_march_kernel(DGrid g, AmdArgs a, int kchunk) {
     // per-level factors of the levels kc0 .. kc1 + 1 of this block: FZ = 2 Δzᶜ, 1 / Δzᶠ, the four metric ratios of the normalised
     // gradients, δ² -- wave-uniform, ~17 FP64 divisions per cell in the per-cell kernel
     __shared__ double lev[8][OCN_AMD_MAXCHUNK + 2];
