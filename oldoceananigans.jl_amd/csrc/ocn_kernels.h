@@ -438,10 +438,23 @@ __device__ __forceinline__ void amd_point(double a, double b, double out[AM_N]) 
     out[AM_SQ1] = a * a; out[AM_SQ2] = b * b; out[AM_P1] = a * s; out[AM_P2] = b * s; out[AM_A] = a; out[AM_B] = b; out[AM_S] = s;
 }
 
-template <int NTR>
 #ifndef OCN_AMD_MARCH_WAVES
-#define OCN_AMD_MARCH_WAVES 2       // 204 VGPRs; 3 waves per SIMD (168 VGPRs, 17 doubles spilled): 0.80 ms instead of 0.29 (measured)
+#define OCN_AMD_MARCH_WAVES 2       // waves per SIMD the register allocation must allow; 3 (168 VGPRs, 17 doubles spilled): 0.80 ms instead of 0.29 (measured)
 #endif
+#ifndef OCN_AMD_PF
+#define OCN_AMD_PF 0                // levels whose loads are issued ahead of the level being evaluated (measured at 256 x 256 x 128: 2 waves per SIMD PF 0 0.249 ms,
+                                    // PF 1 0.64 (256 VGPRs + spills); 1 wave per SIMD PF 1 0.286, PF 2 0.304 -- gathering the loads of a level is what pays, not their distance)
+#endif
+// every value a level contributes, loaded ONCE per level and ahead of its use: the loads depend on the level only, never on a result, so
+// they can be issued OCN_AMD_PF levels early (measured below: no gain over gathering them at the top of their own level)
+template <int NTR> struct AmdRaw {
+    double uc, vc, wc;                       // u, v, w at (ic, j, L)
+    double wim, wjm, wjp, vjp;               // w(ic-1, j), w(ic, j-1), w(ic, j+1), v(ic, j+1)
+    double ujp, ujm, uip, vim, vimjp;        // u(ic, j+1), u(ic, j-1), u(ic+1, j), v(ic-1, j), v(ic-1, j+1)
+    double c[NTR > 0 ? NTR : 1], cim[NTR > 0 ? NTR : 1], cjm[NTR > 0 ? NTR : 1], cjp[NTR > 0 ? NTR : 1];
+};
+
+template <int NTR>
 __global__ void __launch_bounds__(256, OCN_AMD_MARCH_WAVES) amd_diffusivities_march_kernel(DGrid g, AmdArgs a, int kchunk) {
     // per-level factors of the levels kc0 .. kc1 + 1 of this block: FZ = 2 Δzᶜ, 1 / Δzᶠ, the four metric ratios of the normalised
     // gradients, δ² -- wave-uniform, ~17 FP64 divisions per cell in the per-cell kernel
@@ -466,71 +479,95 @@ __global__ void __launch_bounds__(256, OCN_AMD_MARCH_WAVES) amd_diffusivities_ma
     const int ic = min(i, a.r.i1 + 1);                                   // lanes beyond the last needed column repeat it (in bounds)
     const double fxfy = fx / fy, fyfx = fy / fx;
     const FView &u = a.u, &v = a.v, &w = a.w;
+    typedef AmdRaw<NTR> Raw;
+
+    auto load = [&](int L) {                                             // levels beyond the chunk's last needed one: that one again (unused)
+        Raw r;
+        L = min(L, kc1 + 1);
+        r.uc = u.at(ic, j, L); r.vc = v.at(ic, j, L); r.wc = w.at(ic, j, L);
+        r.wim = w.at(ic - 1, j, L); r.wjm = w.at(ic, j - 1, L); r.wjp = w.at(ic, j + 1, L); r.vjp = v.at(ic, j + 1, L);
+        r.ujp = u.at(ic, j + 1, L); r.ujm = u.at(ic, j - 1, L); r.uip = u.at(ic + 1, j, L);
+        r.vim = v.at(ic - 1, j, L); r.vimjp = v.at(ic - 1, j + 1, L);
+#pragma unroll
+        for (int t = 0; t < NTR; ++t) {
+            const FView &c = a.c[t];
+            r.c[t] = c.at(ic, j, L); r.cim[t] = c.at(ic - 1, j, L); r.cjm[t] = c.at(ic, j - 1, L); r.cjp[t] = c.at(ic, j + 1, L);
+        }
+        return r;
+    };
 
     // level state carried from one iteration to the next (see the section comment)
     double ixy[AM_N], ix_fcf[AM_N + 1], iy_cff[AM_N];
     double t_ix[NTR > 0 ? NTR : 1], t_ix2[NTR > 0 ? NTR : 1], t_iy[NTR > 0 ? NTR : 1], t_iy2[NTR > 0 ? NTR : 1], t_z[NTR > 0 ? NTR : 1], t_z2[NTR > 0 ? NTR : 1];
     double n_fcf[AM_N + 1], n_cff[AM_N], n_z[NTR > 0 ? NTR : 1], n_z2[NTR > 0 ? NTR : 1];
 
-    // fcf / cff kinds and the tracers' z operand at level L (what a cell needs of the level ABOVE it)
-    auto vertical = [&](int L, double fcf[AM_N + 1], double cff[AM_N], double tz[], double tz2[]) {
+    // fcf / cff kinds and the tracers' z operand at level L (what a cell needs of the level ABOVE it); r: level L, rb: level L - 1
+    auto vertical = [&](int L, const Raw &r, const Raw &rb, double fcf[AM_N + 1], double cff[AM_N], double tz[], double tz2[]) {
         const int q = L - kc0;
         const double fz = lev[0][q], rdzf = lev[1][q], fxfz = lev[2][q], fzfx = lev[3][q], fyfz = lev[4][q], fzfy = lev[5][q];
-        const double uc = u.at(ic, j, L), vc = v.at(ic, j, L), wc = w.at(ic, j, L);
+        const double uc = r.uc, vc = r.vc, wc = r.wc;
         {   // (ic, j, L): DXW = FX / FZ * ∂x w, DZU = FZ / FX * ∂z u
             double p[AM_N];
-            amd_point(fxfz * ((wc - w.at(ic - 1, j, L)) * rdx), fzfx * ((uc - u.at(ic, j, L - 1)) * rdzf), p);
+            amd_point(fxfz * ((wc - r.wim) * rdx), fzfx * ((uc - rb.uc) * rdzf), p);
 #pragma unroll
             for (int q = 0; q < AM_N; ++q) fcf[q] = ix_lane(p[q]);
         }
         double dyw0;
         {   // rows j and j + 1: DYW = FY / FZ * ∂y w, DZV = FZ / FY * ∂z v
             double p0[AM_N], p1[AM_N];
-            const double wn = w.at(ic, j + 1, L), vn = v.at(ic, j + 1, L);
-            dyw0 = fyfz * ((wc - w.at(ic, j - 1, L)) * rdy);
-            amd_point(dyw0, fzfy * ((vc - v.at(ic, j, L - 1)) * rdzf), p0);
-            amd_point(fyfz * ((wn - wc) * rdy), fzfy * ((vn - v.at(ic, j + 1, L - 1)) * rdzf), p1);
+            const double wn = r.wjp, vn = r.vjp;
+            dyw0 = fyfz * ((wc - r.wjm) * rdy);
+            amd_point(dyw0, fzfy * ((vc - rb.vc) * rdzf), p0);
+            amd_point(fyfz * ((wn - wc) * rdy), fzfy * ((vn - rb.vjp) * rdzf), p1);
 #pragma unroll
             for (int q = 0; q < AM_N; ++q) cff[q] = 0.5 * (p0[q] + p1[q]);
         }
         fcf[AM_N] = ix_lane(dyw0);                                       // Ix of DYW at (·, j, L)
 #pragma unroll
         for (int t = 0; t < NTR; ++t) {
-            const FView &c = a.c[t];
-            const double dzc = fz * ((c.at(ic, j, L) - c.at(ic, j, L - 1)) * rdzf);
+            const double dzc = fz * ((r.c[t] - rb.c[t]) * rdzf);
             tz[t] = dzc; tz2[t] = dzc * dzc;
         }
     };
     // ffc kind and the tracers' x / y operands at level L (what a cell needs of its OWN level)
-    auto horizontal = [&](int L) {
+    auto horizontal = [&](const Raw &r) {
         double p0[AM_N], p1[AM_N];
-        const double uc = u.at(ic, j, L), un = u.at(ic, j + 1, L), vc = v.at(ic, j, L), vn = v.at(ic, j + 1, L);
-        amd_point(fxfy * ((vc - v.at(ic - 1, j, L)) * rdx), fyfx * ((uc - u.at(ic, j - 1, L)) * rdy), p0);
-        amd_point(fxfy * ((vn - v.at(ic - 1, j + 1, L)) * rdx), fyfx * ((un - uc) * rdy), p1);
+        const double uc = r.uc, un = r.ujp, vc = r.vc, vn = r.vjp;
+        amd_point(fxfy * ((vc - r.vim) * rdx), fyfx * ((uc - r.ujm) * rdy), p0);
+        amd_point(fxfy * ((vn - r.vimjp) * rdx), fyfx * ((un - uc) * rdy), p1);
 #pragma unroll
         for (int q = 0; q < AM_N; ++q) ixy[q] = 0.5 * (ix_lane(p0[q]) + ix_lane(p1[q]));
 #pragma unroll
         for (int t = 0; t < NTR; ++t) {
-            const FView &c = a.c[t];
-            const double cc = c.at(ic, j, L);
-            const double dxc = fx * ((cc - c.at(ic - 1, j, L)) * rdx);
+            const double cc = r.c[t];
+            const double dxc = fx * ((cc - r.cim[t]) * rdx);
             t_ix[t] = ix_lane(dxc); t_ix2[t] = ix_lane(dxc * dxc);
-            const double dyc0 = fy * ((cc - c.at(ic, j - 1, L)) * rdy), dyc1 = fy * ((c.at(ic, j + 1, L) - cc) * rdy);
+            const double dyc0 = fy * ((cc - r.cjm[t]) * rdy), dyc1 = fy * ((r.cjp[t] - cc) * rdy);
             t_iy[t] = 0.5 * (dyc0 + dyc1); t_iy2[t] = 0.5 * (dyc0 * dyc0 + dyc1 * dyc1);
         }
     };
 
-    vertical(kc0, ix_fcf, iy_cff, t_z, t_z2);
-    horizontal(kc0);
+    Raw r0, r1, r2, r3;
+    {
+        const Raw rm = load(kc0 - 1);
+        r0 = load(kc0); r1 = load(kc0 + 1);
+        if (OCN_AMD_PF >= 1) r2 = load(kc0 + 2);
+        if (OCN_AMD_PF >= 2) r3 = load(kc0 + 3);
+        vertical(kc0, r0, rm, ix_fcf, iy_cff, t_z, t_z2);
+        horizontal(r0);
+    }
     for (int k = kc0; k <= kc1; ++k) {
-        vertical(k + 1, n_fcf, n_cff, n_z, n_z2);
+        // r0: level k, r1: level k + 1 (r2, r3: the levels after it, in flight)
+        Raw rn;
+        if (OCN_AMD_PF >= 1) rn = load(k + 2 + OCN_AMD_PF);
+        vertical(k + 1, r1, r0, n_fcf, n_cff, n_z, n_z2);
 #pragma unroll
         for (int q = 0; q < AM_N; ++q) { A.ixy[q] = ixy[q]; A.ixz[q] = 0.5 * (ix_fcf[q] + n_fcf[q]); A.iyz[q] = 0.5 * (iy_cff[q] + n_cff[q]); }
         A.ixz[AM_N] = 0.5 * (ix_fcf[AM_N] + n_fcf[AM_N]);
         A.fz_k = lev[0][k - kc0]; A.delta2_k = lev[6][k - kc0];
-        A.dxu_k = (u.at(ic + 1, j, k) - u.at(ic, j, k)) * rdx;
-        A.dyv_k = (v.at(ic, j + 1, k) - v.at(ic, j, k)) * rdy;
-        A.dzw_k = (w.at(ic, j, k + 1) - w.at(ic, j, k)) * lev[7][k - kc0];
+        A.dxu_k = (r0.uip - r0.uc) * rdx;
+        A.dyv_k = (r0.vjp - r0.vc) * rdy;
+        A.dzw_k = (r1.wc - r0.wc) * lev[7][k - kc0];
         if (out_lane) a.nu_e.at(i, j, k) = amd_viscosity(A, a.Cnu, i, j, k);
 #pragma unroll
         for (int t = 0; t < NTR; ++t) {
@@ -544,7 +581,11 @@ __global__ void __launch_bounds__(256, OCN_AMD_MARCH_WAVES) amd_diffusivities_ma
         for (int q = 0; q < AM_N; ++q) iy_cff[q] = n_cff[q];
 #pragma unroll
         for (int t = 0; t < NTR; ++t) { t_z[t] = n_z[t]; t_z2[t] = n_z2[t]; }
-        if (k < kc1) horizontal(k + 1);
+        if (k < kc1) horizontal(r1);
+        r0 = r1;
+        if (OCN_AMD_PF == 0) r1 = load(k + 2);
+        else if (OCN_AMD_PF == 1) { r1 = r2; r2 = rn; }
+        else { r1 = r2; r2 = r3; r3 = rn; }
     }
 }
 
