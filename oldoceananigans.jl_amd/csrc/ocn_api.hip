@@ -2574,11 +2574,15 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     }
     a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
-    a.any_flux = m->any_flux_bc;
+    // compute_flux_bc_tendencies! belongs to the stage that FOLLOWS (runge_kutta_3.jl:118,134,150: called right before rk3_substep!), not to
+    // update_state!: the conditions are folded in only when that stage's substep rides along; otherwise G stays without them and the
+    // stepper adds them when the stage begins (compute_flux_bc_tendencies below) -- with the conditions' values of THAT moment
+    const bool with_flux = sub != nullptr;
+    a.any_flux = m->any_flux_bc && with_flux;
     a.nlin = 0;
     for (int f = 0; f < m->nf; ++f)
         for (int sd = 0; sd < 6; ++sd)
-            if (m->lin[f][sd].on) {
+            if (m->lin[f][sd].on && with_flux) {
                 if (a.nlin == OCN_EPILOGUE_MAX_LIN) return fail(OCN_ESTATE, "more than %d field-dependent Flux conditions in the fused epilogue", OCN_EPILOGUE_MAX_LIN);
                 a.lin[a.nlin].f = f; a.lin[a.nlin].side = sd; a.lin[a.nlin].dep = m->lin[f][sd].dep;
                 a.lin[a.nlin].a = m->lin[f][sd].a; a.lin[a.nlin].b = m->lin[f][sd].b;
@@ -2587,7 +2591,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     const int T[3] = {g.tx, g.ty, g.tz};
     for (int f = 0; f < OCN_MAX_FIELDS; ++f)
         for (int sd = 0; sd < 6; ++sd) {
-            a.has_flux[f][sd] = f < m->nf && ((sd & 1) ? wall_hi(T[sd / 2]) : wall_lo(T[sd / 2])) && m->bcs[f][sd].kind == OCN_BC_FLUX &&
+            a.has_flux[f][sd] = with_flux && f < m->nf && ((sd & 1) ? wall_hi(T[sd / 2]) : wall_lo(T[sd / 2])) && m->bcs[f][sd].kind == OCN_BC_FLUX &&
                                 (m->bcs[f][sd].value != 0.0 || m->bcs[f][sd].array);
             a.flux[f][sd] = f < m->nf ? m->bcs[f][sd].value : 0.0;
             a.flux_arr[f][sd] = f < m->nf ? m->bcs[f][sd].array : nullptr;
@@ -2624,7 +2628,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
             int mask = 0;
             for (int f = 0; f < m->nf; ++f)
                 for (int sd = 0; sd < 6; ++sd)
-                    if ((a.any_flux && a.has_flux[f][sd]) || m->lin[f][sd].on) mask |= 1 << sd;
+                    if ((a.any_flux && a.has_flux[f][sd]) || (with_flux && m->lin[f][sd].on)) mask |= 1 << sd;
             if (mask) {
                 SideList sl;
                 sl.n = 0;
@@ -2732,7 +2736,7 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
                                 m->tendency_impl, physics ? nullptr : sub);
         if (ev) HIP_TRY(hipEventRecord(ev->second, g_stream));
         if (!rc && physics) {
-            if (epilogue_runs(m)) rc = tendency_epilogue(m, sub);
+            if (epilogue_runs(m)) { if (has_physics(m) || sub) rc = tendency_epilogue(m, sub); }      // (Flux conditions alone and no substep: nothing to do)
             else {
                 if (sub) return fail(OCN_ESTATE, "fused substep needs the fused epilogue");
                 if (!rc && m->has_coriolis) rc = add_fplane_coriolis(g, m->fcor, m->U[0], m->U[1], m->Gn[0], m->Gn[1], nullptr);
@@ -2745,15 +2749,23 @@ static int update_state_tail(ocn_model_s *m, bool compute_tend, const FusedSubst
                                             m->Gn[2], m->Gn + 3, nullptr, m->nu_e, m->kappa_e);
             }
         }
-        // compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184) -- inside the epilogue pass when that runs
-        if (m->any_flux_bc && !epilogue_runs(m))
-            for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
-        if (m->any_linear_flux && !epilogue_runs(m))
-            for (int f = 0; f < m->nf && !rc; ++f)
-                for (int sd = 0; sd < 6 && !rc; ++sd)
-                    if (m->lin[f][sd].on)
-                        rc = compute_linear_flux_bc(g, m->Gn[f], m->loc[f], sd, m->lin[f][sd].a, m->lin[f][sd].b, m->U[m->lin[f][sd].dep]);
     }
+    return rc;
+}
+
+// compute_flux_bc_tendencies! (compute_nonhydrostatic_tendencies.jl:170-184): the time steppers call it right before a substep
+// (runge_kutta_3.jl:118,134,150; quasi_adams_bashforth_2.jl:99). Stages whose substep rode along with the previous tendency evaluation had
+// the conditions folded into that pass (tendency_epilogue); every other substep calls this first.
+static int compute_flux_bc_tendencies(ocn_model_s *m) {
+    const DGrid &g = m->grid->d;
+    int rc = OCN_OK;
+    if (m->any_flux_bc)
+        for (int f = 0; f < m->nf && !rc; ++f) rc = compute_flux_bcs(g, m->Gn[f], m->loc[f], m->bcs[f]);
+    if (m->any_linear_flux)
+        for (int f = 0; f < m->nf && !rc; ++f)
+            for (int sd = 0; sd < 6 && !rc; ++sd)
+                if (m->lin[f][sd].on)
+                    rc = compute_linear_flux_bc(g, m->Gn[f], m->loc[f], sd, m->lin[f][sd].a, m->lin[f][sd].b, m->U[m->lin[f][sd].dep]);
     return rc;
 }
 
@@ -3016,6 +3028,7 @@ static int rk3_time_step(ocn_model_s *m, double dt) {
     const bool can_fuse = can_fuse_substep(m);
     bool substep_done = false;
     for (int stage = 0; stage < 3; ++stage) {
+        if (!substep_done && (rc = compute_flux_bc_tendencies(m))) return rc;
         if (!substep_done && (rc = rk3_substep(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, gam[stage], zet[stage], stage > 0))) return rc;
         substep_done = false;
         if (stage < 2) tick(m, sdt[stage], true);
@@ -3112,6 +3125,7 @@ extern "C" int ocn_model_time_step_ab2(ocn_model_t m, double dt, double chi, int
     if (m->iteration == 0 && (rc = update_state(m, true))) return rc;
     const bool eul = euler != 0 || dt != m->last_dt;            // Δt changed, or first step (last_Δt = Inf)
     const double x = eul ? -0.5 : chi;
+    if ((rc = compute_flux_bc_tendencies(m))) return rc;                                   // quasi_adams_bashforth_2.jl:99
     if ((rc = ab2_step(g, m->U, m->Gn, m->Gm, m->loc, m->nf, dt, x))) return rc;
     tick(m, dt, false);
     if ((rc = pressure_step(m, dt))) return rc;

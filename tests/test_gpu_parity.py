@@ -1222,3 +1222,120 @@ def test_boundary_conditions_on_the_diffusivity_fields_match_oracle(ocn, oracle,
         assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, name
     with pytest.raises(ocn.OcnError):
         ocn.NonhydrostaticModel(grid=g_gpu, closure=ocn.AnisotropicMinimumDissipation(), boundary_conditions={"νₑ": F(bottom=ocn.FluxBoundaryCondition(1.0))})
+
+
+def test_seeded_random_physics_configurations_match_the_oracle(ocn, oracle, arch):
+    """sixteen seeded random small models against the ORACLE: random sizes (4 .. 20 per direction), Periodic / Bounded mixes (stretched z on
+    half of the Bounded ones), 0 .. 2 tracers, ScalarDiffusivity or AnisotropicMinimumDissipation, FPlane, buoyancy (tracer or linear
+    seawater), valued Flux conditions on random walls and a field-dependent one. Tendencies from identical inputs (no projection) bit for
+    bit -- every physics kernel, the z-marching ones included --, then 3 RK3 steps from a projected smooth state within 1e-12."""
+    rng = np.random.default_rng(771)
+    F = ocn.FieldBoundaryConditions
+    topo_names = ("Periodic", "Bounded")
+    sides = {0: ("west", "east"), 1: ("south", "north"), 2: ("bottom", "top")}
+    normal = {"u": 0, "v": 1, "w": 2}
+    for case in range(16):
+        size = tuple(int(rng.integers(4, 21)) for _ in range(3))
+        topology = tuple(topo_names[int(rng.random() < 0.5)] for _ in range(3))
+        z = tanh_faces(size[2]) if (topology[2] == "Bounded" and rng.random() < 0.5) else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+        ntr = int(rng.integers(0, 3))
+        gpu_names = ("T", "S")[:ntr]
+        cpu_names = ["u", "v", "w"] + ["c%d" % t for t in range(ntr)]
+        amd = rng.random() < 0.5
+        kw = dict(closure=ocn.AnisotropicMinimumDissipation() if amd else ocn.ScalarDiffusivity(ν=3e-3, κ=2e-3))
+        g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        g_cpu = oracle.Grid(size, topology=tuple({"Periodic": 0, "Bounded": 1}[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+        m_cpu = oracle.Model(g_cpu, ntr)
+        if amd:
+            m_cpu.set_amd()
+        else:
+            m_cpu.set_closure(nu=3e-3, kappa=2e-3)
+        if rng.random() < 0.5:
+            kw["coriolis"] = ocn.FPlane(f=0.6)
+            m_cpu.set_coriolis(0.6)
+        if ntr == 2 and rng.random() < 0.6:
+            kw["buoyancy"] = ocn.SeawaterBuoyancy(ocn.LinearEquationOfState(thermal_expansion=2e-4, haline_contraction=8e-4))
+            m_cpu.set_seawater_buoyancy(alpha=2e-4, beta=8e-4)
+        elif ntr >= 1 and rng.random() < 0.4:
+            gpu_names = ("b",) + gpu_names[1:]
+            kw["buoyancy"] = ocn.BuoyancyTracer()
+            m_cpu.set_buoyancy_tracer(0)
+        bcs = {}
+        for name, cname in zip(("u", "v", "w") + gpu_names, cpu_names):
+            conds = {}
+            for d in range(3):
+                if topology[d] == "Bounded" and normal.get(name) != d:
+                    for sd in sides[d]:
+                        if rng.random() < 0.3:
+                            val = float(rng.normal()) * 1e-3
+                            conds[sd] = ocn.FluxBoundaryCondition(val)
+                            m_cpu.set_bc(cname, sd, "flux", val)
+            if conds:
+                bcs[name] = F(**conds)
+        if ntr >= 1 and topology[2] == "Bounded" and gpu_names[-1] not in bcs and rng.random() < 0.5:
+            rate = 2.5e-3
+            bcs[gpu_names[-1]] = F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-rate), field_dependencies=gpu_names[-1]))
+            m_cpu.set_linear_flux_bc(cpu_names[-1], "top", 0.0, -rate, cpu_names[-1])
+        if bcs:
+            kw["boundary_conditions"] = bcs
+        m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=gpu_names, **kw)
+        what = (case, size, topology, ntr, sorted(kw), sorted(bcs))
+        set_both(ocn, m_gpu, m_cpu, seed=900 + case, enforce_incompressibility=False)
+        ocn.update_state(m_gpu, True)
+        m_cpu.update_state(True)
+        for n, cn in zip(m_gpu.fields().keys(), cpu_names):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (what, n)
+        set_both(ocn, m_gpu, m_cpu, seed=1234 + case, smooth=True)
+        dz = float(np.min(g_gpu.Δzᵃᵃᶜ))
+        dt = 0.05 * min(g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, dz) / 0.6
+        for _ in range(3):
+            ocn.time_step(m_gpu, dt)
+            m_cpu.time_step(dt)
+        for name, a, b in field_pairs(m_gpu, m_cpu):
+            if name == "pNHS":
+                continue                                    # the pressure has its own error model (test_time_step_parity_10_steps)
+            e = rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3])
+            assert e < 1e-12, (what, name, e)
+        m_gpu.close()
+
+
+def test_flux_condition_changed_between_steps_acts_on_the_next_first_stage(ocn, oracle, arch):
+    """compute_flux_bc_tendencies! belongs to the STAGE (runge_kutta_3.jl:118,134,150: right before rk3_substep!), not to update_state!: after a
+    time-step the stored tendencies carry no Flux-condition terms, and a condition whose value changes between two steps (a wind stress
+    updated by a callback) acts on the next step's first stage with its NEW value. The library folds the conditions into the tendency pass
+    only where the next stage's substep rides along; here: tendencies after update_state! and after a step bit / 1e-10 against the oracle,
+    and a run that switches the surface stress after step 2 against the oracle doing the same, with the fused and the separate substeps"""
+    from oldoceananigans_jl_amd import _lib
+    size, topology = (12, 10, 9), ("Periodic", "Periodic", "Bounded")
+    z = tanh_faces(size[2])
+    F = ocn.FieldBoundaryConditions
+    for fuse in (1, 0):
+        g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        g_cpu = oracle.Grid(size, topology=(0, 0, 1), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+        m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T", "S"), closure=ocn.ScalarDiffusivity(ν=2e-3, κ=1e-3),
+                                        boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-3)), "T": F(top=ocn.FluxBoundaryCondition(4e-3))})
+        m_gpu.set_option("fuse_substep", fuse)
+        m_cpu = oracle.Model(g_cpu, 2)
+        m_cpu.set_closure(nu=2e-3, kappa=1e-3)
+        m_cpu.set_bc("u", "top", "flux", -1e-3)
+        m_cpu.set_bc("c0", "top", "flux", 4e-3)
+        set_both(ocn, m_gpu, m_cpu, seed=3, enforce_incompressibility=False)
+        ocn.update_state(m_gpu, True)
+        m_cpu.update_state(True)
+        for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (fuse, n)     # no Flux terms in update_state!'s tendencies
+        set_both(ocn, m_gpu, m_cpu, seed=1234, smooth=True)
+        dt = 2e-3
+        for step in range(4):
+            if step == 2:                                    # the stress reverses between two steps
+                _lib.check(_lib.lib().ocn_model_set_boundary_condition(m_gpu.handle, b"u", 5, 1, 2.5e-3))
+                m_cpu.set_bc("u", "top", "flux", 2.5e-3)
+            ocn.time_step(m_gpu, dt)
+            m_cpu.time_step(dt)
+            for n, cn in zip(m_gpu.fields().keys(), ["u", "v", "w", "c0", "c1"]):
+                a, b = m_gpu.tendency(n).parent()[3:-3, 3:-3, 3:-3], m_cpu.field("G" + cn)[3:-3, 3:-3, 3:-3]
+                assert rel_err(a, b) < 1e-10, (fuse, step, n, rel_err(a, b))
+        for name, a, b in field_pairs(m_gpu, m_cpu):
+            if name != "pNHS":
+                assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (fuse, name)
+        m_gpu.close()
