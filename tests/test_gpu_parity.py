@@ -1339,3 +1339,80 @@ def test_flux_condition_changed_between_steps_acts_on_the_next_first_stage(ocn, 
             if name != "pNHS":
                 assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (fuse, name)
         m_gpu.close()
+
+
+def test_seeded_random_flat_ab2_and_value_gradient_configurations_match_the_oracle(ocn, oracle, arch):
+    """sixteen more seeded random small models against the ORACLE, on the axes the first random test leaves out: Flat directions (at most one,
+    size 1), Value / Gradient conditions on walls (no-slip velocities, fixed tracers), the QuasiAdamsBashforth2 stepper on half of the
+    cases, with ScalarDiffusivity / FPlane / buoyancy mixes. Tendencies from identical inputs bit for bit, then 3 steps within 1e-12."""
+    rng = np.random.default_rng(4242)
+    F = ocn.FieldBoundaryConditions
+    sides = {0: ("west", "east"), 1: ("south", "north"), 2: ("bottom", "top")}
+    normal = {"u": 0, "v": 1, "w": 2}
+    code = {"Periodic": 0, "Bounded": 1, "Flat": 3}
+    for case in range(16):
+        topology = [("Periodic", "Bounded")[int(rng.random() < 0.5)] for _ in range(3)]
+        flat = int(rng.integers(0, 4))                      # 3: no Flat direction
+        if flat < 3:
+            topology[flat] = "Flat"
+        topology = tuple(topology)
+        size = tuple(1 if t == "Flat" else int(rng.integers(5, 19)) for t in topology)
+        z = tanh_faces(size[2]) if (topology[2] == "Bounded" and rng.random() < 0.5) else ((-1.0, 0.0) if topology[2] == "Bounded" else (0.0, 1.0))
+        ntr = int(rng.integers(1, 3))
+        gpu_names = ("T", "S")[:ntr]
+        cpu_names = ["u", "v", "w"] + ["c%d" % t for t in range(ntr)]
+        ab2 = rng.random() < 0.5
+        kw = dict(timestepper="QuasiAdamsBashforth2" if ab2 else "RungeKutta3")
+        g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        g_cpu = oracle.Grid(size, topology=tuple(code[t] for t in topology), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+        m_cpu = oracle.Model(g_cpu, ntr)
+        if rng.random() < 0.7:
+            kw["closure"] = ocn.ScalarDiffusivity(ν=3e-3, κ=2e-3)
+            m_cpu.set_closure(nu=3e-3, kappa=2e-3)
+        if rng.random() < 0.5:
+            kw["coriolis"] = ocn.FPlane(f=0.6)
+            m_cpu.set_coriolis(0.6)
+        if ntr == 2 and topology[2] != "Flat" and rng.random() < 0.5:
+            kw["buoyancy"] = ocn.SeawaterBuoyancy()
+            m_cpu.set_seawater_buoyancy()
+        bcs = {}
+        for name, cname in zip(("u", "v", "w") + gpu_names, cpu_names):
+            conds = {}
+            for d in range(3):
+                if topology[d] == "Bounded" and normal.get(name) != d:
+                    for sd in sides[d]:
+                        r = rng.random()
+                        val = float(rng.normal()) * (1e-2 if name in ("u", "v", "w") else 0.3)
+                        if r < 0.25:
+                            conds[sd] = ocn.ValueBoundaryCondition(val); m_cpu.set_bc(cname, sd, "value", val)
+                        elif r < 0.45:
+                            conds[sd] = ocn.GradientBoundaryCondition(val); m_cpu.set_bc(cname, sd, "gradient", val)
+                        elif r < 0.6:
+                            conds[sd] = ocn.FluxBoundaryCondition(val * 1e-1); m_cpu.set_bc(cname, sd, "flux", val * 1e-1)
+            if conds:
+                bcs[name] = F(**conds)
+        if bcs:
+            kw["boundary_conditions"] = bcs
+        m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=gpu_names, **kw)
+        what = (case, size, topology, ntr, sorted(kw), {n: sorted(b.sides) for n, b in bcs.items()})
+        set_both(ocn, m_gpu, m_cpu, seed=500 + case, enforce_incompressibility=False)
+        ocn.update_state(m_gpu, True)
+        m_cpu.update_state(True)
+        for n, cn in zip(m_gpu.fields().keys(), cpu_names):
+            assert np.array_equal(m_gpu.tendency(n).parent(), m_cpu.field("G" + cn)), (what, n)
+        set_both(ocn, m_gpu, m_cpu, seed=77 + case, smooth=True)
+        spacings = [d for d, t in zip((g_gpu.Δxᶜᵃᵃ, g_gpu.Δyᵃᶜᵃ, float(np.min(g_gpu.Δzᵃᵃᶜ))), topology) if t != "Flat"]
+        dt = 0.05 * min(spacings) / 0.6
+        for _ in range(3):
+            ocn.time_step(m_gpu, dt)
+            if ab2:
+                m_cpu.time_step_ab2(dt)
+            else:
+                m_cpu.time_step(dt)
+        core = tuple(slice(None) if t == "Flat" else slice(3, -3) for t in topology)
+        for name, a, b in field_pairs(m_gpu, m_cpu):
+            if name == "pNHS":
+                continue
+            e = rel_err(a[core], b[core])
+            assert e < 1e-12, (what, name, e)
+        m_gpu.close()
