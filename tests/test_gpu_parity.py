@@ -1416,3 +1416,60 @@ def test_seeded_random_flat_ab2_and_value_gradient_configurations_match_the_orac
             e = rel_err(a[core], b[core])
             assert e < 1e-12, (what, name, e)
         m_gpu.close()
+
+
+def test_api_call_sequences_between_steps_match_the_oracle(ocn, oracle, arch):
+    """what happens BETWEEN time-steps follows the reference too: set! in the middle of a run ends with update_state!(compute_tendencies = false)
+    (set_nonhydrostatic_model.jl:52-57), so the next first stage still uses the tendencies of the state before the set! (only iteration 0
+    re-evaluates them, runge_kutta_3.jl:97); an explicit update_state! re-evaluates them. Sequence: 2 steps, set! of a new state, 2 steps,
+    update_state!, 1 step -- HIP against the oracle making the same calls, fields within 1e-12 after every call."""
+    size, topology = (12, 10, 8), ("Periodic", "Bounded", "Bounded")
+    g_gpu, g_cpu, m_gpu, m_cpu = make_pair(ocn, oracle, arch, size, topology, z=tanh_faces(size[2]))
+
+    def check(tag):
+        for name, a, b in field_pairs(m_gpu, m_cpu):
+            if name != "pNHS":
+                assert rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]) < 1e-12, (tag, name, rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3]))
+
+    set_both(ocn, m_gpu, m_cpu, seed=11, smooth=True)
+    dt = 2e-3
+    for _ in range(2):
+        ocn.time_step(m_gpu, dt); m_cpu.time_step(dt)
+    check("two steps")
+    set_both(ocn, m_gpu, m_cpu, seed=12, smooth=True)             # a new state in the middle of the run
+    check("set!")
+    for _ in range(2):
+        ocn.time_step(m_gpu, dt); m_cpu.time_step(dt)
+    check("two steps after set!")
+    ocn.update_state(m_gpu, True); m_cpu.update_state(True)
+    ocn.time_step(m_gpu, dt); m_cpu.time_step(dt)
+    check("step after update_state!")
+    assert m_gpu.clock.iteration == 5 and abs(m_gpu.clock.time - m_cpu.time) < 1e-15
+    m_gpu.close()
+
+
+def test_ab2_with_a_time_step_that_changes_matches_the_oracle(ocn, oracle, arch):
+    """QuasiAdamsBashforth2: the first step and every step whose Δt differs from clock.last_Δt are forward-Euler steps (χ = -1/2,
+    quasi_adams_bashforth_2.jl:86-97); a Flux condition and a closure ride along. Δt sequence dt, dt, 0.7 dt, 0.7 dt, dt against the oracle."""
+    size, topology = (10, 12, 9), ("Bounded", "Periodic", "Bounded")
+    z = tanh_faces(size[2])
+    g_gpu = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+    g_cpu = oracle.Grid(size, topology=(1, 0, 1), x=(0.0, 1.0), y=(0.0, 1.0), z=z)
+    F = ocn.FieldBoundaryConditions
+    m_gpu = ocn.NonhydrostaticModel(grid=g_gpu, tracers=("T", "S"), timestepper="QuasiAdamsBashforth2", closure=ocn.ScalarDiffusivity(ν=2e-3, κ=1e-3),
+                                    boundary_conditions={"T": F(top=ocn.FluxBoundaryCondition(3e-3)), "v": F(west=ocn.ValueBoundaryCondition(0.0))})
+    m_cpu = oracle.Model(g_cpu, 2)
+    m_cpu.set_closure(nu=2e-3, kappa=1e-3)
+    m_cpu.set_bc("c0", "top", "flux", 3e-3)
+    m_cpu.set_bc("v", "west", "value", 0.0)
+    set_both(ocn, m_gpu, m_cpu, seed=21, smooth=True)
+    dt = 1.5e-3
+    for n, step_dt in enumerate([dt, dt, 0.7 * dt, 0.7 * dt, dt]):
+        ocn.time_step(m_gpu, step_dt)
+        m_cpu.time_step_ab2(step_dt)
+        for name, a, b in field_pairs(m_gpu, m_cpu):
+            if name != "pNHS":
+                e = rel_err(a[3:-3, 3:-3, 3:-3], b[3:-3, 3:-3, 3:-3])
+                assert e < 1e-12, (n, name, e)
+    assert abs(m_gpu.clock.time - m_cpu.time) < 1e-15
+    m_gpu.close()
