@@ -134,6 +134,31 @@ def test_library_x_solve_layouts_agree(ocn, arch, size, R):
             _compare(out, ref, r, nxl, size)
 
 
+def test_seeded_random_x_slab_partitions_match_single_gpu(ocn, arch):
+    """eight seeded random x-slab runs through the in-library partitioned step (threads sharing the card) against the single-GPU model:
+    2 .. 4 ranks, local widths 7 .. 40 (regular: every solver path -- x-fastest / z-fastest substructured, transposing), Ny (a multiple
+    of the rank count, distributed_fft_based_poisson_solver.jl:218-226) and Nz at random, one of the four physics presets (triply periodic; Bounded z with ScalarDiffusivity + buoyancy;
+    stretched z with Coriolis and Flux / Value / Gradient conditions; the configs[4] physics), three RK3 steps, 1e-12"""
+    _own_stream()
+    rng = np.random.default_rng(31337)
+    for case in range(8):
+        R = int(rng.integers(2, 5))
+        nxl = int(rng.choice([8, 16, 32, 64, 7, 12, 20, 40]))
+        ny = int(rng.choice([8, 12, 16, 24])) if rng.random() < 0.7 else int(rng.integers(6, 20))
+        ny += (-ny) % R                                   # Ny divisible by the number of ranks, as the reference's transposing solvers require
+        nz = int(rng.choice([8, 16])) if rng.random() < 0.5 else int(rng.integers(6, 14))
+        zkind = str(rng.choice(["periodic", "bounded", "stretched", "amd"]))
+        size = (R * nxl, ny, nz)
+        ref, time, dt = _single_gpu(ocn, arch, size, zkind, 3)
+        results = _run_library_ranks(ocn, arch, R, size, 3, zkind, {})
+        for r, (out, div, t, _off) in enumerate(results):
+            assert div < 5e-8 and t == time, (case, R, size, zkind)
+            try:
+                _compare(out, ref, r, nxl, size)
+            except AssertionError as e:
+                raise AssertionError((case, R, size, zkind, str(e)))
+
+
 def test_fused_source_term_and_z_transform_is_bit_identical(ocn, arch):
     """x-fastest substructured solve: the source term written straight into the LDS line buffer of the paired z transform
     (source_paired_zline_r2c_kernel) against the two separate kernels (option dist_fuse_source = 0): same expressions on the same operands,
