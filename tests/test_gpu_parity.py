@@ -1473,3 +1473,47 @@ def test_ab2_with_a_time_step_that_changes_matches_the_oracle(ocn, oracle, arch)
                 assert e < 1e-12, (n, name, e)
     assert abs(m_gpu.clock.time - m_cpu.time) < 1e-15
     m_gpu.close()
+
+
+def test_seeded_random_launch_ranges_of_the_flux_sharing_tendency_kernels(ocn, arch):
+    """KernelParameters launches (kernel_launching.jl:25-95: the interior / strip ranges of the distributed update, a29-a30): twenty seeded
+    random index ranges on a triply periodic and on a stretched Bounded-z grid, the flux-sharing kernels (role kernel, all-fields kernel:
+    ocn_compute_tendencies with tendency_impl 2 and 1) against the per-field kernels (ocn_compute_Gu .. Gc, bit-identical to the oracle)
+    on the same range: equal inside the range, nothing written outside it (the arrays carry a sentinel)"""
+    rng = np.random.default_rng(99)
+    for topology, size in ((("Periodic", "Periodic", "Periodic"), (70, 12, 20)), (("Periodic", "Periodic", "Bounded"), (66, 9, 14))):
+        z = tanh_faces(size[2]) if topology[2] == "Bounded" else (0.0, 1.0)
+        grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+        u, v, w, T, S = ocn.XFaceField(grid), ocn.YFaceField(grid), ocn.ZFaceField(grid), ocn.CenterField(grid), ocn.CenterField(grid)
+        vals = smooth_state({n: grid.nodes(f.loc) for n, f in zip("uvwTS", (u, v, w, T, S))}, 5)
+        for n, f in zip("uvwTS", (u, v, w, T, S)):
+            f.set(vals[n])
+            ocn.fill_halo_regions(f)
+        mk = {"u": ocn.XFaceField, "v": ocn.YFaceField, "w": ocn.ZFaceField, "T": ocn.CenterField, "S": ocn.CenterField}
+        for case in range(10):
+            lo = [int(rng.integers(1, n + 1)) for n in size]
+            hi = [int(rng.integers(l, n + 1)) for l, n in zip(lo, size)]
+            if case == 0:
+                lo, hi = [1, 1, 1], list(size)
+            r = (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+            want = {n: mk[n](grid) for n in "uvwTS"}
+            for f in want.values():
+                f.set_parent(np.full(f.shape, -7.25))
+            ocn.kernels.compute_Gu(grid, u, v, w, want["u"], kernel_parameters=r)
+            ocn.kernels.compute_Gv(grid, u, v, w, want["v"], kernel_parameters=r)
+            ocn.kernels.compute_Gw(grid, u, v, w, want["w"], kernel_parameters=r)
+            ocn.kernels.compute_Gc(grid, u, v, w, T, want["T"], kernel_parameters=r)
+            ocn.kernels.compute_Gc(grid, u, v, w, S, want["S"], kernel_parameters=r)
+            for impl in (2, 1):
+                ocn.set_option("tendency_impl", impl)
+                try:
+                    got = {n: mk[n](grid) for n in "uvwTS"}
+                    for f in got.values():
+                        f.set_parent(np.full(f.shape, -7.25))
+                    ocn.kernels.compute_tendencies(grid, u, v, w, [T, S], got["u"], got["v"], got["w"], [got["T"], got["S"]], kernel_parameters=r)
+                finally:
+                    ocn.set_option("tendency_impl", 2)
+                for n in "uvwTS":
+                    a, b = got[n].parent(), want[n].parent()
+                    assert np.array_equal(a, b), (topology, r, impl, n, int((a != b).sum()))
+                    assert (b != -7.25).sum() > 0
