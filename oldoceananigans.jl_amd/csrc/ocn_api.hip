@@ -993,6 +993,7 @@ static inline void launch_zline_solve(double2 *hc, const double2 *tw, const doub
 }
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
+static int g_skip_stage_pressure = 1;   // RK3 stages 1, 2: pNHS of the stage is not stored (overwritten by the next stage before anything can read it)
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
 static int g_dist_fuse_source = 1;     // x-fastest solve: source term and paired z transform in one kernel (no dense real right-hand side)
@@ -2526,6 +2527,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "epilogue_rows")) { if (value < 1 || value > 8) return fail(OCN_EINVAL, "epilogue_rows is 1 .. 8"); g_epilogue_rows = value; return OCN_OK; }
     if (!strcmp(key, "epilogue_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "epilogue_kchunk must be >= 0 (0 = automatic)"); g_epilogue_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
+    if (!strcmp(key, "skip_stage_pressure")) { g_skip_stage_pressure = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }
@@ -2793,9 +2795,12 @@ static int make_pressure_correction(ocn_model_s *m, double dt) {
 // compute_pressure_correction! + make_pressure_correction! (pressure_correction.jl:8-53). With a split solver the inverse transform
 // leaves the solution in a dense real array and ONE kernel corrects u, v, w from it and writes p / Δt⁺ into the haloed pressure field
 // (was: strided C2R into the field, halo fill, correction kernel, divide kernel).
-static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow);
-static int pressure_step(ocn_model_s *m, double dt, bool tendencies_follow = true) {
-    if (m->dm) return dist_pressure_step(m, dt, tendencies_follow);
+static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow, bool keep_p);
+// keep_p = false (stages 1 and 2 of an RK3 step): nothing can read pNHS before the next stage overwrites it (the time-step is one call), so the
+// dense-solution path neither stores p / Δt⁺ nor fills its halos there -- after the step the field holds the last stage's pressure, as the
+// reference's does
+static int pressure_step(ocn_model_s *m, double dt, bool tendencies_follow = true, bool keep_p = true) {
+    if (m->dm) return dist_pressure_step(m, dt, tendencies_follow, keep_p || !g_skip_stage_pressure);
     int rc;
     ocn_poisson_s *s = m->solver;
     if (!(s->split && g_split_solve && g_real_fft && !s->general)) {
@@ -2812,8 +2817,9 @@ static int pressure_step(ocn_model_s *m, double dt, bool tendencies_follow = tru
     const double dtp = std::fmax(2.220446049250313e-16, dt);
     hipLaunchKernelGGL(pressure_correction_dense_kernel, grid3(g.Nx, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, make_view(g, m->U[0], LOC_U),
                        make_view(g, m->U[1], LOC_V), make_view(g, m->U[2], LOC_W), (const double *)s->rrhs, make_view(g, m->p, LOC_C), dtp,
-                       g.tz == OCN_BOUNDED);
+                       g.tz == OCN_BOUNDED, keep_p || !g_skip_stage_pressure);
     KERNEL_CHECK();
+    if (!keep_p && g_skip_stage_pressure) return OCN_OK;
     double *pp[1] = {m->p};
     const int pl[1][3] = {{OCN_CENTER, OCN_CENTER, OCN_CENTER}};
     return fill_halo_regions(m->grid, pp, pl, 1, true);
@@ -3038,7 +3044,7 @@ static int rk3_time_step(ocn_model_s *m, double dt) {
             m->last_stage_dt = corrected;
             m->last_dt = dt;
         }
-        if ((rc = pressure_step(m, sdt[stage]))) return rc;
+        if ((rc = pressure_step(m, sdt[stage], true, stage == 2))) return rc;
         if (stage < 2 && (rc = cache_previous_tendencies(m))) return rc;
         if (stage < 2 && can_fuse) {
             FusedSubstep sub{m->U2, m->Gm, dt, gam[stage + 1], zet[stage + 1], 1};

@@ -620,7 +620,7 @@ static int dist_compute_pressure_correction(ocn_model_s *m) {
 // write p / dt into the model's pressure field -- no divide pass, no pointer swap (ocn_model_field pointers stay valid).
 // start_halo_exchange (tendencies are evaluated next): correct the two Hx-wide boundary strips first, fill their y / z halos, pack
 // them and START the x exchange of the coming update_state!; the interior correction runs while the halos are in flight.
-static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_halo_exchange) {
+static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_halo_exchange, bool keep_p = true) {
     DistModel *dm = m->dm;
     const DGrid &g = m->grid->d;
     const double dtp = std::fmax(2.220446049250313e-16, dt);
@@ -636,7 +636,7 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
         auto pcz = [&](int ia, int ib) {
             if (!zf)         // the solution is dense and x-fastest: the single-GPU path's dense correction on a column range
                 hipLaunchKernelGGL(pressure_correction_dense_slab_kernel, grid3(ib - ia + 1, g.Ny, g.Nz, BLK), BLK, 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib,
-                                   d.sj, d.sk, zb);
+                                   d.sj, d.sk, zb, keep_p);
             else
                 hipLaunchKernelGGL(pressure_correction_zfast_kernel, dim3((ib - ia + 32) / 32, (g.Nz + 31) / 32, (g.Ny + OCN_ZC_JB - 1) / OCN_ZC_JB), dim3(32, 8), 0,
                                    g_stream, g, vu, vv, vw, pd, pw, vp, dtp, ia, ib);
@@ -646,7 +646,7 @@ static int dist_make_pressure_correction(ocn_model_s *m, double dt, bool start_h
         if (!early) return pcz(1, g.Nx);
         if (!zf)
             hipLaunchKernelGGL(pressure_correction_dense_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx,
-                               d.sj, d.sk, zb);
+                               d.sj, d.sk, zb, keep_p);
         else
             hipLaunchKernelGGL(pressure_correction_zfast_strips_kernel, dim3(1, (g.Ny + 31) / 32, g.Nz), dim3(8, 32), 0, g_stream, g, vu, vv, vw, pd, pw, vp, dtp, g.Hx);
         KERNEL_CHECK();
@@ -720,10 +720,10 @@ static int dist_update_state(ocn_model_s *m, bool compute_tend, const FusedSubst
     return OCN_OK;
 }
 
-static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow) {
+static int dist_pressure_step(ocn_model_s *m, double dt, bool tendencies_follow, bool keep_p) {
     int rc = dist_compute_pressure_correction(m);
     if (rc) return rc;
-    return dist_make_pressure_correction(m, dt, tendencies_follow);
+    return dist_make_pressure_correction(m, dt, tendencies_follow, keep_p);
 }
 
 // NonhydrostaticModel(grid::DistributedRectilinearGrid; ...) -- `local_grid`: the rank's slab with x topology FullyConnected

@@ -1172,7 +1172,7 @@ __global__ void __launch_bounds__(256) pressure_correction_kernel(DGrid g, FView
 // bottom face keeps its w). The haloed pressure field receives p / Δt⁺. Same expressions as pressure_correction_kernel +
 // divide_interior_kernel.
 __global__ void __launch_bounds__(256) pressure_correction_dense_kernel(DGrid g, FView u, FView v, FView w, const double *pd, FView p,
-                                                                        double divisor, bool zbounded) {
+                                                                        double divisor, bool zbounded, bool store_p) {
     const int i = 1 + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
@@ -1186,7 +1186,7 @@ __global__ void __launch_bounds__(256) pressure_correction_dense_kernel(DGrid g,
     u.at(i, j, k) -= (pc - pim) * g.rdx;
     v.at(i, j, k) -= (pc - pjm) * g.rdy;
     w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
-    p.at(i, j, k) = pc / divisor;
+    if (store_p) p.at(i, j, k) = pc / divisor;
 }
 
 __global__ void __launch_bounds__(256) divide_interior_kernel(DGrid g, FView p, double divisor) {
@@ -2522,7 +2522,8 @@ __global__ void __launch_bounds__(256) column_pack_dense_kernel(int Nx, int Ny, 
 // The dense array holds cell (i, j, k) at (i-1) + sj (j-1) + sk (k-1): (Nx, Nx Ny) for the x-fastest substructured solve, (Nxe Nz, Nxe) for the
 // transposing solvers' paired-column layout; zbounded: p[0] = p[1] (the no-flux halo of a Bounded z: the bottom face keeps its w).
 __global__ void __launch_bounds__(256) pressure_correction_dense_slab_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
-                                                                             FView p, double divisor, int ia, int ib, long sj, long sk, bool zbounded) {
+                                                                             FView p, double divisor, int ia, int ib, long sj, long sk, bool zbounded,
+                                                                             bool store_p) {
     const int i = ia + blockIdx.x * blockDim.x + threadIdx.x;
     const int j = 1 + blockIdx.y * blockDim.y + threadIdx.y;
     const int k = 1 + blockIdx.z;
@@ -2536,11 +2537,11 @@ __global__ void __launch_bounds__(256) pressure_correction_dense_slab_kernel(DGr
     u.at(i, j, k) -= (pc - pim) * g.rdx;
     v.at(i, j, k) -= (pc - pjm) * g.rdy;
     w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
-    p.at(i, j, k) = pc / divisor;
+    if (store_p) p.at(i, j, k) = pc / divisor;
 }
 // ... and on the two Hx-wide boundary strips in one launch (threads along (column, y))
 __global__ void __launch_bounds__(256) pressure_correction_dense_strips_kernel(DGrid g, FView u, FView v, FView w, const double *pd, const double *pw,
-                                                                               FView p, double divisor, int H, long sj, long sk, bool zbounded) {
+                                                                               FView p, double divisor, int H, long sj, long sk, bool zbounded, bool store_p) {
     const int c = threadIdx.x, j = 1 + blockIdx.y * blockDim.y + threadIdx.y, k = 1 + blockIdx.z;
     if (c >= 2 * H || j > g.Ny || k > g.Nz) return;
     const int i = c < H ? 1 + c : g.Nx - 2 * H + 1 + c;
@@ -2553,7 +2554,7 @@ __global__ void __launch_bounds__(256) pressure_correction_dense_strips_kernel(D
     u.at(i, j, k) -= (pc - pim) * g.rdx;
     v.at(i, j, k) -= (pc - pjm) * g.rdy;
     w.at(i, j, k) -= (pc - pkm) * g.rdzf[k - 1 + g.Hz];
-    p.at(i, j, k) = pc / divisor;
+    if (store_p) p.at(i, j, k) = pc / divisor;
 }
 
 // per-block max |a - b| (plan cross-checks)

@@ -1517,3 +1517,31 @@ def test_seeded_random_launch_ranges_of_the_flux_sharing_tendency_kernels(ocn, a
                     a, b = got[n].parent(), want[n].parent()
                     assert np.array_equal(a, b), (topology, r, impl, n, int((a != b).sum()))
                     assert (b != -7.25).sum() > 0
+
+
+@pytest.mark.parametrize("topology", [("Periodic", "Periodic", "Periodic"), ("Periodic", "Periodic", "Bounded")])
+def test_stage_pressures_that_nothing_can_read_are_not_stored(ocn, arch, topology):
+    """RK3 stages 1 and 2: the stage's pNHS is overwritten by the next stage before anything outside the time-step call can read it, so the
+    dense-solution path does not store it (nor fill its halos) -- option skip_stage_pressure = 0 stores it like the reference does. Fields,
+    tendencies and the pressure left after each of three steps (the last stage's, halos included) bit for bit."""
+    size = (32, 16, 16)
+    z = tanh_faces(size[2]) if topology[2] == "Bounded" else (0.0, 1.0)
+    grid = ocn.RectilinearGrid(arch, size=size, x=(0.0, 1.0), y=(0.0, 1.0), z=z, topology=tuple(getattr(ocn, t) for t in topology))
+    outs = []
+    for skip in (1, 0):
+        ocn.set_option("skip_stage_pressure", skip)
+        try:
+            model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"))
+            ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, 8))
+            per_step = []
+            for _ in range(3):
+                ocn.time_step(model, 1e-3)
+                per_step.append([f.parent() for f in model.fields().values()] + [model.tendency(n).parent() for n in model.fields()] + [model.pressures.pNHS.parent()])
+            outs.append(per_step)
+            model.close()
+        finally:
+            ocn.set_option("skip_stage_pressure", 1)
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    assert np.abs(outs[0][-1][-1]).max() > 0
