@@ -346,7 +346,9 @@ int ocn_model_set_linear_flux_bc(ocn_model_t model, const char *name, int side, 
  *   pressure solve: "real_fft" (1: D2Z/Z2D, 0: the reference's complex-to-complex), "c2r_strided", "fused_zfft" (z FFT + divide +
  *     inverse z FFT as one LDS pass), "split_solve" (model time-step: 1-D x plans on 128-B-padded rows + LDS column-FFT kernel for y +
  *     pressure correction and p/Δt from the dense solution), "skip_stage_pressure" (1: RK3 stages 1 and 2 do not store their pNHS --
- *     nothing can read it before the next stage overwrites it; after a time-step the field holds the last stage's pressure either way);
+ *     nothing can read it before the next stage overwrites it; after a time-step the field holds the last stage's pressure either way),
+ *     "skip_dead_tendency_store" (1: the tendency evaluated after RK3's second stage feeds the third stage's substep riding along and is
+ *     not stored -- nothing else reads it; after a time-step Gⁿ = G(U³) and G⁻ = G(U¹) either way);
  *   x-slab solve: "dist_substructured" (1: gathered interface solve, 0: the reference's two transposes), "dist_zfirst" (z-fastest
  *     local layout), "dist_yline" (LDS column-FFT kernel for the local y transform), "dist_xfast" (the substructured solve in the fields'
  *     own x-fastest layout), "dist_fuse_source" (source term written straight into the z transform's line buffer), "dist_xline_group"

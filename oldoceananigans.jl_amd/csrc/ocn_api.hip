@@ -993,6 +993,7 @@ static inline void launch_zline_solve(double2 *hc, const double2 *tw, const doub
 }
 static int g_real_fft = 1, g_c2r_strided = 1;
 static int g_fused_zfft = 1;
+static int g_skip_dead_tendency_store = 1;   // the tendency evaluated after RK3's second stage is not stored (FusedSubstep::store_G)
 static int g_skip_stage_pressure = 1;   // RK3 stages 1, 2: pNHS of the stage is not stored (overwritten by the next stage before anything can read it)
 static int g_split_solve = 1;            // model time-step: split (x, y) transforms + pressure correction from the dense solution (see ocn_poisson_s::split)
 static int g_dist_substructured = 1;   // distributed FFT solver (z Periodic): substructured x solve + one small all-gather instead of two all-to-alls    // FFT solver, z Periodic, Nz = 2^m <= 1024: z transform + divide + inverse z transform in one pass
@@ -2528,6 +2529,7 @@ extern "C" int ocn_set_option(const char *key, int value) {
     if (!strcmp(key, "epilogue_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "epilogue_kchunk must be >= 0 (0 = automatic)"); g_epilogue_kchunk = value; return OCN_OK; }
     if (!strcmp(key, "split_solve")) { g_split_solve = value; return OCN_OK; }
     if (!strcmp(key, "skip_stage_pressure")) { g_skip_stage_pressure = value; return OCN_OK; }
+    if (!strcmp(key, "skip_dead_tendency_store")) { g_skip_dead_tendency_store = value; return OCN_OK; }
     if (!strcmp(key, "fused_kchunk")) { if (value < 0) return fail(OCN_EINVAL, "fused_kchunk must be >= 0 (0 = automatic)"); g_fused_kchunk = value; return OCN_OK; }
     return fail(OCN_EINVAL, "unknown option %s", key);
 }
@@ -2575,6 +2577,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
         for (int t = 0; t < m->ntr; ++t) a.kappa_e[t] = make_view(g, m->kappa_e[t], LOC_C);
     }
     a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
+    a.store_G = !sub || sub->store_G;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
     // compute_flux_bc_tendencies! belongs to the stage that FOLLOWS (runge_kutta_3.jl:118,134,150: called right before rk3_substep!), not to
     // update_state!: the conditions are folded in only when that stage's substep rides along; otherwise G stays without them and the
@@ -2618,6 +2621,11 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
                 while (kchunk > 8 && (long)bx * by * ((nk + kchunk - 1) / kchunk) * g_epilogue_rows < 8192) kchunk = (kchunk + 1) / 2;
             }
             const dim3 mg(bx, by, (nk + kchunk - 1) / kchunk), mb(64, g_epilogue_rows);
+            int mask = 0;                 // sides that carry a Flux condition: epilogue_flux_shell_kernel re-does their cells from the STORED tendency
+            for (int f = 0; f < m->nf; ++f)
+                for (int sd = 0; sd < 6; ++sd)
+                    if ((a.any_flux && a.has_flux[f][sd]) || (with_flux && m->lin[f][sd].on)) mask |= 1 << sd;
+            if (mask) a.store_G = true;
 #define OCN_EPM(COR, BUOY, CLO, NTR) hipLaunchKernelGGL((tendency_epilogue_march_kernel<COR, BUOY, CLO, NTR>), mg, mb, 0, g_stream, g, a, R, kchunk)
 #define OCN_EPM_N(COR, BUOY, CLO) do { if (m->ntr == 2) OCN_EPM(COR, BUOY, CLO, 2); else if (m->ntr == 1) OCN_EPM(COR, BUOY, CLO, 1); else OCN_EPM(COR, BUOY, CLO, 0); } while (0)
 #define OCN_EPM_CLO(COR, BUOY) do { if (clo == 2) OCN_EPM_N(COR, BUOY, 2); else OCN_EPM_N(COR, BUOY, 1); } while (0)
@@ -2627,10 +2635,6 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
 #undef OCN_EPM_N
 #undef OCN_EPM
             KERNEL_CHECK();
-            int mask = 0;
-            for (int f = 0; f < m->nf; ++f)
-                for (int sd = 0; sd < 6; ++sd)
-                    if ((a.any_flux && a.has_flux[f][sd]) || (with_flux && m->lin[f][sd].on)) mask |= 1 << sd;
             if (mask) {
                 SideList sl;
                 sl.n = 0;
@@ -3048,6 +3052,7 @@ static int rk3_time_step(ocn_model_s *m, double dt) {
         if (stage < 2 && (rc = cache_previous_tendencies(m))) return rc;
         if (stage < 2 && can_fuse) {
             FusedSubstep sub{m->U2, m->Gm, dt, gam[stage + 1], zet[stage + 1], 1};
+            sub.store_G = stage != 1 || !g_skip_dead_tendency_store;        // G(U²): read by the third stage's substep only
             if ((rc = update_state(m, true, &sub))) return rc;
             for (int f = 0; f < m->nf; ++f) std::swap(m->U[f], m->U2[f]);
             substep_done = true;

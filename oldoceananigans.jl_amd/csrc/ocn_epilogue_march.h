@@ -155,7 +155,7 @@ __global__ void __launch_bounds__(512) tendency_epilogue_march_kernel(DGrid g, E
                 const Range6 &r = a.r[f];
                 if (out_lane && i >= r.i0 && i <= r.i1 && j >= r.j0 && j <= r.j1 && k >= r.k0 && k <= r.k1) {
                     const double G = Gout[f];
-                    a.Gn[f][qf[f]] = G;
+                    if (a.store_G) a.Gn[f][qf[f]] = G;
                     if (a.substep) {
                         double Uv = f == 0 ? u_m : (f == 1 ? v_m : (f == 2 ? w_m : c_m[f >= 3 ? f - 3 : 0]));      // the field at (i, j, k): still the "level below"
                         if (a.has_zeta) Uv += a.dt * (a.gamma * G + a.zeta * Gmin[f]);

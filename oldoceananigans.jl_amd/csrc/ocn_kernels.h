@@ -736,6 +736,7 @@ struct EpilogueArgs {
     double *Un[OCN_MAX_FIELDS];
     Range6 r[OCN_MAX_FIELDS];
     bool has_coriolis, has_buoyancy, substep, has_zeta;
+    bool store_G;                               // false: the completed tendency feeds the substep riding along and nothing else (FusedSubstep::store_G)
     double fcor, nu, kappa[OCN_MAX_FIELDS], dt, gamma, zeta;
     bool amd;                                   // eddy coefficients from arrays (AnisotropicMinimumDissipation)
     FView nu_e, kappa_e[OCN_MAX_FIELDS];
@@ -825,7 +826,7 @@ __global__ void __launch_bounds__(256) tendency_epilogue_kernel(DGrid g, Epilogu
             G = (G - closure_divergence<F_C>(g, a.u, a.v, a.w, a.c[f - 3], kap, i, j, k, VAR, a.kappa_e[f - 3])) + 0.0;
     }
     G = epilogue_flux_conditions(g, a, f, i, j, k, q, G);
-    a.Gn[f][q] = G;
+    if (a.store_G) a.Gn[f][q] = G;
     if (a.substep) {
         double Uv = fv.p[q];
         if (a.has_zeta) Uv += a.dt * (a.gamma * G + a.zeta * a.Gm[f][q]);

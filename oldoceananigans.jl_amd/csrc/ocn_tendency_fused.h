@@ -386,6 +386,10 @@ struct FusedSubstep {
     const double *const *Gm;
     double dt, gamma, zeta;
     int has_zeta;
+    // false on the evaluation that follows RK3's SECOND stage: G(U²) is consumed by the third stage's substep riding along and by nothing
+    // else -- no cache_previous_tendencies! follows the third stage (runge_kutta_3.jl:150-166) and the closing update_state! overwrites Gⁿ
+    // -- so the kernels that carry that substep do not store it (after a time-step Gⁿ = G(U³), G⁻ = G(U¹), as in the reference)
+    bool store_G = true;
 };
 
 static inline int launch_fused_tendency(const DGrid &g, hipStream_t stream, const double *u, const double *v, const double *w,

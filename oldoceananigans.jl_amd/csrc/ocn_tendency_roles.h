@@ -51,6 +51,7 @@ struct RoleArgs {
     int wk0;                   // first level whose w tendency is stored (exclude_periphery on Bounded z)
     int kchunk, ntile_x, ntile, npair, band;
     int has_zeta;
+    int store_G;               // 0: the tendency is consumed by the fused substep only (FusedSubstep::store_G)
     double dt, gamma, zeta;
 };
 
@@ -271,6 +272,7 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     // no zeta: loaded and not used), next-stage field out
     const Rsrc rG = make_rsrc(a.G[fidx] + sh), rUn = make_rsrc((SUB ? a.Un[fidx] : a.G[fidx]) + sh), rGm = make_rsrc((SUB ? a.Gm[fidx] : a.G[fidx]) + sh);
     const unsigned cell_off = cell_r ? 0u : ROLE_OOB;
+    const unsigned g_oob = (SUB && !a.store_G) ? ROLE_OOB : 0u;
 
     double fz_prev = 0, qn = 0, gmn = 0;
     double qnn = 0, gmnn = 0;                         // OCN_ROLE_PF == 2: the same streams one more plane ahead
@@ -361,7 +363,7 @@ __device__ __forceinline__ void role_march(const DGrid &g, const Args &a, const 
     };
     auto stores = [&]() {
         const unsigned st = o.c | (store ? 0u : ROLE_OOB);
-        stb<24>(rG, st, (OCN_ROLE_ABLATE & 64) ? s2 * 3u : p.so - s2, Gn);                             // level k - 1
+        stb<24>(rG, st | g_oob, (OCN_ROLE_ABLATE & 64) ? s2 * 3u : p.so - s2, Gn);                     // level k - 1 (dropped by the hardware when nothing reads it)
         if (SUB) stb<24>(rUn, st, (OCN_ROLE_ABLATE & 64) ? s2 * 3u : p.so - s2, Uv);
     };
 
@@ -510,6 +512,7 @@ static int launch_roles_n(const DGrid &g, hipStream_t stream, const double *u, c
     a.U[0] = u; a.U[1] = v; a.U[2] = w; a.G[0] = Gu; a.G[1] = Gv; a.G[2] = Gw;
     for (int t = 0; t < NTR; ++t) { a.U[3 + t] = tr[t]; a.G[3 + t] = Gc[t]; }
     a.has_zeta = sub ? sub->has_zeta : 0;
+    a.store_G = (sub && !sub->store_G) ? 0 : 1;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
     for (int f = 0; f < NF; ++f) { a.Un[f] = sub ? sub->Un[f] : nullptr; a.Gm[f] = sub ? sub->Gm[f] : nullptr; }
     const int Px = g.Nx + 2 * g.Hx, Py = g.Ny + 2 * g.Hy;

@@ -1545,3 +1545,41 @@ def test_stage_pressures_that_nothing_can_read_are_not_stored(ocn, arch, topolog
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
     assert np.abs(outs[0][-1][-1]).max() > 0
+
+
+@pytest.mark.parametrize("case", ["ppp", "ppb_amd_flux", "bbb_scalar"])
+def test_the_tendency_after_the_second_stage_is_not_stored_and_nobody_can_tell(ocn, arch, case):
+    """G(U²), evaluated after RK3's second stage, feeds the third stage's substep (riding along in the same kernel) and nothing else: no
+    cache_previous_tendencies! follows the third stage and the closing update_state! overwrites Gⁿ (runge_kutta_3.jl:150-166). The kernels
+    that carry that substep therefore do not store it (option skip_dead_tendency_store = 0 stores it). After each of three steps: fields, Gⁿ
+    (= G(U³)), G⁻ (= G(U¹)) and the pressure bit for bit."""
+    F = ocn.FieldBoundaryConditions
+    kw = {}
+    if case == "ppp":
+        grid = ocn.RectilinearGrid(arch, size=(70, 12, 16), extent=(1, 1, 1))
+    elif case == "ppb_amd_flux":
+        grid = ocn.RectilinearGrid(arch, size=(40, 12, 14), x=(0, 1), y=(0, 1), z=tanh_faces(14), topology=(ocn.Periodic, ocn.Periodic, ocn.Bounded))
+        kw = dict(closure=ocn.AnisotropicMinimumDissipation(), buoyancy=ocn.SeawaterBuoyancy(), coriolis=ocn.FPlane(f=0.3),
+                  boundary_conditions={"u": F(top=ocn.FluxBoundaryCondition(-1e-3)),
+                                       "S": F(top=ocn.FluxBoundaryCondition(ocn.LinearFieldFlux(b=-2.5e-3), field_dependencies="S"))})
+    else:
+        grid = ocn.RectilinearGrid(arch, size=(20, 11, 9), extent=(1, 1, 1), topology=(ocn.Bounded,) * 3)
+        kw = dict(closure=ocn.ScalarDiffusivity(ν=2e-3, κ=1e-3))
+    outs = []
+    for skip in (1, 0):
+        ocn.set_option("skip_dead_tendency_store", skip)
+        try:
+            model = ocn.NonhydrostaticModel(grid=grid, tracers=("T", "S"), **kw)
+            ocn.set_model(model, **smooth_state({n: grid.nodes(f.loc) for n, f in model.fields().items()}, 31))
+            per_step = []
+            for _ in range(3):
+                ocn.time_step(model, 1e-3)
+                per_step.append([f.parent() for f in model.fields().values()] + [model.tendency(n).parent() for n in model.fields()] +
+                                [model.tendency(n, previous=True).parent() for n in model.fields()] + [model.pressures.pNHS.parent()])
+            outs.append(per_step)
+            model.close()
+        finally:
+            ocn.set_option("skip_dead_tendency_store", 1)
+    for a, b in zip(outs[0], outs[1]):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
