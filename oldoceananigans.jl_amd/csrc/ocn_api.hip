@@ -2578,6 +2578,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
     }
     a.substep = sub != nullptr; a.has_zeta = sub && sub->has_zeta;
     a.store_G = !sub || sub->store_G;
+    a.store_sides = 0;
     a.dt = sub ? sub->dt : 0.0; a.gamma = sub ? sub->gamma : 0.0; a.zeta = sub ? sub->zeta : 0.0;
     // compute_flux_bc_tendencies! belongs to the stage that FOLLOWS (runge_kutta_3.jl:118,134,150: called right before rk3_substep!), not to
     // update_state!: the conditions are folded in only when that stage's substep rides along; otherwise G stays without them and the
@@ -2625,7 +2626,7 @@ static int tendency_epilogue(ocn_model_s *m, const FusedSubstep *sub) {
             for (int f = 0; f < m->nf; ++f)
                 for (int sd = 0; sd < 6; ++sd)
                     if ((a.any_flux && a.has_flux[f][sd]) || (with_flux && m->lin[f][sd].on)) mask |= 1 << sd;
-            if (mask) a.store_G = true;
+            a.store_sides = mask;         // (a tendency that is not stored otherwise still is on those sides)
 #define OCN_EPM(COR, BUOY, CLO, NTR) hipLaunchKernelGGL((tendency_epilogue_march_kernel<COR, BUOY, CLO, NTR>), mg, mb, 0, g_stream, g, a, R, kchunk)
 #define OCN_EPM_N(COR, BUOY, CLO) do { if (m->ntr == 2) OCN_EPM(COR, BUOY, CLO, 2); else if (m->ntr == 1) OCN_EPM(COR, BUOY, CLO, 1); else OCN_EPM(COR, BUOY, CLO, 0); } while (0)
 #define OCN_EPM_CLO(COR, BUOY) do { if (clo == 2) OCN_EPM_N(COR, BUOY, 2); else OCN_EPM_N(COR, BUOY, 1); } while (0)

@@ -155,7 +155,10 @@ __global__ void __launch_bounds__(512) tendency_epilogue_march_kernel(DGrid g, E
                 const Range6 &r = a.r[f];
                 if (out_lane && i >= r.i0 && i <= r.i1 && j >= r.j0 && j <= r.j1 && k >= r.k0 && k <= r.k1) {
                     const double G = Gout[f];
-                    if (a.store_G) a.Gn[f][qf[f]] = G;
+                    const int ms = a.store_sides;
+                    const bool on_side = ms && (((ms & 1) && i == 1) || ((ms & 2) && i == g.Nx) || ((ms & 4) && j == 1) || ((ms & 8) && j == g.Ny) ||
+                                                ((ms & 16) && k == 1) || ((ms & 32) && k == g.Nz));
+                    if (a.store_G || on_side) a.Gn[f][qf[f]] = G;
                     if (a.substep) {
                         double Uv = f == 0 ? u_m : (f == 1 ? v_m : (f == 2 ? w_m : c_m[f >= 3 ? f - 3 : 0]));      // the field at (i, j, k): still the "level below"
                         if (a.has_zeta) Uv += a.dt * (a.gamma * G + a.zeta * Gmin[f]);

@@ -737,6 +737,7 @@ struct EpilogueArgs {
     Range6 r[OCN_MAX_FIELDS];
     bool has_coriolis, has_buoyancy, substep, has_zeta;
     bool store_G;                               // false: the completed tendency feeds the substep riding along and nothing else (FusedSubstep::store_G)
+    int store_sides;                            // ... except on these sides (bit = side): epilogue_flux_shell_kernel re-does their cells from the stored value
     double fcor, nu, kappa[OCN_MAX_FIELDS], dt, gamma, zeta;
     bool amd;                                   // eddy coefficients from arrays (AnisotropicMinimumDissipation)
     FView nu_e, kappa_e[OCN_MAX_FIELDS];
