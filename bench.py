@@ -488,7 +488,13 @@ def main():
     ms = 1e3 * elapsed / args.steps
     value = cells * args.steps / elapsed
     t_launch = 1e-3 * tend_ms / max(tend_n, 1)
-    bytes_per_cell = TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * fused_substep
+    # bytes the tendency launches of a time-step move, averaged over the three: 80 B/cell each; + 80 on the two that carry the next stage's
+    # substep (only when it rides in the advection kernel itself: with physics it rides in the epilogue pass); - 40 on the second of those,
+    # whose tendency G(U2) feeds that substep only and is not stored (option skip_dead_tendency_store)
+    in_kernel = model.get_option("substep_in_tendency_kernel") == 1
+    dead_store_skipped = in_kernel and model.get_option("skip_dead_tendency_store") == 1
+    bytes_per_cell = (TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * in_kernel
+                      - (1.0 / 3.0) * 40.0 * dead_store_skipped)
     cells_per_gpu = cells / world
     achieved = bytes_per_cell * cells_per_gpu / t_launch / 1e9 if tend_n else None
     traffic, traffic_path = measured_traffic(args.tendency_impl, N) if world == 1 and args.workload == "ppp" else (None, None)
@@ -542,7 +548,9 @@ def main():
                      "traffic_source": (os.path.relpath(traffic_path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)") if traffic else None,
                      "algorithmic_bytes_per_launch": bytes_per_cell * cells_per_gpu,
                      "algorithmic_bytes_note": ("average over the 3 launches of a time-step: 80 B/cell (tendencies) + 80 B/cell on the 2 "
-                                                "launches that carry the fused RK3 substep of the next stage") if fused_substep
+                                                "launches that carry the fused RK3 substep of the next stage" +
+                                                (" - 40 B/cell on the second of them (its tendency feeds that substep only and is not stored)"
+                                                 if dead_store_skipped else "")) if in_kernel
                      else "80 B/cell: 5 fields read + 5 tendencies written",
                      "valu": measured_valu(args.tendency_impl, N, t_launch, arithmetic_active) if world == 1 and args.workload == "ppp" else None,
                      "avg_launch_ms": 1e3 * t_launch, "launches_timed": tend_n,

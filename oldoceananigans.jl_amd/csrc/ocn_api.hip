@@ -2690,6 +2690,11 @@ extern "C" int ocn_model_get_option(ocn_model_t m, const char *key, int *value) 
     if (!strcmp(key, "graph_failures")) { *value = m->graph_failures; return OCN_OK; }
     if (!strcmp(key, "fuse_substep")) { *value = m->fuse_substep; return OCN_OK; }
     if (!strcmp(key, "fuse_substep_active")) { *value = can_fuse_substep(m) ? 1 : 0; return OCN_OK; }
+    // what the tendency LAUNCH itself carries (bench.py prices its bytes with these): the next stage's substep rides in the advection kernel
+    // only without physics / Flux conditions (with them it rides in the epilogue pass); the tendency of the second stage is then not stored
+    if (!strcmp(key, "substep_in_tendency_kernel")) { *value = (can_fuse_substep(m) && !epilogue_runs(m)) ? 1 : 0; return OCN_OK; }
+    if (!strcmp(key, "skip_dead_tendency_store")) { *value = g_skip_dead_tendency_store; return OCN_OK; }
+    if (!strcmp(key, "skip_stage_pressure")) { *value = g_skip_stage_pressure; return OCN_OK; }
     if (!strcmp(key, "arithmetic")) { *value = g_arithmetic; return OCN_OK; }
     if (dist_model_get_option(m, key, value) == OCN_OK) return OCN_OK;
     if (!strcmp(key, "fused_tendency_active")) { *value = fused_path(m->grid->d, nullptr, m->ntr, m->tendency_impl) ? 1 : 0; return OCN_OK; }
