@@ -466,6 +466,8 @@ def main():
     fastest = float(np.min(samples)) if samples else None
     div = ocn.max_abs_divergence(model)
     fused_substep = model.get_option("fuse_substep_active") == 1
+    in_kernel = model.get_option("substep_in_tendency_kernel") == 1           # (read here: a partitioned model is closed before the line is built)
+    dead_store_skipped = in_kernel and model.get_option("skip_dead_tendency_store") == 1
     arithmetic_active = model.get_option("arithmetic")
 
     communicator = None
@@ -491,8 +493,6 @@ def main():
     # bytes the tendency launches of a time-step move, averaged over the three: 80 B/cell each; + 80 on the two that carry the next stage's
     # substep (only when it rides in the advection kernel itself: with physics it rides in the epilogue pass); - 40 on the second of those,
     # whose tendency G(U2) feeds that substep only and is not stored (option skip_dead_tendency_store)
-    in_kernel = model.get_option("substep_in_tendency_kernel") == 1
-    dead_store_skipped = in_kernel and model.get_option("skip_dead_tendency_store") == 1
     bytes_per_cell = (TENDENCY_BYTES_PER_CELL + (2.0 / 3.0) * FUSED_SUBSTEP_EXTRA_BYTES_PER_CELL * in_kernel
                       - (1.0 / 3.0) * 40.0 * dead_store_skipped)
     cells_per_gpu = cells / world

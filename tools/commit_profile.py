@@ -3,7 +3,7 @@ profiles carry (command, bench line of the same run):  python tools/commit_profi
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, out, cmd = sys.argv[1], sys.argv[2], sys.argv[3]
-f = glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+f = max(glob.glob(os.path.join(ROOT, "gpurun_out", tag + "_stats", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)   # the newest collection
 line = None
 for ln in open(os.path.join(ROOT, "gpurun_out", tag + "_stats.log")):
     if ln.startswith('{"metric"'):
