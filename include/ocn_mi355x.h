@@ -283,11 +283,14 @@ int ocn_model_destroy(ocn_model_t model);
  * pointer of the parent array and its location. Pointers stay valid for the model's lifetime and are stable at
  * time-step boundaries. */
 int ocn_model_field(ocn_model_t model, const char *name, double **ptr, int loc[3]);
-/* update_state!(model; compute_tendencies) (update_nonhydrostatic_model_state.jl:20-56) */
+/* update_state!(model; compute_tendencies) (update_nonhydrostatic_model_state.jl:20-56). As in the reference the tendencies it leaves carry
+ * no Flux-boundary-condition terms: compute_flux_bc_tendencies! belongs to the stage that follows (runge_kutta_3.jl:118,134,150). */
 int ocn_model_update_state(ocn_model_t model, int compute_tendencies);
 /* tail of set!(model; ...) after the interiors were written (set_nonhydrostatic_model.jl:44-57) */
 int ocn_model_set_finalize(ocn_model_t model, int enforce_incompressibility);
-/* time_step!(model, Δt) (runge_kutta_3.jl:93-170) */
+/* time_step!(model, Δt) (runge_kutta_3.jl:93-170). One call = the three stages; what it leaves is what the reference leaves: the fields,
+ * pNHS of the third stage, Gⁿ = G(U³) without Flux-condition terms, G⁻ = G(U¹). Intermediate values nothing can read from outside the call
+ * (pNHS of stages 1 and 2, the tendency of the second stage) are not stored: options "skip_stage_pressure", "skip_dead_tendency_store". */
 int ocn_model_time_step(ocn_model_t model, double dt);
 /* time_step!(model::AbstractModel{<:QuasiAdamsBashforth2TimeStepper}, Δt; euler) (TimeSteppers/quasi_adams_bashforth_2.jl:74-123;
  * SURVEY.md 8f.1): χ = 0.1 is the reference's default; a forward-Euler step is taken when Δt differs from clock.last_Δt (first
