@@ -402,6 +402,36 @@ def test_library_pencil_partition_matches_single_gpu(ocn, arch, partition, size,
         _compare(out, ref, r, None, size, offset=i0, joffset=j0)
 
 
+def test_seeded_random_pencil_and_wall_partitions_match_single_gpu(ocn, arch):
+    """eight seeded random partitions with pencils and / or walls in the partitioned directions: Partition(Rx, Ry) with Rx, Ry in 1 .. 3 (at most
+    six ranks share the card), x and y Periodic or Bounded at random, irregular local sizes (remainder on the last rank), one of the four
+    physics presets -- the transposing pencil solver on triply periodic regular cases, the gathered solve elsewhere --, three RK3 steps, 1e-12"""
+    _own_stream()
+    rng = np.random.default_rng(2718)
+    done = 0
+    while done < 8:
+        Rx, Ry = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        if Rx * Ry < 2 or Rx * Ry > 6:
+            continue
+        nx = Rx * int(rng.integers(7, 13)) + (int(rng.integers(0, 3)) if Rx > 1 else 0)      # the last rank takes the remainder
+        ny = Ry * int(rng.integers(7, 11)) + (int(rng.integers(0, 3)) if Ry > 1 else 0)
+        nz = int(rng.integers(6, 11))
+        if Ry == 1:
+            ny += (-ny) % Rx                              # x-slabs: the reference's transposing solvers need Ny divisible by the rank count
+        zkind = str(rng.choice(["periodic", "bounded", "stretched", "amd"]))
+        xb, yb = bool(rng.random() < 0.4), bool(rng.random() < 0.4 and Ry > 1)
+        size = (nx, ny, nz)
+        results = _run_library_ranks(ocn, arch, Rx * Ry, size, 3, zkind, {}, xbounded=xb, ybounded=yb, partition=(Rx, Ry))
+        ref, time, _ = _single_gpu(ocn, arch, size, zkind, 3, xbounded=xb, ybounded=yb)
+        for r, (out, div, t, (i0, j0)) in enumerate(results):
+            assert div < 5e-8 and t == time, (done, (Rx, Ry), size, zkind, xb, yb)
+            try:
+                _compare(out, ref, r, None, size, offset=i0, joffset=j0)
+            except AssertionError as e:
+                raise AssertionError((done, (Rx, Ry), size, zkind, xb, yb, str(e)))
+        done += 1
+
+
 def test_library_transposing_solver_matches(ocn, arch):
     """the all-to-all form of the periodic solver (option dist_substructured = 0) through the library's orchestration"""
     _own_stream()
